@@ -1,0 +1,191 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- fp32 restatement of TDNet's per-frame hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.  The product
+package (tdnet_amd/) never does: it fails loudly when the HIP library is missing.
+
+What it is: a functional re-statement, written from scratch, of the reference's Testing/ model graph on
+torch CPU tensors (the reference's arithmetic lives in PyTorch -- SURVEY.md §8c -- so the faithful CPU
+restatement uses the same L0 ops: conv2d / batch-norm formula / bmm / softmax / layer_norm / interpolate).
+State is an explicit FIFO, weights are a flat {name: tensor} dict with the reference's state_dict keys.
+
+Pinning: tools/make_golden.py imports the real reference from /root/reference (this container only),
+loads the same synthetic weights, and stores per-stage outputs under tests/golden/; tests/test_oracle.py
+checks this file against those vectors.  Parity is pinned by those goldens (the reference has no tests).
+
+Every function cites the reference lines it follows (paths relative to /root/reference/Testing/model/pspnet).
+"""
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tdnet_amd import arch  # noqa: E402  (pure-python spec, no HIP)
+
+BN_EPS = 1e-5
+
+
+def bn_eval(x, sd, pre, leaky=False):
+    """Eval-mode BatchNorm2d followed by identity or LeakyReLU(0.01): td4_psp18.py:11-24."""
+    y = (x - sd[pre + ".running_mean"][None, :, None, None]) / torch.sqrt(sd[pre + ".running_var"][None, :, None, None] + BN_EPS)
+    y = y * sd[pre + ".weight"][None, :, None, None] + sd[pre + ".bias"][None, :, None, None]
+    return F.leaky_relu(y, 0.01) if leaky else y
+
+
+def basic_block(x, sd, pre, b):
+    """resnet.py:25-59: relu(bn1(conv1 x)) -> bn2(conv2 .) -> + (downsample x | x) -> relu."""
+    out = F.conv2d(x, sd[pre + ".conv1.weight"], None, b.stride, b.dil1, b.dil1)
+    out = F.relu(bn_eval(out, sd, pre + ".bn1"))
+    out = F.conv2d(out, sd[pre + ".conv2.weight"], None, 1, b.dil2, b.dil2)
+    out = bn_eval(out, sd, pre + ".bn2")
+    res = x
+    if b.downsample:
+        res = bn_eval(F.conv2d(x, sd[pre + ".downsample.0.weight"], None, b.stride), sd, pre + ".downsample.1")
+    return F.relu(out + res)
+
+
+def backbone(x, sd, pre, blocks):
+    """resnet.py:204-215: 7x7 s2 p3 stem, BN, ReLU, max-pool 3x3 s2 p1, layer1..4 -> c4."""
+    x = F.conv2d(x, sd[pre + ".conv1.weight"], None, 2, 3)
+    x = F.relu(bn_eval(x, sd, pre + ".bn1"))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for b in blocks:
+        x = basic_block(x, sd, "%s.%s" % (pre, b.name), b)
+    return x
+
+
+def pyramid_pooling(c4, sd, pre, path_num, pid):
+    """td4_psp18.py:271-284: 4 adaptive pools (1,2,3,6) -> 1x1 conv+BN+ReLU -> bilinear(align_corners) -> slice+concat."""
+    n, c, h, w = c4.shape
+    feats = []
+    for j, o in enumerate((1, 2, 3, 6), 1):
+        p = F.adaptive_avg_pool2d(c4, o)
+        p = F.relu(bn_eval(F.conv2d(p, sd["%s.conv%d.0.weight" % (pre, j)]), sd, "%s.conv%d.1" % (pre, j)))
+        feats.append(F.interpolate(p, (h, w), mode="bilinear", align_corners=True))
+    cs = c // path_num
+    fs = c // (path_num * 4)
+    parts = [c4[:, pid * cs:(pid + 1) * cs]] + [f[:, pid * fs:(pid + 1) * fs] for f in feats]
+    return torch.cat(parts, 1)
+
+
+def _conv_bias(x, sd, pre):
+    """ConvBNReLU with norm_layer=None is just a biased 1x1 conv: transformer.py:142-161."""
+    return F.conv2d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"])
+
+
+def _qk_branch(x, sd, pre):
+    """w_qs / w_ks: 1x1 conv(+bias) -> BN -> LeakyReLU(0.01) -> 1x1 conv(+bias): transformer.py:18-22."""
+    y = bn_eval(_conv_bias(x, sd, pre + ".0"), sd, pre + ".0.bn", leaky=True)
+    return _conv_bias(y, sd, pre + ".1")
+
+
+def _flat(x):
+    """[n,c,h,w] -> [n, h*w, c] (row-major positions): transformer.py:43-49."""
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).contiguous().view(n, h * w, c)
+
+
+def encoding(z, sd, pre, pre_flag):
+    """transformer.py:28-56.  pre=False -> (q [n,Lq,dk], v [n,dv,h,w]); pre=True -> stride-4 subsample, (q_,k_,v_) flat."""
+    if pre_flag:
+        zs = z[:, :, ::4, ::4]                      # MaxPool2d(kernel 1, stride 4): transformer.py:26,36
+        k_ = _flat(_qk_branch(zs, sd, pre + ".w_ks"))
+        v_ = _flat(_conv_bias(zs, sd, pre + ".w_vs.0"))
+        q_ = _flat(_qk_branch(zs, sd, pre + ".w_qs"))
+        return q_, k_, v_
+    v = _conv_bias(z, sd, pre + ".w_vs.0")
+    q = _flat(_qk_branch(z, sd, pre + ".w_qs"))
+    return q, v
+
+
+def attention(k_src, v_src, q_tgr, sd, pre, fea_size=None):
+    """transformer.py:71-92 + :126-139: softmax(q k^T / 8) v, then per-position fc (1x1 conv with bias)."""
+    dk = q_tgr.shape[-1]
+    attn = torch.bmm(q_tgr, k_src.transpose(1, 2)) / math.pow(dk, 0.5)
+    attn = torch.softmax(attn, dim=2)
+    out = torch.bmm(attn, v_src)                                    # [n, Lq, dv]
+    w = sd[pre + ".fc.0.conv.weight"][:, :, 0, 0]
+    out = out @ w.t() + sd[pre + ".fc.0.conv.bias"]
+    if fea_size is not None:
+        n, _, h, wd = fea_size
+        out = out.permute(0, 2, 1).contiguous().view(n, -1, h, wd)
+    return out
+
+
+def layer_norm_hw(x, sd, pre):
+    """td4_psp18.py:306-312: nn.LayerNorm([h,w]) -- each channel plane normalised, affine [h,w] shared over channels."""
+    return F.layer_norm(x, x.shape[-2:], sd[pre + ".ln.weight"], sd[pre + ".ln.bias"], 1e-5)
+
+
+def fcn_head(x, sd, pre):
+    """td4_psp18.py:287-302: conv3x3 p1 (no bias) -> BN -> ReLU -> Dropout2d(eval=id) -> conv1x1 (+bias)."""
+    y = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv5.0.weight"], None, 1, 1), sd, pre + ".conv5.1"))
+    return F.conv2d(y, sd[pre + ".conv5.4.weight"], sd[pre + ".conv5.4.bias"])
+
+
+class TDNetRef:
+    """Stateful per-frame forward: td4_psp18.py:123-229 / td2_psp50.py:98-155 (FIFO depth P-1, warm-up branch)."""
+
+    def __init__(self, spec, state_dict):
+        self.spec = spec
+        self.sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in state_dict.items()}
+        self.blocks = arch.backbone_blocks(spec.backbone)
+        self.Q, self.K, self.V = [], [], []
+        self.trace = None            # optional dict filled with stage outputs of the last frame
+
+    def reset(self):
+        self.Q, self.K, self.V = [], [], []
+
+    def _t(self, name, val):
+        if self.trace is not None:
+            self.trace[name] = val
+
+    def forward_lowres(self, img, pos_id):
+        sp, sd = self.spec, self.sd
+        p = pos_id + 1
+        c4 = backbone(img, sd, "pretrained%d" % p, self.blocks)
+        z = pyramid_pooling(c4, sd, "psp%d" % p, sp.psp_path_num, sp.pids[pos_id])
+        q_cur, v_cur = encoding(z, sd, "enc%d" % p, False)
+        self._t("c4", c4); self._t("z", z); self._t("q_cur", q_cur); self._t("v_cur", v_cur)
+        if len(self.Q) < sp.fifo:                                   # warm-up: td4_psp18.py:142-143
+            feat = v_cur
+        else:
+            names = sp.atn_names[pos_id]
+            if sp.name == "td4":                                     # td4_psp18.py:145-151
+                v2 = attention(self.K[0], self.V[0], self.Q[1], sd, names[0])
+                v3 = attention(self.K[1], v2 + self.V[1], self.Q[2], sd, names[1])
+                v4 = attention(self.K[2], v3 + self.V[2], q_cur, sd, names[2], fea_size=z.shape)
+                self._t("v2", v2); self._t("v3", v3); self._t("v4", v4)
+                feat = v4 + v_cur
+            else:                                                    # td2_psp50.py:120-122
+                v1 = attention(self.K[0], self.V[0], q_cur, sd, names[0], fea_size=z.shape)
+                self._t("v4", v1)
+                feat = v1 + v_cur
+        ln = layer_norm_hw(feat, sd, "layer_norm%d" % p)
+        out = fcn_head(ln, sd, "head%d" % p)
+        self._t("feat", feat); self._t("ln", ln); self._t("lowres", out)
+        q_, k_, v_ = encoding(z, sd, "enc%d" % p, True)              # td4_psp18.py:153-154
+        self._t("cache_q", q_); self._t("cache_k", k_); self._t("cache_v", v_)
+        self.Q.append(q_); self.K.append(k_); self.V.append(v_)
+        if len(self.Q) > sp.fifo:                                   # buffer_contral: td4_psp18.py:123-134
+            self.Q.pop(0); self.K.pop(0); self.V.pop(0)
+        return out
+
+    @torch.no_grad()
+    def forward(self, img, pos_id=0):
+        """td4_psp18.py:216-229: path dispatch, then bilinear align_corners upsample to the input size."""
+        h, w = img.shape[-2:]
+        out = self.forward_lowres(img, pos_id)
+        return F.interpolate(out, (h, w), mode="bilinear", align_corners=True)
+
+
+def confusion_miou(pred, ref, n_class):
+    """mIoU of `pred` against `ref` labels via the confusion-matrix formula of Training/ptsemseg/metrics.py:12-35."""
+    import numpy as np
+    pred = np.asarray(pred).reshape(-1); ref = np.asarray(ref).reshape(-1)
+    hist = np.bincount(n_class * ref.astype(np.int64) + pred.astype(np.int64), minlength=n_class ** 2).reshape(n_class, n_class)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+    return float(np.nanmean(iu)), hist

@@ -1,0 +1,140 @@
+"""Architecture description of the TDNet per-frame hot path (pure data, no torch).
+
+One place that states WHAT the reference builds, so the synthetic-weight generator, the CPU
+oracle, the C-ABI weight loader and the tests all agree on names and shapes.
+
+Reference (read-only, /root/reference):
+  * backbone layout ......... Testing/model/pspnet/resnet.py:114-202 (_make_layer, dilation / multi-grid rules)
+  * td4 wiring .............. Testing/model/pspnet/td4_psp18.py:70-116
+  * td2 wiring .............. Testing/model/pspnet/td2_psp50.py:70-89
+  * attention module order .. Testing/model/pspnet/td4_psp18.py:145-147,166-168,185-187,204-206
+"""
+from collections import namedtuple
+
+BlockSpec = namedtuple("BlockSpec", "name cin cout stride dil1 dil2 downsample")
+
+_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+
+def feat_size(n):
+    """Spatial size after the three stride-2 stages (stem conv, max-pool, layer2): n -> ((n-1)//2+1) x3."""
+    for _ in range(3):
+        n = (n - 1) // 2 + 1
+    return n
+
+
+def key_size(n):
+    """Size of the stride-4 key/value sub-sampling of a feature axis (transformer.py:26,36)."""
+    return (n - 1) // 4 + 1
+
+
+def backbone_blocks(backbone):
+    """BasicBlock list of the dilated, multi-grid ResNet used by TDNet (output stride 8).
+
+    resnet.py:138-149 -> layer1 (64, s1, d1), layer2 (128, s2, d1), layer3 (256, s1, dilation=2),
+    layer4 (512, s1, dilation=4, multi_grid -> block dilations 4, 8, 16); conv1 of a block uses `dilation`,
+    conv2 uses `previous_dilation` (resnet.py:32-37); the first block of layer3 uses dilation 1 (resnet.py:183-185).
+    """
+    if backbone not in _LAYERS:
+        raise ValueError("backbone must be resnet18 or resnet34 on the HIP path (BasicBlock); got %r" % (backbone,))
+    nb = _LAYERS[backbone]
+    blocks = []
+    inpl = 64
+    # (planes, blocks, stride, dilation, multi_grid)
+    for li, (planes, n, stride, dil, mg) in enumerate(
+            [(64, nb[0], 1, 1, False), (128, nb[1], 2, 1, False), (256, nb[2], 1, 2, False), (512, nb[3], 1, 4, True)], 1):
+        for b in range(n):
+            first = b == 0
+            if mg:
+                d1 = (4, 8, 16)[b]
+            elif first:
+                d1 = 1 if dil in (1, 2) else 2
+            else:
+                d1 = dil
+            ds = first and (stride != 1 or inpl != planes)
+            blocks.append(BlockSpec("layer%d.%d" % (li, b), inpl if first else planes, planes,
+                                    stride if first else 1, d1, dil, ds))
+        inpl = planes
+    return blocks
+
+
+ModelSpec = namedtuple("ModelSpec", "name path_num backbone d_model d_k d_v psp_path_num pids head_mid nclass fifo atn_names")
+
+
+def model_spec(name, nclass=19, backbone=None):
+    """name: 'td4' (td4_psp18.py) or 'td2' (td2_psp50.py with a BasicBlock backbone)."""
+    if name == "td4":
+        bb = backbone or "resnet18"
+        # td4_psp18.py:80-83 -> PyramidPooling(path_num=path_num//2, pid=0,1,0,1); :85-88 d_v = 512
+        atn = {0: ("atn1_2", "atn1_3", "atn1_4"), 1: ("atn2_3", "atn2_4", "atn2_1"),
+               2: ("atn3_4", "atn3_1", "atn3_2"), 3: ("atn4_1", "atn4_2", "atn4_3")}
+        return ModelSpec("td4", 4, bb, 512, 64, 512, 2, (0, 1, 0, 1), 512 // 4, nclass, 3, atn)
+    if name == "td2":
+        bb = backbone or "resnet18"
+        # td2_psp50.py:76-82 -> PyramidPooling(path_num=2, pid=0,1); d_v = 512*exp//4 = 128; head chn_down=2 (:88-89)
+        atn = {0: ("atn1",), 1: ("atn2",)}
+        return ModelSpec("td2", 2, bb, 512, 64, 128, 2, (0, 1), 128 // 2, nclass, 1, atn)
+    raise ValueError(name)
+
+
+def state_dict_shapes(spec, h, w):
+    """Ordered {key: shape} of the reference state_dict for this model at feature size h x w.
+
+    Mirrors the 728-tensor td4 / td2 checkpoints (names as produced by nn.Module registration order in
+    td4_psp18.py:70-116 / td2_psp50.py:70-89). `num_batches_tracked` entries have shape ().
+    """
+    out = {}
+
+    def bn(prefix, c):
+        out[prefix + ".weight"] = (c,)
+        out[prefix + ".bias"] = (c,)
+        out[prefix + ".running_mean"] = (c,)
+        out[prefix + ".running_var"] = (c,)
+        out[prefix + ".num_batches_tracked"] = ()
+
+    P = spec.path_num
+    for p in range(1, P + 1):
+        pre = "pretrained%d" % p
+        out[pre + ".conv1.weight"] = (64, 3, 7, 7)
+        bn(pre + ".bn1", 64)
+        for b in backbone_blocks(spec.backbone):
+            out["%s.%s.conv1.weight" % (pre, b.name)] = (b.cout, b.cin, 3, 3)
+            bn("%s.%s.bn1" % (pre, b.name), b.cout)
+            out["%s.%s.conv2.weight" % (pre, b.name)] = (b.cout, b.cout, 3, 3)
+            bn("%s.%s.bn2" % (pre, b.name), b.cout)
+            if b.downsample:
+                out["%s.%s.downsample.0.weight" % (pre, b.name)] = (b.cout, b.cin, 1, 1)
+                bn("%s.%s.downsample.1" % (pre, b.name), b.cout)
+        out[pre + ".fc.weight"] = (1000, 512)
+        out[pre + ".fc.bias"] = (1000,)
+    dm, dk, dv = spec.d_model, spec.d_k, spec.d_v
+    for p in range(1, P + 1):
+        for j in range(1, 5):
+            out["psp%d.conv%d.0.weight" % (p, j)] = (dm // 4, dm, 1, 1)
+            bn("psp%d.conv%d.1" % (p, j), dm // 4)
+    for p in range(1, P + 1):
+        for br in ("w_qs", "w_ks"):
+            out["enc%d.%s.0.conv.weight" % (p, br)] = (dk, dm, 1, 1)
+            out["enc%d.%s.0.conv.bias" % (p, br)] = (dk,)
+            bn("enc%d.%s.0.bn" % (p, br), dk)
+            out["enc%d.%s.1.conv.weight" % (p, br)] = (dk, dk, 1, 1)
+            out["enc%d.%s.1.conv.bias" % (p, br)] = (dk,)
+        out["enc%d.w_vs.0.conv.weight" % p] = (dv, dm, 1, 1)
+        out["enc%d.w_vs.0.conv.bias" % p] = (dv,)
+    if spec.name == "td4":
+        names = ["atn1_2", "atn1_3", "atn1_4", "atn2_1", "atn2_3", "atn2_4",
+                 "atn3_1", "atn3_2", "atn3_4", "atn4_1", "atn4_2", "atn4_3"]
+    else:
+        names = ["atn1", "atn2"]
+    for a in names:
+        out[a + ".fc.0.conv.weight"] = (dv, dv, 1, 1)
+        out[a + ".fc.0.conv.bias"] = (dv,)
+    for p in range(1, P + 1):
+        out["layer_norm%d.ln.weight" % p] = (h, w)
+        out["layer_norm%d.ln.bias" % p] = (h, w)
+    for p in range(1, P + 1):
+        out["head%d.conv5.0.weight" % p] = (spec.head_mid, dv, 3, 3)
+        bn("head%d.conv5.1" % p, spec.head_mid)
+        out["head%d.conv5.4.weight" % p] = (spec.nclass, spec.head_mid, 1, 1)
+        out["head%d.conv5.4.bias" % p] = (spec.nclass,)
+    return out

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (imported read-only from /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).  The only modification made
+to the reference objects is the one SURVEY.md §8c documents: `layer_normN` is re-created for the feature
+size of the input, because the shipped modules hard-code LayerNorm([97,193]) (td4_psp18.py:107-110).
+
+    python tools/make_golden.py            # writes tests/golden/
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/Testing")
+
+import torch  # noqa: E402
+from model.pspnet import td4_psp18 as ref_td4, td2_psp50 as ref_td2  # noqa: E402  (the reference itself)
+
+from tdnet_amd import arch, weights  # noqa: E402
+
+THREADS = 8
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def build_reference(name, backbone, H, W, seed):
+    spec = arch.model_spec(name, 19, backbone)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    if name == "td4":
+        m = ref_td4.td4_psp18(nclass=19, path_num=4, model_path=None, backbone=backbone)
+        LN = ref_td4.Layer_Norm
+    else:
+        m = ref_td2.td2_psp50(nclass=19, path_num=2, model_path=None, backbone=backbone)
+        LN = ref_td2.Layer_Norm
+    for i in range(1, spec.path_num + 1):
+        setattr(m, "layer_norm%d" % i, LN([h, w]))
+    sd = weights.synth_state_dict(spec, h, w, seed)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)   # proves key/shape parity
+    return spec, m.eval()
+
+
+def run_traced(spec, m, frames):
+    """Run the reference on `frames`, capturing stage outputs with forward hooks."""
+    per_frame = []
+    cur = {}
+
+    def hook(tag):
+        def f(mod, inp, out):
+            cur.setdefault(tag, []).append(out)
+        return f
+
+    hs = []
+    for p in range(1, spec.path_num + 1):
+        hs.append(getattr(m, "pretrained%d" % p).register_forward_hook(hook("c4")))
+        hs.append(getattr(m, "psp%d" % p).register_forward_hook(hook("z")))
+        hs.append(getattr(m, "enc%d" % p).register_forward_hook(hook("enc")))
+        hs.append(getattr(m, "layer_norm%d" % p).register_forward_hook(hook("ln")))
+        hs.append(getattr(m, "head%d" % p).register_forward_hook(hook("lowres")))
+    for names in spec.atn_names.values():
+        for a in names:
+            hs.append(getattr(m, a).register_forward_hook(hook("atn")))
+    with torch.no_grad():
+        for t, x in enumerate(frames):
+            cur.clear()
+            out = m(torch.from_numpy(x), pos_id=t % spec.path_num)
+            rec = {"c4": cur["c4"][0], "z": cur["z"][0], "ln": cur["ln"][0], "lowres": cur["lowres"][0], "logits": out}
+            (q_cur, v_cur), (cq, ck, cv) = cur["enc"]
+            rec.update(q_cur=q_cur, v_cur=v_cur, cache_q=cq, cache_k=ck, cache_v=cv)
+            if "atn" in cur:
+                a = cur["atn"]
+                rec["v4"] = a[-1]
+                if len(a) == 3:
+                    rec["v2"], rec["v3"] = a[0], a[1]
+            per_frame.append({k: v.detach().numpy().copy() for k, v in rec.items()})
+    for h in hs:
+        h.remove()
+    return per_frame
+
+
+def main():
+    torch.set_num_threads(THREADS)
+    os.makedirs(OUT, exist_ok=True)
+    meta = "torch %s, threads %d" % (torch.__version__, THREADS)
+
+    # ---- small, fully traced cases (every stage boundary) -------------------------------------------------
+    cases = [("td4", "resnet18", 33, 65, 6, True), ("td2", "resnet18", 33, 65, 4, True),
+             ("td2", "resnet34", 33, 65, 3, False), ("td4", "resnet18", 65, 129, 6, False),
+             ("td2", "resnet18", 49, 81, 3, False)]
+    for name, bb, H, W, T, full in cases:
+        spec, m = build_reference(name, bb, H, W, seed=0)
+        frames = weights.synth_video(H, W, T, seed=1)
+        rec = run_traced(spec, m, frames)
+        arrs = {}
+        for t, r in enumerate(rec):
+            keep = r.keys() if full else ("lowres", "logits", "cache_k", "ln")
+            for k in keep:
+                if k in r:
+                    arrs["f%d_%s" % (t, k)] = r[k].astype(np.float32)
+        fn = os.path.join(OUT, "%s_%s_%dx%d.npz" % (name, bb, H, W))
+        np.savez_compressed(fn, __meta__=np.array(meta), **arrs)
+        print("wrote", fn, "%.1f MB" % (os.path.getsize(fn) / 1e6))
+
+    # ---- full-size digests (statistics + strided samples only) --------------------------------------------
+    digests = {}
+    for name, bb, H, W, T in [("td2", "resnet18", 512, 1024, 4), ("td4", "resnet18", 1024, 2048, 6),
+                              ("td4", "resnet18", 769, 1537, 5), ("td2", "resnet34", 720, 960, 3)]:
+        spec, m = build_reference(name, bb, H, W, seed=0)
+        frames = weights.synth_video(H, W, T, seed=1)
+        with torch.no_grad():
+            for t, x in enumerate(frames):
+                out = m(torch.from_numpy(x), pos_id=t % spec.path_num).numpy()
+        lab = out[0].argmax(0)
+        tag = "%s_%s_%dx%d" % (name, bb, H, W)
+        top2 = np.sort(out[0], axis=0)[-2:]
+        gap = top2[1] - top2[0]
+        digests[tag + "_last_frame"] = np.array(T - 1)
+        digests[tag + "_stats"] = np.array([out.min(), out.max(), out.mean(), np.sqrt((out.astype(np.float64) ** 2).sum())], dtype=np.float64)
+        digests[tag + "_sample"] = out[0, :, ::61, ::67].astype(np.float32)
+        digests[tag + "_labels_sample"] = lab[::61, ::67].astype(np.int16)
+        digests[tag + "_gap_hist"] = np.array([(gap < 1e-4).sum(), (gap < 1e-3).sum(), gap.size], dtype=np.int64)
+        digests[tag + "_label_sha256"] = np.array(hashlib.sha256(lab.astype(np.uint8).tobytes()).hexdigest())
+        print(tag, digests[tag + "_stats"], digests[tag + "_gap_hist"])
+    fn = os.path.join(OUT, "fullsize_digests.npz")
+    np.savez_compressed(fn, __meta__=np.array(meta), **digests)
+    print("wrote", fn)
+
+
+if __name__ == "__main__":
+    main()
