@@ -1,0 +1,105 @@
+/*
+ * tdnet.h -- C ABI of the MI355X-native TDNet per-frame inference hot path (libtdnet_hip.so).
+ *
+ * The reference's boundary for this path is a Python nn.Module API, not a C API:
+ *     model = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=...)      Testing/test.py:26
+ *     out   = model(image, pos_id=i % path_num)                               Testing/test.py:53
+ * tdnet_amd/model/{td4_psp18,td2_psp50}.py keep that Python API and call the entry points below through
+ * ctypes; INTEGRATION.md shows the stub.  Plain pointers and sizes only -- no torch types cross this line.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; tdnet_last_error() gives the message (thread-local).
+ *   - "dev" pointers are device (HBM) pointers owned by the caller; the handle owns weights, workspace and
+ *     the K/Q/V FIFO.  One handle per video stream and per GPU; a handle is not thread-safe.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
+ *   - all tensors are fp32.  Image in / logits out are NCHW like the reference; internal layout is NHWC.
+ */
+#ifndef TDNET_H
+#define TDNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tdnet tdnet_t;
+
+typedef struct tdnet_cfg {
+    int32_t model;      /* 4 = td4 (Testing/model/pspnet/td4_psp18.py:29-120), 2 = td2 (td2_psp50.py:29-96)        */
+    int32_t backbone;   /* 18 or 34 (BasicBlock ResNets, resnet.py:218-236)                                         */
+    int32_t nclass;     /* 19 for Cityscapes (test.py:26)                                                            */
+    int32_t height;     /* input H; the LayerNorm affine is [ceil(H/8), ceil(W/8)] (td4_psp18.py:107-110)            */
+    int32_t width;      /* input W                                                                                   */
+    int32_t device;     /* HIP device ordinal                                                                        */
+} tdnet_cfg;
+
+/* ---- lifecycle: replaces the nn.Module constructor + load_state_dict (td4_psp18.py:32-120, :232-240) ---------- */
+int  tdnet_create(const tdnet_cfg* cfg, tdnet_t** out);
+void tdnet_destroy(tdnet_t* h);
+
+/* One call per state_dict entry, reference key names ("pretrained1.layer4.1.conv2.weight", ...), host fp32
+ * data in the reference's own layout (conv OIHW).  Unknown names and wrong sizes are errors (strict=True,
+ * td4_psp18.py:237); unused reference tensors (pretrainedN.fc.*, *.num_batches_tracked) are accepted and ignored. */
+int  tdnet_set_weight(tdnet_t* h, const char* name, const float* host, size_t count);
+/* Folds BN (fp64), repacks to the kernels' layouts, uploads.  Fails listing the first missing tensor.            */
+int  tdnet_finalize_weights(tdnet_t* h);
+
+/* ---- the hot path: replaces model(image, pos_id) (td4_psp18.py:216-229 / td2_psp50.py:146-155) ---------------- */
+/* img_nchw_dev [1,3,H,W] -> logits_nchw_dev [1,nclass,H,W].  Mutates the K/Q/V FIFO exactly like
+ * buffer_contral (td4_psp18.py:123-134): frames must arrive in order with pos_id = t mod path_num.              */
+int  tdnet_forward(tdnet_t* h, const float* img_nchw_dev, int pos_id, float* logits_nchw_dev, void* stream);
+/* argmax over classes with first-max tie-break = output.max(1)[1] (test.py:61); labels int32 [H,W].             */
+int  tdnet_argmax(tdnet_t* h, const float* logits_nchw_dev, int32_t* labels_dev, void* stream);
+/* forward + argmax without materialising the full-resolution logits (labels identical to the two calls above).  */
+int  tdnet_forward_labels(tdnet_t* h, const float* img_nchw_dev, int pos_id, int32_t* labels_dev, void* stream);
+/* Empties the FIFO (the reference never resets between clips; needed to feed a second clip).                     */
+int  tdnet_reset(tdnet_t* h);
+int  tdnet_fifo_len(const tdnet_t* h);
+
+/* ---- introspection for the parity tests ------------------------------------------------------------------------ */
+/* Copies an internal stage buffer of the LAST frame to host, converted to the reference's layout
+ * (NCHW for maps, [L,C] for q/k/v).  names: c4 z q_cur v_cur feat ln lowres cache_q cache_k cache_v.
+ * Returns the element count, or <0.                                                                              */
+long tdnet_get_stage(tdnet_t* h, const char* name, float* host, size_t capacity);
+/* Algorithmic FLOP (2*MAC, conv + attention matmuls) of one steady-state frame for this configuration.          */
+double tdnet_flops_per_frame(const tdnet_t* h);
+/* Device time of the dominant kernel family inside the last tdnet_forward (HIP events on the forward's stream):
+ * which: 0 = all conv/GEMM kernels, 1 = attention kernels, 2 = everything else, 3 = the dominant kernel only
+ * (the 128x128-tile 3x3 implicit-GEMM conv).  ms, <0 if profiling is off.                                        */
+int    tdnet_set_profiling(tdnet_t* h, int on);
+double tdnet_last_ms(const tdnet_t* h, int which);
+/* same selection: summed algorithmic FLOP / number of launches of that family in the last forward.              */
+double tdnet_last_flops(const tdnet_t* h, int which);
+double tdnet_last_launches(const tdnet_t* h, int which);
+
+const char* tdnet_last_error(void);
+const char* tdnet_version(void);
+
+/* ---- single-operator entry points (used by tests/ to check each kernel family against torch fp32) -------------- */
+/* NHWC conv: in [H,W,Cin] dev, weight OIHW host [Cout,Cin,KS,KS], bias host [Cout] or NULL, residual dev
+ * [Ho,Wo,Cout] or NULL, act 0 none / 1 ReLU / 2 LeakyReLU(0.01); out [Ho,Wo,Cout] dev.                           */
+int tdnet_op_conv2d(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
+                    int Cout, int KS, int stride, int dil, const float* resid_dev, int act, float* out_dev, void* stream);
+/* the same with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64) -- lets tests cover every variant */
+int tdnet_op_conv2d_tile(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
+                         int Cout, int KS, int stride, int dil, const float* resid_dev, int act, int tile,
+                         float* out_dev, void* stream);
+/* stem: NCHW image [3,H,W] -> conv7x7 s2 p3 (+bias) -> ReLU -> maxpool3x3 s2 p1 -> NHWC [H2,W2,64] (resnet.py:205-208) */
+int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const float* bias_host, float* out_dev, void* stream);
+/* softmax(q k^T / sqrt(dk)) v' + bias + resid: q [Lq,64], k [Lk,64], vp [Lk,DV], bias dev [DV]|NULL, resid [Lq,DV]|NULL */
+int tdnet_op_attention(const float* q_dev, const float* k_dev, const float* vp_dev, const float* bias_dev,
+                       const float* resid_dev, int Lq, int Lk, int DV, float* out_dev, void* stream);
+/* LayerNorm over the (h,w) plane of every channel, affine g,b [h*w] shared by channels (td4_psp18.py:306-312); NHWC */
+int tdnet_op_layernorm_hw(const float* x_dev, int HW, int C, const float* g_dev, const float* b_dev, float* out_dev, void* stream);
+/* PPM (td4_psp18.py:271-284): c4 NHWC [h,w,512] -> z NHWC [h,w,512]; w_host: 4 folded [128,512] matrices, b_host 4x[128] */
+int tdnet_op_ppm(const float* c4_dev, int h, int w, const float* w_host, const float* b_host, int path_num, int pid,
+                 float* z_dev, void* stream);
+/* bilinear align_corners=True (td4_psp18.py:227): planar [C,h,w] -> [C,H,W]                                       */
+int tdnet_op_upsample(const float* in_dev, int C, int h, int w, int H, int W, float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""ctypes binding of include/tdnet.h (libtdnet_hip.so).
+
+The HIP library is the product: importing a model fails loudly when it is missing -- there is no CPU or
+torch fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libtdnet_hip.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_void_p = ctypes.c_void_p
+
+
+class TdnetCfg(ctypes.Structure):
+    _fields_ = [("model", ctypes.c_int32), ("backbone", ctypes.c_int32), ("nclass", ctypes.c_int32),
+                ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("device", ctypes.c_int32)]
+
+
+class TdnetError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/tdnet.h declares
+SYMBOLS = {
+    "tdnet_create": (ctypes.c_int, [ctypes.POINTER(TdnetCfg), ctypes.POINTER(c_void_p)]),
+    "tdnet_destroy": (None, [c_void_p]),
+    "tdnet_set_weight": (ctypes.c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
+    "tdnet_finalize_weights": (ctypes.c_int, [c_void_p]),
+    "tdnet_forward": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "tdnet_argmax": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tdnet_forward_labels": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "tdnet_reset": (ctypes.c_int, [c_void_p]),
+    "tdnet_fifo_len": (ctypes.c_int, [c_void_p]),
+    "tdnet_get_stage": (ctypes.c_long, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
+    "tdnet_flops_per_frame": (ctypes.c_double, [c_void_p]),
+    "tdnet_set_profiling": (ctypes.c_int, [c_void_p, ctypes.c_int]),
+    "tdnet_last_ms": (ctypes.c_double, [c_void_p, ctypes.c_int]),
+    "tdnet_last_flops": (ctypes.c_double, [c_void_p, ctypes.c_int]),
+    "tdnet_last_launches": (ctypes.c_double, [c_void_p, ctypes.c_int]),
+    "tdnet_last_error": (ctypes.c_char_p, []),
+    "tdnet_version": (ctypes.c_char_p, []),
+    "tdnet_op_conv2d": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "tdnet_op_conv2d_tile": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int,
+                                            c_void_p, c_void_p]),
+    "tdnet_op_stem": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tdnet_op_attention": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, c_void_p, c_void_p]),
+    "tdnet_op_layernorm_hw": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tdnet_op_ppm": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
+                                    c_void_p, c_void_p]),
+    "tdnet_op_upsample": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         c_void_p, c_void_p]),
+}
+
+
+class Lib:
+    """A loaded libtdnet shared object with typed entry points; `check()` turns return codes into TdnetError."""
+
+    def __init__(self, path=DEFAULT_LIB):
+        if not os.path.exists(path):
+            raise TdnetError("HIP library not found: %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self.dll = ctypes.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(self.dll, name)              # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def check(self, rc):
+        if rc is not None and rc < 0:
+            raise TdnetError(self.tdnet_last_error().decode())
+        return rc
+
+
+_default = None
+
+
+def lib():
+    """The product library (in-tree libtdnet_hip.so), loaded once."""
+    global _default
+    if _default is None:
+        _default = Lib(DEFAULT_LIB)
+    return _default

@@ -1,0 +1,193 @@
+// td_attn.h -- fused attention-propagation kernel:  out = softmax(q k^T / sqrt(64)) v' + bias (+ resid)
+//
+// Reference: ScaledDotProductAttention (transformer.py:126-139: bmm, /8, softmax over keys, bmm) followed by the
+// per-position fc of Attention.forward (transformer.py:84-86).  The fc is linear, so (P v) W^T + b = P (v W^T) + b: the
+// host multiplies the (small, Lk-row) value matrix by W^T first (a 1x1 conv on the GEMM kernel) and this kernel consumes
+// v' = v W^T; for the final propagation step (Lq = 16 Lk) that removes 16/17 of the fc FLOPs.  The residual argument
+// fuses the "+ V_queue[i]" / "+ v_cur" adds of td4_psp18.py:146-151.
+//
+// The Lq x Lk score matrix is never materialised (the reference writes 268 MB of it per frame at 1024x2048).
+// Softmax is exact two-pass: pass 1 computes every query's row maximum (QK^T only, 1/9 of the MFMA work), pass 2
+// recomputes the scores, exponentiates against the final maximum and accumulates P V' -- no online rescaling.
+//
+// MFMA mapping (fp32, v_mfma_f32_32x32x2_f32), one wave = 32 queries x (32*NT) output channels:
+//   scores are computed TRANSPOSED, S^T = K Q^T (A = K tile, B = Q^T): lane (q = lane&31, half) then holds, in register
+//   r, the score of ITS query against key (r&3) + 8 (r>>2) + 4 half -- four consecutive keys per 4 registers, which is
+//   exactly one float4 of the P image the P V' MFMAs read back as their A operand.  Row max / row sum are per-lane
+//   register reductions plus ONE cross-half shuffle; no serial-lane softmax.
+//   A block is QW query tiles x CW channel groups of waves (QW*CW = 4).  The CW waves of a query tile split each
+//   super-tile of 32*CW keys between them for S^T, publish P through LDS (conflict-free float4 rows), and each
+//   accumulates its own 32*NT channels over all the keys.  V' rows are read straight from L2 into the B operand:
+//   lane j owns NT consecutive channels, so one global float4 feeds 4 MFMAs.
+#pragma once
+#include "td_device.h"
+#include "td_conv.h"   // td_ld4 / td_st4
+
+struct AttnArgs {
+    const float* q;      // [Lq][64]
+    const float* k;      // [Lk][64]
+    const float* vp;     // [Lk][DV]
+    const float* bias;   // [DV] or nullptr
+    const float* resid;  // [Lq][DV] or nullptr
+    float* out;          // [Lq][DV]
+    int Lq, Lk;
+    float scale_log2e;   // log2(e) / sqrt(d_k)
+};
+
+template <int QW, int CW>
+struct AttnLds {
+    static constexpr int P_FLOATS = QW * (8 * CW) * 32 * 4;      // one super-tile of P: [qw][kq][q][4]
+    static constexpr int RED_FLOATS = QW * CW * 32;
+    static constexpr int BYTES = (2 * P_FLOATS + 2 * RED_FLOATS) * 4;
+};
+
+template <int QW, int CW, int NT>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
+    static_assert(QW * CW == 4, "4 waves per block");
+    static_assert(NT == 4, "lane owns one float4 of channels");
+    constexpr int DV = CW * NT * 32;
+    constexpr int SK = 32 * CW;                                  // keys per super-tile
+    using L = AttnLds<QW, CW>;
+    TD_DYN_LDS(smem);
+    float* Ps = reinterpret_cast<float*>(smem);                  // [2][P_FLOATS]
+    float* red = Ps + 2 * L::P_FLOATS;                           // [QW][CW][32] row-max exchange
+    float* red2 = red + L::RED_FLOATS;                           // [QW][CW][32] row-sum exchange
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int qw = wave / CW, cw = wave % CW;
+    const int q0 = (blockIdx.x * QW + qw) * 32;                  // first query of this wave's tile
+
+    // ---- this lane's query row, pre-scaled so that exp(s/8 - max) = exp2(S - M) -------------------------------
+    f32x4 qf[8];
+    {
+        const int q = q0 + l31;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q < p.Lq) v = td_ld4(p.q + (size_t)q * 64 + 8 * g + 4 * half);
+            qf[g] = v * p.scale_log2e;
+        }
+    }
+    // S^T tile of 32 keys starting at kb: returns this lane's 16 scores (query l31, keys (r&3)+8(r>>2)+4half)
+    auto score_tile = [&](int kb) -> f32x16 {
+        f32x4 kf[8];
+        const int key = kb + l31;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key < p.Lk) v = td_ld4(p.k + (size_t)key * 64 + 8 * g + 4 * half);
+            kf[g] = v;
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = td_mfma32(kf[g][e], qf[g][e], s);
+        return s;
+    };
+
+    const int nsuper = (p.Lk + SK - 1) / SK;
+    const float NEG = -3.0e38f;
+
+    // ---- pass 1: row maxima ----------------------------------------------------------------------------------
+    float mx = NEG;
+    for (int st = 0; st < nsuper; ++st) {
+        const int kb = st * SK + cw * 32;
+        if (kb >= p.Lk) break;
+        const f32x16 s = score_tile(kb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            mx = (key < p.Lk && s[r] > mx) ? s[r] : mx;
+        }
+    }
+    mx = fmaxf(mx, td_shfl_xor(mx, 32));
+    if (half == 0) red[(qw * CW + cw) * 32 + l31] = mx;
+    __syncthreads();
+    float rowmax = NEG;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) rowmax = fmaxf(rowmax, red[(qw * CW + c) * 32 + l31]);
+
+    // ---- pass 2: P = exp2(S - max), O += P V' ----------------------------------------------------------------
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float lsum = 0.f;
+    const int cb = cw * (NT * 32) + l31 * NT;                     // this lane's first output channel
+    for (int st = 0; st < nsuper; ++st) {
+        const int kb = st * SK + cw * 32;
+        f32x16 pr;
+        if (kb < p.Lk) {
+            const f32x16 s = score_tile(kb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float e = (key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
+                pr[r] = e;
+                lsum += e;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = 0.f;
+        }
+        float* Pw = Ps + (st & 1) * L::P_FLOATS + qw * (8 * CW * 128);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4 v = {pr[4 * u], pr[4 * u + 1], pr[4 * u + 2], pr[4 * u + 3]};
+            td_st4(Pw + ((cw * 8 + 2 * u + half) * 32 + l31) * 4, v);
+        }
+        __syncthreads();
+        const int kbase = st * SK;
+#pragma unroll 4
+        for (int G = 0; G < 4 * CW; ++G) {
+            const f32x4 a4 = td_ld4(Pw + ((2 * G + half) * 32 + l31) * 4);
+            const int key0 = kbase + 4 * (2 * G + half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (key0 + e < p.Lk) b4 = td_ld4(p.vp + (size_t)(key0 + e) * DV + cb);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = td_mfma32(a4[e], b4[j], acc[j]);
+            }
+        }
+    }
+    // ---- row sums -> 1/l, epilogue ---------------------------------------------------------------------------
+    lsum += td_shfl_xor(lsum, 32);
+    if (half == 0) red2[(qw * CW + cw) * 32 + l31] = lsum;
+    __syncthreads();
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = td_ld4(p.bias + cb);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int q = q0 + row;
+        if (q >= p.Lq) continue;
+        float l = 0.f;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
+        const float inv = 1.0f / l;
+        f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
+        o = o + bv;
+        const size_t off = (size_t)q * DV + cb;
+        if (p.resid) o = o + td_ld4(p.resid + off);
+        td_st4(p.out + off, o);
+    }
+}
+
+static inline int attn_launch(const AttnArgs& a, int DV, hipStream_t s) {
+    if (DV == 512) {
+        const int grid = (a.Lq + 31) / 32;
+        TD_LAUNCH((k_attention<1, 4, 4>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+    } else if (DV == 128) {
+        const int grid = (a.Lq + 127) / 128;
+        TD_LAUNCH((k_attention<4, 1, 4>), dim3(grid), dim3(256), (AttnLds<4, 1>::BYTES), s, a);
+    } else {
+        return -1;
+    }
+    return 0;
+}

@@ -1,0 +1,31 @@
+// td_device.h -- the (small) set of gfx950 device/runtime primitives the TDNet kernels are written against.
+//
+// Everything here is CDNA4-only: 64-lane wavefronts, the f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32
+// fma chain at the fp32 vector rate, 64 FLOP/clk/SIMD -- MI355X_MICROARCH.md "Matrix cores"), dynamic LDS.
+// tests/emu/ carries a host-side stand-in for this one header so the SAME kernel sources can be executed lane by
+// lane on a CPU to verify their index math before spending GPU time; the product library is built only from this file.
+#ifndef TD_DEVICE_H
+#define TD_DEVICE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TD_KERNEL __global__
+#define TD_DEV __device__ __forceinline__
+#define TD_HOSTDEV __host__ __device__ __forceinline__
+#define TD_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
+// all LDS is dynamic and 16-byte aligned (cdna_hip_programming.md Guideline 17)
+#define TD_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define TD_LAUNCH(kern, grid, block, lds, stream, ...) hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__)
+
+// D(32x32) += A(32x2) * B(2x32).  lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+TD_DEV float td_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+TD_DEV float td_exp2(float x) { return exp2f(x); }
+TD_DEV int td_lane() { return threadIdx.x & 63; }
+TD_DEV int td_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+#endif  // TD_DEVICE_H

@@ -1,0 +1,281 @@
+// td_misc.h -- the HBM-bound tail of the TDNet hot path: layout change, max-pool, pyramid pooling, plane LayerNorm,
+// classifier, bilinear upsample, argmax, key/value sub-sampling.  All NHWC fp32, float4 per lane, grid-stride.
+#pragma once
+#include "td_device.h"
+#include "td_conv.h"   // td_ld4 / td_st4
+
+static inline int td_grid_for(long work_items, int block = 256, int max_blocks = 256 * 8) {
+    long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > max_blocks ? max_blocks : g);
+}
+
+// ---- image NCHW [3][H][W] -> NHWC4 [H][W][4] (4th channel 0) so the stem gathers one float4 per tap --------------
+TD_KERNEL void k_nchw3_to_nhwc4(const float* __restrict__ img, float* __restrict__ out, int HW) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+        f32x4 v = {img[p], img[HW + p], img[2 * HW + p], 0.f};
+        td_st4(out + (size_t)p * 4, v);
+    }
+}
+
+// ---- MaxPool2d(3, stride 2, pad 1), padding = -inf, floor mode (resnet.py:137) -----------------------------------
+TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
+    const int CV = C >> 2;
+    const long total = (long)Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long pix = i / CV;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = td_ld4(in + ((size_t)iy * W + ix) * C + cv * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        td_st4(out + (size_t)pix * C + cv * 4, m);
+    }
+}
+
+// ---- Pyramid pooling (td4_psp18.py:243-284) ----------------------------------------------------------------------
+// AdaptiveAvgPool2d(o): bin i covers [floor(i n / o), ceil((i+1) n / o)).  12 x-bins (levels 1,2,3,6) per row first,
+// then rows are combined per y-bin: 50 bins x C sums, each input element read once per level.
+TD_HOSTDEV int td_bin_lo(int i, int n, int o) { return (i * n) / o; }
+TD_HOSTDEV int td_bin_hi(int i, int n, int o) { return ((i + 1) * n + o - 1) / o; }
+
+// grid = h rows, block = C/4 threads; rowpart [h][12][C]
+TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C) {
+    const int y = blockIdx.x, cv = threadIdx.x;
+    const float* row = c4 + (size_t)y * w * C + cv * 4;
+    int b = 0;
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        const int o = lvl == 0 ? 1 : lvl == 1 ? 2 : lvl == 2 ? 3 : 6;
+        for (int i = 0; i < o; ++i, ++b) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
+            for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
+            td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
+        }
+    }
+}
+// grid = 50 bins, block = C/4; pooled [50][C] = mean over the bin.  bin order: level-major, then by, then bx.
+TD_KERNEL void k_ppm_bins(const float* __restrict__ rowpart, float* __restrict__ pooled, int h, int w, int C) {
+    int bin = blockIdx.x, lvl = 0, o = 1, xoff = 0;
+    if (bin >= 14) { lvl = 3; o = 6; xoff = 6; bin -= 14; }
+    else if (bin >= 5) { lvl = 2; o = 3; xoff = 3; bin -= 5; }
+    else if (bin >= 1) { lvl = 1; o = 2; xoff = 1; bin -= 1; }
+    (void)lvl;
+    const int by = bin / o, bx = bin % o, cv = threadIdx.x;
+    const int ylo = td_bin_lo(by, h, o), yhi = td_bin_hi(by, h, o);
+    const int cnt = (yhi - ylo) * (td_bin_hi(bx, w, o) - td_bin_lo(bx, w, o));
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowpart + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
+    td_st4(pooled + (size_t)blockIdx.x * C + cv * 4, s * (1.0f / (float)cnt));
+}
+// pyramid 1x1 conv (BN folded) + ReLU on the 50 pooled vectors, only the FS channels this path keeps:
+// feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][f][c] pooled[bin][c]).  grid = 50, block = FS (64).
+TD_KERNEL void k_ppm_conv(const float* __restrict__ pooled, const float* __restrict__ wgt, const float* __restrict__ bias,
+                          float* __restrict__ feat, int C, int FS) {
+    const int bin = blockIdx.x, f = threadIdx.x;
+    const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
+    const float* wr = wgt + ((size_t)lvl * FS + f) * C;
+    const float* pv = pooled + (size_t)bin * C;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(wr[c], pv[c], s);
+    s += bias[lvl * FS + f];
+    feat[(size_t)bin * FS + f] = s > 0.f ? s : 0.f;
+}
+// z[p] = [ c4[p][pid*XS : +XS] | bilinear(feat_l)(p)[0:FS] for l = 0..3 ]   (align_corners=True, td4_psp18.py:273-284)
+TD_KERNEL void k_ppm_assemble(const float* __restrict__ c4, const float* __restrict__ feat, float* __restrict__ z,
+                              int h, int w, int C, int xs_off, int XS, int FS) {
+    const int ZC = XS + 4 * FS, ZV = ZC >> 2;
+    const long total = (long)h * w * ZV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int zv = (int)(i % ZV);
+        const long pix = i / ZV;
+        const int c = zv * 4;
+        f32x4 v;
+        if (c < XS) {
+            v = td_ld4(c4 + (size_t)pix * C + xs_off + c);
+        } else {
+            const int lvl = (c - XS) / FS, f = (c - XS) % FS;
+            const int o = lvl == 0 ? 1 : lvl == 1 ? 2 : lvl == 2 ? 3 : 6;
+            const int boff = lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 5 : 14;
+            const int x = (int)(pix % w), y = (int)(pix / w);
+            const float sy = (h > 1) ? (float)(o - 1) / (float)(h - 1) : 0.f;
+            const float sx = (w > 1) ? (float)(o - 1) / (float)(w - 1) : 0.f;
+            const float fy = sy * (float)y, fx = sx * (float)x;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < o - 1 ? 1 : 0), x1 = x0 + (x0 < o - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float* fb = feat + (size_t)boff * FS + f;
+            const f32x4 v00 = td_ld4(fb + (size_t)(y0 * o + x0) * FS), v01 = td_ld4(fb + (size_t)(y0 * o + x1) * FS);
+            const f32x4 v10 = td_ld4(fb + (size_t)(y1 * o + x0) * FS), v11 = td_ld4(fb + (size_t)(y1 * o + x1) * FS);
+            v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        }
+        td_st4(z + (size_t)pix * ZC + c, v);
+    }
+}
+
+// ---- LayerNorm over the (h,w) plane of each channel (td4_psp18.py:306-312), NHWC ----------------------------------
+// pass A: part[strip][C] = sum_p (x[p][c] - shift[c])^2 or plain sum (shift == nullptr); strips of pixels, fixed order.
+TD_KERNEL void k_ln_partial(const float* __restrict__ x, const float* __restrict__ shift, float* __restrict__ part,
+                            int HW, int C, int sq) {
+    TD_DYN_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);               // [rows][C]
+    const int CV = C >> 2, rows = blockDim.x / CV;
+    const int cv = threadIdx.x % CV, r = threadIdx.x / CV;
+    const int per = (HW + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+    if (shift) sh = td_ld4(shift + cv * 4);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + r; p < p1; p += rows) {
+        const f32x4 v = td_ld4(x + (size_t)p * C + cv * 4) - sh;
+        s = s + (sq ? v * v : v);
+    }
+    td_st4(red + (size_t)r * C + cv * 4, s);
+    __syncthreads();
+    if (r == 0) {
+        for (int k = 1; k < rows; ++k) s = s + td_ld4(red + (size_t)k * C + cv * 4);
+        td_st4(part + (size_t)blockIdx.x * C + cv * 4, s);
+    }
+}
+// pass B: out[c] = mode 0: sum/HW (mean) ; mode 1: 1/sqrt(sum/HW + eps) (rstd).  one thread per channel.
+TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int HW, int C, int mode, float eps,
+                             float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nstrips; ++k) s += part[(size_t)k * C + c];
+    s /= (float)HW;
+    out[c] = mode ? 1.0f / sqrtf(s + eps) : s;
+}
+// pass C: y = (x - mean[c]) * rstd[c] * g[p] + b[p]
+TD_KERNEL void k_ln_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                          const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ y, int HW, int C) {
+    const int CV = C >> 2;
+    const long total = (long)HW * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long p = i / CV;
+        const f32x4 v = td_ld4(x + (size_t)p * C + cv * 4);
+        const f32x4 m = td_ld4(mean + cv * 4), rs = td_ld4(rstd + cv * 4);
+        td_st4(y + (size_t)p * C + cv * 4, (v - m) * rs * g[p] + b[p]);
+    }
+}
+
+// ---- classifier: 1x1 conv C -> NC (+bias) (td4_psp18.py:299), NHWC in, PLANAR [NC][HW] out ------------------------
+template <int NC_MAX>
+TD_KERNEL void k_classifier(const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
+                            float* __restrict__ out, int HW, int C, int NC) {
+    TD_DYN_LDS(smem);
+    float* ws = reinterpret_cast<float*>(smem);                // [NC][C]
+    for (int i = threadIdx.x; i < NC * C; i += blockDim.x) ws[i] = wgt[i];
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float acc[NC_MAX];
+#pragma unroll
+    for (int k = 0; k < NC_MAX; ++k) acc[k] = 0.f;
+    for (int c = 0; c < C; c += 4) {
+        const f32x4 v = td_ld4(x + (size_t)p * C + c);
+#pragma unroll
+        for (int k = 0; k < NC_MAX; ++k) {
+            if (k < NC) {
+                const float* wr = ws + k * C + c;
+                acc[k] = fmaf(v[0], wr[0], acc[k]); acc[k] = fmaf(v[1], wr[1], acc[k]);
+                acc[k] = fmaf(v[2], wr[2], acc[k]); acc[k] = fmaf(v[3], wr[3], acc[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC_MAX; ++k)
+        if (k < NC) out[(size_t)k * HW + p] = acc[k] + bias[k];
+}
+
+// ---- bilinear, align_corners=True (td4_psp18.py:227): planar [C][h][w] -> [C][H][W] ------------------------------
+struct UpCoef { int i0, i1; float l; };
+TD_DEV UpCoef td_up_coef(int d, float scale, int n_in) {
+    const float f = scale * (float)d;
+    UpCoef c;
+    c.i0 = (int)f;
+    c.i1 = c.i0 + (c.i0 < n_in - 1 ? 1 : 0);
+    c.l = f - (float)c.i0;
+    return c;
+}
+TD_KERNEL void k_upsample(const float* __restrict__ in, float* __restrict__ out, int C, int h, int w, int H, int W) {
+    const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = (long)C * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W);
+        const long t = i / W;
+        const int Y = (int)(t % H), c = (int)(t / H);
+        const UpCoef cy = td_up_coef(Y, sy, h), cx = td_up_coef(X, sx, w);
+        const float* pl = in + (size_t)c * h * w;
+        const float v00 = pl[cy.i0 * w + cx.i0], v01 = pl[cy.i0 * w + cx.i1];
+        const float v10 = pl[cy.i1 * w + cx.i0], v11 = pl[cy.i1 * w + cx.i1];
+        out[i] = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
+    }
+}
+// argmax over classes, first maximum wins (== output.max(1)[1], test.py:61); labels int32 [H][W]
+TD_KERNEL void k_argmax(const float* __restrict__ logits, int32_t* __restrict__ labels, int C, long HW) {
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        float best = logits[p];
+        int bi = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = logits[(size_t)c * HW + p];
+            if (v > best) { best = v; bi = c; }
+        }
+        labels[p] = bi;
+    }
+}
+// fused upsample + argmax: the same arithmetic as k_upsample followed by k_argmax, without the [C][H][W] round trip
+TD_KERNEL void k_upsample_argmax(const float* __restrict__ in, int32_t* __restrict__ labels, int C, int h, int w, int H, int W) {
+    const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W), Y = (int)(i / W);
+        const UpCoef cy = td_up_coef(Y, sy, h), cx = td_up_coef(X, sx, w);
+        float best = 0.f;
+        int bi = 0;
+        for (int c = 0; c < C; ++c) {
+            const float* pl = in + (size_t)c * h * w;
+            const float v00 = pl[cy.i0 * w + cx.i0], v01 = pl[cy.i0 * w + cx.i1];
+            const float v10 = pl[cy.i1 * w + cx.i0], v11 = pl[cy.i1 * w + cx.i1];
+            const float v = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
+            if (c == 0 || v > best) { best = v; bi = c; }
+        }
+        labels[i] = bi;
+    }
+}
+
+// ---- stride-4 sub-sampling of an NHWC map (MaxPool2d(kernel 1, stride 4), transformer.py:26,36) -------------------
+TD_KERNEL void k_subsample(const float* __restrict__ in, float* __restrict__ out, int w, int C, int ho, int wo, int stride) {
+    const int CV = C >> 2;
+    const long total = (long)ho * wo * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long pix = i / CV;
+        const int ox = (int)(pix % wo), oy = (int)(pix / wo);
+        td_st4(out + (size_t)pix * C + cv * 4, td_ld4(in + ((size_t)(oy * stride) * w + ox * stride) * C + cv * 4));
+    }
+}
+// NHWC [HW][C] -> planar [C][HW] into HOST-layout staging (used only by tdnet_get_stage)
+TD_KERNEL void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, long HW, int C) {
+    const long total = HW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i % HW;
+        const int c = (int)(i / HW);
+        out[i] = in[(size_t)p * C + c];
+    }
+}

@@ -1,0 +1,827 @@
+// td_model.hip -- host side of libtdnet_hip.so: handle, strict weight loading + BN folding + packing, the per-frame
+// forward (kernel sequence of SURVEY.md §8a rows A1-A13), the K/Q/V FIFO, and the C ABI of include/tdnet.h.
+//
+// Reference behaviour mirrored here (paths relative to /root/reference/Testing/model/pspnet):
+//   forward / path dispatch ........ td4_psp18.py:216-229, td2_psp50.py:146-155
+//   per-path graph ................. td4_psp18.py:137-212, td2_psp50.py:112-143
+//   FIFO ........................... td4_psp18.py:123-134 (depth 3), td2_psp50.py:98-109 (depth 1)
+//   strict state_dict loading ...... td4_psp18.py:232-240
+#include "../../include/tdnet.h"
+#include "td_device.h"
+#include "td_conv.h"
+#include "td_attn.h"
+#include "td_misc.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+static int td_fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+#define TD_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return td_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* tdnet_last_error(void) { return g_err; }
+extern "C" const char* tdnet_version(void) { return "tdnet_amd 0.1 (gfx950, fp32 MFMA)"; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// architecture description (same rules as tdnet_amd/arch.py; resnet.py:114-202)
+// ---------------------------------------------------------------------------------------------------------------
+struct BlockSpec { std::string name; int cin, cout, stride, dil1, dil2; bool ds; };
+
+static std::vector<BlockSpec> backbone_blocks(int backbone) {
+    const int nb18[4] = {2, 2, 2, 2}, nb34[4] = {3, 4, 6, 3};
+    const int* nb = backbone == 18 ? nb18 : nb34;
+    const int planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 1, 1}, dils[4] = {1, 1, 2, 4};
+    std::vector<BlockSpec> out;
+    int inpl = 64;
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < nb[li]; ++b) {
+            const bool first = b == 0, mg = li == 3;
+            int d1;
+            if (mg) d1 = b == 0 ? 4 : b == 1 ? 8 : 16;            // multi-grid (4,8,16): resnet.py:181,196-198
+            else if (first) d1 = (dils[li] == 1 || dils[li] == 2) ? 1 : 2;
+            else d1 = dils[li];
+            BlockSpec s;
+            char nm[32];
+            snprintf(nm, sizeof(nm), "layer%d.%d", li + 1, b);
+            s.name = nm;
+            s.cin = first ? inpl : planes[li];
+            s.cout = planes[li];
+            s.stride = first ? strides[li] : 1;
+            s.dil1 = d1;
+            s.dil2 = dils[li];
+            s.ds = first && (strides[li] != 1 || inpl != planes[li]);
+            out.push_back(s);
+        }
+        inpl = planes[li];
+    }
+    return out;
+}
+static int feat_size(int n) { for (int i = 0; i < 3; ++i) n = (n - 1) / 2 + 1; return n; }
+static int key_size(int n) { return (n - 1) / 4 + 1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// device conv layer
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvLayer {
+    int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
+    bool stem = false;
+    ConvTile tile = CT_128x128;
+    int CoutPad = 0, nsteps = 0;
+    float* d_wp = nullptr;
+    float* d_bias = nullptr;
+    double flops_per_pixel() const { return 2.0 * Cout * (stem ? 147.0 : (double)Cin * KS * KS); }
+};
+
+static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2 * pad - dil * (KS - 1) - 1) / stride + 1; }
+
+// Upload a BN-folded OIHW weight + bias as a ConvLayer for an output of M pixels.
+static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& b, int Cout, int Cin, int KS,
+                           int stride, int dil, int act, bool stem, long M) {
+    L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
+    L.pad = stem ? 3 : dil * (KS / 2);
+    if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
+    L.tile = conv_pick_tile((int)M, Cout);
+    L.CoutPad = conv_cout_pad(Cout, L.tile);
+    L.nsteps = conv_nsteps(Cin, KS, stem);
+    std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
+    conv_pack_weights(w.data(), Cout, Cin, KS, stem, L.tile, packed.data());
+    TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(float)));
+    TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> bb(Cout, 0.f);
+    if (!b.empty()) bb = b;
+    TD_HIP(hipMalloc((void**)&L.d_bias, Cout * sizeof(float)));
+    TD_HIP(hipMemcpy(L.d_bias, bb.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+static void free_conv_layer(ConvLayer& L) {
+    if (L.d_wp) hipFree(L.d_wp);
+    if (L.d_bias) hipFree(L.d_bias);
+    L.d_wp = L.d_bias = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------------------------
+struct BlockLayers { ConvLayer c1, c2, ds; bool has_ds = false; };
+struct AtnLayer { ConvLayer fc; float* d_bias = nullptr; };          // fc applied to the value matrix (no bias), bias added after P V'
+struct PathLayers {
+    ConvLayer stem;
+    std::vector<BlockLayers> blocks;
+    float* d_ppm_w = nullptr; float* d_ppm_b = nullptr;                // [4][FS][512], [4][FS]
+    ConvLayer enc_v, enc_q0, enc_q1, enc_k0, enc_k1;
+    std::vector<AtnLayer> atn;                                         // in the order the path applies them
+    float* d_ln_g = nullptr; float* d_ln_b = nullptr;                  // [h*w]
+    ConvLayer head3;
+    float* d_cls_w = nullptr; float* d_cls_b = nullptr;                // [nclass][mid], [nclass]
+    int pid = 0;
+};
+struct CacheSlot { float* q = nullptr; float* k = nullptr; float* v = nullptr; };
+struct ProfRec { int family; bool dominant; hipEvent_t e0, e1; double flops; };
+
+struct tdnet {
+    tdnet_cfg cfg;
+    int P = 0, DV = 0, MID = 0, FIFO = 0;
+    int H = 0, W = 0, H1 = 0, W1 = 0, H2 = 0, W2 = 0, h = 0, w = 0, hk = 0, wk = 0, Lq = 0, Lk = 0;
+    std::vector<BlockSpec> bspec;
+    std::map<std::string, std::vector<float>> sd;                      // host state_dict until finalize
+    std::map<std::string, size_t> expected;                            // name -> element count
+    bool finalized = false;
+    std::vector<PathLayers> paths;
+    // workspace
+    float *img4 = nullptr, *s1 = nullptr, *bx = nullptr, *bt = nullptr, *br = nullptr;
+    float *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr, *z = nullptr;
+    float *v_cur = nullptr, *q1 = nullptr, *q_cur = nullptr, *k1 = nullptr;
+    float *vp = nullptr, *chain_a = nullptr, *chain_b = nullptr, *feat = nullptr;
+    float *ln_part = nullptr, *ln_mean = nullptr, *ln_rstd = nullptr, *ln = nullptr;
+    float *headmid = nullptr, *lowres = nullptr, *stage_tmp = nullptr, *logits_tmp = nullptr;
+    size_t stage_tmp_floats = 0;
+    std::vector<CacheSlot> slots;
+    std::vector<int> fifo;                                             // slot ids, oldest first
+    int last_slot = -1;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    size_t nrec = 0;
+    double flops_frame = 0.0;
+};
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+    TD_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+
+// expected reference state_dict (names + sizes): same inventory as tdnet_amd/arch.py:state_dict_shapes
+static void add_bn(std::map<std::string, size_t>& e, const std::string& pre, int c) {
+    e[pre + ".weight"] = c; e[pre + ".bias"] = c; e[pre + ".running_mean"] = c; e[pre + ".running_var"] = c;
+    e[pre + ".num_batches_tracked"] = 1;
+}
+static std::vector<std::string> atn_module_names(int model) {
+    if (model == 4) return {"atn1_2", "atn1_3", "atn1_4", "atn2_1", "atn2_3", "atn2_4", "atn3_1", "atn3_2", "atn3_4", "atn4_1", "atn4_2", "atn4_3"};
+    return {"atn1", "atn2"};
+}
+// attention modules in application order for path p (0-based): td4_psp18.py:145-147,166-168,185-187,204-206
+static std::vector<std::string> atn_order(int model, int p) {
+    if (model == 2) return {p == 0 ? "atn1" : "atn2"};
+    static const char* t[4][3] = {{"atn1_2", "atn1_3", "atn1_4"}, {"atn2_3", "atn2_4", "atn2_1"},
+                                  {"atn3_4", "atn3_1", "atn3_2"}, {"atn4_1", "atn4_2", "atn4_3"}};
+    return {t[p][0], t[p][1], t[p][2]};
+}
+static void build_expected(tdnet* n) {
+    auto& e = n->expected;
+    char b[160];
+    for (int p = 1; p <= n->P; ++p) {
+        snprintf(b, sizeof(b), "pretrained%d", p);
+        std::string pre = b;
+        e[pre + ".conv1.weight"] = 64 * 3 * 49;
+        add_bn(e, pre + ".bn1", 64);
+        for (auto& s : n->bspec) {
+            std::string bp = pre + "." + s.name;
+            e[bp + ".conv1.weight"] = (size_t)s.cout * s.cin * 9;
+            add_bn(e, bp + ".bn1", s.cout);
+            e[bp + ".conv2.weight"] = (size_t)s.cout * s.cout * 9;
+            add_bn(e, bp + ".bn2", s.cout);
+            if (s.ds) { e[bp + ".downsample.0.weight"] = (size_t)s.cout * s.cin; add_bn(e, bp + ".downsample.1", s.cout); }
+        }
+        e[pre + ".fc.weight"] = 1000 * 512; e[pre + ".fc.bias"] = 1000;
+        for (int j = 1; j <= 4; ++j) {
+            snprintf(b, sizeof(b), "psp%d.conv%d", p, j);
+            e[std::string(b) + ".0.weight"] = 128 * 512;
+            add_bn(e, std::string(b) + ".1", 128);
+        }
+        for (const char* br : {"w_qs", "w_ks"}) {
+            snprintf(b, sizeof(b), "enc%d.%s", p, br);
+            std::string ep = b;
+            e[ep + ".0.conv.weight"] = 64 * 512; e[ep + ".0.conv.bias"] = 64; add_bn(e, ep + ".0.bn", 64);
+            e[ep + ".1.conv.weight"] = 64 * 64; e[ep + ".1.conv.bias"] = 64;
+        }
+        snprintf(b, sizeof(b), "enc%d.w_vs.0.conv", p);
+        e[std::string(b) + ".weight"] = (size_t)n->DV * 512; e[std::string(b) + ".bias"] = n->DV;
+        snprintf(b, sizeof(b), "layer_norm%d.ln", p);
+        e[std::string(b) + ".weight"] = (size_t)n->h * n->w; e[std::string(b) + ".bias"] = (size_t)n->h * n->w;
+        snprintf(b, sizeof(b), "head%d.conv5", p);
+        std::string hp = b;
+        e[hp + ".0.weight"] = (size_t)n->MID * n->DV * 9; add_bn(e, hp + ".1", n->MID);
+        e[hp + ".4.weight"] = (size_t)n->cfg.nclass * n->MID; e[hp + ".4.bias"] = n->cfg.nclass;
+    }
+    for (auto& a : atn_module_names(n->cfg.model)) {
+        e[a + ".fc.0.conv.weight"] = (size_t)n->DV * n->DV; e[a + ".fc.0.conv.bias"] = n->DV;
+    }
+}
+
+extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) {
+    if (!cfg || !out) return td_fail("tdnet_create: null argument");
+    if (cfg->model != 4 && cfg->model != 2) return td_fail("tdnet_create: model must be 4 (td4) or 2 (td2), got %d", cfg->model);
+    if (cfg->backbone != 18 && cfg->backbone != 34)
+        return td_fail("tdnet_create: backbone must be 18 or 34 (BasicBlock ResNets), got %d", cfg->backbone);
+    if (cfg->nclass < 1 || cfg->nclass > 32) return td_fail("tdnet_create: nclass must be in 1..32");
+    if (cfg->height < 9 || cfg->width < 9) return td_fail("tdnet_create: input too small");
+    TD_HIP(hipSetDevice(cfg->device));
+    tdnet* n = new tdnet();
+    n->cfg = *cfg;
+    n->P = cfg->model;
+    n->DV = cfg->model == 4 ? 512 : 128;                               // td4_psp18.py:85 / td2_psp50.py:79
+    n->MID = cfg->model == 4 ? 128 : 64;                               // FCNHead chn_down 4 / 2
+    n->FIFO = cfg->model == 4 ? 3 : 1;
+    n->H = cfg->height; n->W = cfg->width;
+    n->H1 = (n->H - 1) / 2 + 1; n->W1 = (n->W - 1) / 2 + 1;
+    n->H2 = (n->H1 - 1) / 2 + 1; n->W2 = (n->W1 - 1) / 2 + 1;
+    n->h = feat_size(n->H); n->w = feat_size(n->W);
+    n->hk = key_size(n->h); n->wk = key_size(n->w);
+    n->Lq = n->h * n->w; n->Lk = n->hk * n->wk;
+    n->bspec = backbone_blocks(cfg->backbone);
+    build_expected(n);
+    *out = n;
+    return 0;
+}
+
+static void free_path(PathLayers& p) {
+    free_conv_layer(p.stem);
+    for (auto& b : p.blocks) { free_conv_layer(b.c1); free_conv_layer(b.c2); free_conv_layer(b.ds); }
+    for (ConvLayer* c : {&p.enc_v, &p.enc_q0, &p.enc_q1, &p.enc_k0, &p.enc_k1, &p.head3}) free_conv_layer(*c);
+    for (auto& a : p.atn) { free_conv_layer(a.fc); if (a.d_bias) hipFree(a.d_bias); }
+    for (float* q : {p.d_ppm_w, p.d_ppm_b, p.d_ln_g, p.d_ln_b, p.d_cls_w, p.d_cls_b}) if (q) hipFree(q);
+}
+extern "C" void tdnet_destroy(tdnet_t* n) {
+    if (!n) return;
+    for (auto& p : n->paths) free_path(p);
+    for (float* q : {n->img4, n->s1, n->bx, n->bt, n->br, n->rowpart, n->pooled, n->ppmfeat, n->z, n->v_cur, n->q1, n->q_cur,
+                     n->k1, n->vp, n->chain_a, n->chain_b, n->feat, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, n->headmid,
+                     n->lowres, n->stage_tmp, n->logits_tmp})
+        if (q) hipFree(q);
+    for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
+    for (auto& r : n->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    delete n;
+}
+
+extern "C" int tdnet_set_weight(tdnet_t* n, const char* name, const float* host, size_t count) {
+    if (!n || !name || !host) return td_fail("tdnet_set_weight: null argument");
+    if (n->finalized) return td_fail("tdnet_set_weight: weights already finalized");
+    auto it = n->expected.find(name);
+    if (it == n->expected.end()) return td_fail("Unexpected key in state_dict: \"%s\"", name);
+    if (it->second != count) return td_fail("size mismatch for %s: expected %zu elements, got %zu", name, it->second, count);
+    const std::string s = name;
+    if (s.find(".fc.weight") != std::string::npos && s.compare(0, 10, "pretrained") == 0) return 0;   // unused classifier
+    if (s.find(".fc.bias") != std::string::npos && s.compare(0, 10, "pretrained") == 0) return 0;
+    if (s.size() > 19 && s.compare(s.size() - 19, 19, "num_batches_tracked") == 0) { n->sd[s] = {0.f}; return 0; }
+    n->sd[s].assign(host, host + count);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BN folding (fp64): y = (conv(x)+b - mu) * g / sqrt(var + eps) + beta   (td4_psp18.py:23-24)
+// ---------------------------------------------------------------------------------------------------------------
+struct Folded { std::vector<float> w, b; };
+static const std::vector<float>& T(tdnet* n, const std::string& k) { return n->sd.at(k); }
+static Folded fold(tdnet* n, const std::string& wkey, const std::string& bkey, const std::string& bn, int Cout) {
+    Folded f;
+    const std::vector<float>& w = T(n, wkey);
+    const size_t per = w.size() / Cout;
+    f.w.resize(w.size());
+    f.b.assign(Cout, 0.f);
+    for (int o = 0; o < Cout; ++o) {
+        double scale = 1.0, shift = 0.0, cb = bkey.empty() ? 0.0 : (double)T(n, bkey)[o];
+        if (!bn.empty()) {
+            const double g = T(n, bn + ".weight")[o], be = T(n, bn + ".bias")[o], mu = T(n, bn + ".running_mean")[o],
+                         var = T(n, bn + ".running_var")[o];
+            scale = g / std::sqrt(var + 1e-5);
+            shift = be - mu * scale;
+        }
+        for (size_t i = 0; i < per; ++i) f.w[o * per + i] = (float)((double)w[o * per + i] * scale);
+        f.b[o] = (float)(cb * scale + shift);
+    }
+    return f;
+}
+static int upload(float** d, const std::vector<float>& v) {
+    TD_HIP(hipMalloc((void**)d, v.size() * sizeof(float)));
+    TD_HIP(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int alloc_workspace(tdnet* n) {
+    const size_t hw = (size_t)n->Lq, lk = (size_t)n->Lk;
+    size_t bmax = (size_t)n->H2 * n->W2 * 64;
+    if (hw * 512 > bmax) bmax = hw * 512;
+    if (dev_alloc(&n->img4, (size_t)n->H * n->W * 4)) return -1;
+    if (dev_alloc(&n->s1, (size_t)n->H1 * n->W1 * 64)) return -1;
+    if (dev_alloc(&n->bx, bmax) || dev_alloc(&n->bt, bmax) || dev_alloc(&n->br, bmax)) return -1;
+    if (dev_alloc(&n->rowpart, (size_t)n->h * 12 * 512) || dev_alloc(&n->pooled, 50 * 512) || dev_alloc(&n->ppmfeat, 50 * 64)) return -1;
+    if (dev_alloc(&n->z, hw * 512) || dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
+    if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
+    if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
+    if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
+    if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass)) return -1;
+    n->stage_tmp_floats = hw * 512;
+    if (dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
+    n->slots.resize(n->FIFO + 1);
+    for (auto& s : n->slots)
+        if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
+    return 0;
+}
+
+static double frame_flops(const tdnet* n);
+
+extern "C" int tdnet_finalize_weights(tdnet_t* n) {
+    if (!n) return td_fail("tdnet_finalize_weights: null handle");
+    if (n->finalized) return td_fail("tdnet_finalize_weights: already finalized");
+    for (auto& kv : n->expected) {
+        const std::string& k = kv.first;
+        if (k.compare(0, 10, "pretrained") == 0 && (k.find(".fc.weight") != std::string::npos || k.find(".fc.bias") != std::string::npos)) continue;
+        if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) continue;
+        if (!n->sd.count(k)) return td_fail("Missing key in state_dict: \"%s\"", k.c_str());
+    }
+    const int C = 512, DV = n->DV, FS = C / (2 * 4), NC = n->cfg.nclass;
+    n->paths.resize(n->P);
+    char b[160];
+    for (int p = 0; p < n->P; ++p) {
+        PathLayers& L = n->paths[p];
+        L.pid = p & 1;                                                 // td4_psp18.py:80-83 / td2_psp50.py:76-77
+        snprintf(b, sizeof(b), "pretrained%d", p + 1);
+        const std::string pre = b;
+        {
+            Folded f = fold(n, pre + ".conv1.weight", "", pre + ".bn1", 64);
+            if (make_conv_layer(L.stem, f.w, f.b, 64, 3, 7, 2, 1, 1, true, (long)n->H1 * n->W1)) return -1;
+        }
+        int ch = n->H2, cw = n->W2;
+        for (auto& s : n->bspec) {
+            BlockLayers B;
+            const std::string bp = pre + "." + s.name;
+            const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
+            const long M = (long)oh * ow;
+            Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.cout);
+            if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M)) return -1;
+            Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.cout);
+            if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M)) return -1;
+            B.has_ds = s.ds;
+            if (s.ds) {
+                Folded fd = fold(n, bp + ".downsample.0.weight", "", bp + ".downsample.1", s.cout);
+                if (make_conv_layer(B.ds, fd.w, fd.b, s.cout, s.cin, 1, s.stride, 1, 0, false, M)) return -1;
+            }
+            L.blocks.push_back(B);
+            ch = oh; cw = ow;
+        }
+        if (ch != n->h || cw != n->w) return td_fail("internal: feature size mismatch %dx%d vs %dx%d", ch, cw, n->h, n->w);
+        // pyramid convs: keep only the FS output channels this path's slice uses (td4_psp18.py:279-282)
+        std::vector<float> pw((size_t)4 * FS * C), pb((size_t)4 * FS);
+        for (int j = 0; j < 4; ++j) {
+            snprintf(b, sizeof(b), "psp%d.conv%d", p + 1, j + 1);
+            Folded f = fold(n, std::string(b) + ".0.weight", "", std::string(b) + ".1", 128);
+            for (int o = 0; o < FS; ++o) {
+                memcpy(&pw[((size_t)j * FS + o) * C], &f.w[(size_t)(L.pid * FS + o) * C], C * sizeof(float));
+                pb[j * FS + o] = f.b[L.pid * FS + o];
+            }
+        }
+        if (upload(&L.d_ppm_w, pw) || upload(&L.d_ppm_b, pb)) return -1;
+        snprintf(b, sizeof(b), "enc%d", p + 1);
+        const std::string ep = b;
+        {
+            Folded fv = fold(n, ep + ".w_vs.0.conv.weight", ep + ".w_vs.0.conv.bias", "", DV);
+            if (make_conv_layer(L.enc_v, fv.w, fv.b, DV, C, 1, 1, 1, 0, false, n->Lq)) return -1;
+            Folded q0 = fold(n, ep + ".w_qs.0.conv.weight", ep + ".w_qs.0.conv.bias", ep + ".w_qs.0.bn", 64);
+            if (make_conv_layer(L.enc_q0, q0.w, q0.b, 64, C, 1, 1, 1, 2, false, n->Lq)) return -1;
+            Folded q1 = fold(n, ep + ".w_qs.1.conv.weight", ep + ".w_qs.1.conv.bias", "", 64);
+            if (make_conv_layer(L.enc_q1, q1.w, q1.b, 64, 64, 1, 1, 1, 0, false, n->Lq)) return -1;
+            Folded k0 = fold(n, ep + ".w_ks.0.conv.weight", ep + ".w_ks.0.conv.bias", ep + ".w_ks.0.bn", 64);
+            if (make_conv_layer(L.enc_k0, k0.w, k0.b, 64, C, 1, 4, 1, 2, false, n->Lk)) return -1;   // stride 4 = the key sub-sampling
+            Folded k1 = fold(n, ep + ".w_ks.1.conv.weight", ep + ".w_ks.1.conv.bias", "", 64);
+            if (make_conv_layer(L.enc_k1, k1.w, k1.b, 64, 64, 1, 1, 1, 0, false, n->Lk)) return -1;
+        }
+        for (auto& an : atn_order(n->cfg.model, p)) {
+            AtnLayer A;
+            std::vector<float> nob;
+            if (make_conv_layer(A.fc, T(n, an + ".fc.0.conv.weight"), nob, DV, DV, 1, 1, 1, 0, false, n->Lk)) return -1;
+            if (upload(&A.d_bias, T(n, an + ".fc.0.conv.bias"))) return -1;
+            L.atn.push_back(A);
+        }
+        snprintf(b, sizeof(b), "layer_norm%d.ln", p + 1);
+        if (upload(&L.d_ln_g, T(n, std::string(b) + ".weight")) || upload(&L.d_ln_b, T(n, std::string(b) + ".bias"))) return -1;
+        snprintf(b, sizeof(b), "head%d.conv5", p + 1);
+        const std::string hp = b;
+        Folded fh = fold(n, hp + ".0.weight", "", hp + ".1", n->MID);
+        if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, DV, 3, 1, 1, 1, false, n->Lq)) return -1;
+        if (upload(&L.d_cls_w, T(n, hp + ".4.weight")) || upload(&L.d_cls_b, T(n, hp + ".4.bias"))) return -1;
+        (void)NC;
+    }
+    n->sd.clear();
+    if (alloc_workspace(n)) return -1;
+    TD_HIP(hipDeviceSynchronize());
+    n->finalized = true;
+    n->flops_frame = frame_flops(n);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------------------------
+static void prof_begin(tdnet* n, int family, bool dominant, double flops, hipStream_t s) {
+    if (!n || !n->prof) return;
+    if (n->nrec == n->recs.size()) {
+        ProfRec r;
+        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+        n->recs.push_back(r);
+    }
+    ProfRec& r = n->recs[n->nrec];
+    r.family = family; r.dominant = dominant; r.flops = flops;
+    hipEventRecord(r.e0, s);
+}
+static void prof_end(tdnet* n, hipStream_t s) {
+    if (!n || !n->prof) return;
+    hipEventRecord(n->recs[n->nrec].e1, s);
+    n->nrec++;
+}
+
+// out[Ho*Wo][Cout] = act(conv(in[H][W][Cin]) + bias (+ resid))
+static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
+                    int* Ho_out = nullptr, int* Wo_out = nullptr) {
+    const int Ho = out_size(H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(W, L.KS, L.stride, L.dil, L.pad);
+    ConvArgs a;
+    a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
+    a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0;
+    prof_begin(n, 0, L.tile == CT_128x128 && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
+    conv_launch(a, L.tile, L.KS, L.stem, s);
+    prof_end(n, s);
+    if (Ho_out) *Ho_out = Ho;
+    if (Wo_out) *Wo_out = Wo;
+    return 0;
+}
+
+static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
+                         int Lq, int Lk, int DV, float* out, hipStream_t s) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
+    a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
+    prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
+    const int rc = attn_launch(a, DV, s);
+    prof_end(n, s);
+    if (rc) return td_fail("attention: unsupported d_v=%d (128 or 512)", DV);
+    return 0;
+}
+
+static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* g, const float* b, float* part, float* mean,
+                          float* rstd, float* y, hipStream_t s) {
+    const int CV = C / 4, rows = 256 / CV;
+    int nstr = (HW + rows - 1) / rows;
+    if (nstr > 512) nstr = 512;
+    const int lds = rows * C * 4;
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_ln_partial, dim3(nstr), dim3(256), lds, s, x, (const float*)nullptr, part, HW, C, 0);
+    TD_LAUNCH(k_ln_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)part, nstr, HW, C, 0, 1e-5f, mean);
+    TD_LAUNCH(k_ln_partial, dim3(nstr), dim3(256), lds, s, x, (const float*)mean, part, HW, C, 1);
+    TD_LAUNCH(k_ln_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)part, nstr, HW, C, 1, 1e-5f, rstd);
+    TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
+    prof_end(n, s);
+}
+
+static void run_ppm(tdnet* n, const float* c4, int h, int w, const float* wgt, const float* bias, int pid, float* rowpart,
+                    float* pooled, float* ppmfeat, float* z, hipStream_t s) {
+    const int C = 512, XS = 256, FS = 64;
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_ppm_rowsum, dim3(h), dim3(C / 4), 0, s, c4, rowpart, w, C);
+    TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
+    TD_LAUNCH(k_ppm_conv, dim3(50), dim3(FS), 0, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
+    TD_LAUNCH(k_ppm_assemble, dim3(td_grid_for((long)h * w * (C / 4))), dim3(256), 0, s, c4, (const float*)ppmfeat, z, h, w, C,
+              pid * XS, XS, FS);
+    prof_end(n, s);
+}
+
+static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, hipStream_t s) {
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_nchw3_to_nhwc4, dim3(td_grid_for((long)H * W)), dim3(256), 0, s, img, img4, H * W);
+    prof_end(n, s);
+}
+static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* out, hipStream_t s) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_maxpool3s2, dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, in, out, H, W, C, Ho, Wo);
+    prof_end(n, s);
+}
+static int run_classifier(tdnet* n, const float* x, int HW, int C, int NC, const float* wgt, const float* bias, float* out, hipStream_t s) {
+    prof_begin(n, 2, false, 0, s);
+    const int grid = (HW + 255) / 256, lds = NC * C * 4;
+    if (NC <= 19) TD_LAUNCH((k_classifier<19>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
+    else TD_LAUNCH((k_classifier<32>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
+    prof_end(n, s);
+    return 0;
+}
+
+// low-resolution logits of one frame (planar [nclass][h*w]) + FIFO update
+static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
+    if (!n->finalized) return td_fail("tdnet_forward: weights not finalized (the HIP path never runs on random init)");
+    if (pos_id < 0 || pos_id >= n->P) return td_fail("tdnet_forward: pos_id %d out of range 0..%d", pos_id, n->P - 1);
+    PathLayers& L = n->paths[pos_id];
+    n->nrec = 0;
+    const int DV = n->DV;
+    // backbone (resnet.py:204-215)
+    run_stem_pre(n, img, n->H, n->W, n->img4, s);
+    run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s);
+    run_maxpool(n, n->s1, n->H1, n->W1, 64, n->bx, s);
+    int ch = n->H2, cw = n->W2;
+    for (auto& B : L.blocks) {
+        int oh, ow;
+        run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow);
+        const float* res = n->bx;
+        if (B.has_ds) { run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s); res = n->br; }
+        run_conv(n, B.c2, n->bt, oh, ow, res, n->bx, s);                // in-place on bx when res == bx (same element)
+        ch = oh; cw = ow;
+    }
+    float* c4 = n->bx;
+    // pyramid pooling slice (td4_psp18.py:271-284)
+    run_ppm(n, c4, n->h, n->w, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
+    // Encoding, pre=False (transformer.py:52-56)
+    run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s);
+    run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s);
+    run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, s);
+    const float* feat = n->v_cur;
+    if ((int)n->fifo.size() >= n->FIFO) {
+        if (n->P == 4) {                                               // td4_psp18.py:145-151
+            const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
+            run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, s);
+            if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, s)) return -1;   // v2 + V[1]
+            run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, s);
+            if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, s)) return -1;   // v3 + V[2]
+            run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, s);
+            if (run_attention(n, n->q_cur, c2.k, n->vp, L.atn[2].d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s)) return -1;   // v4 + v_cur
+        } else {                                                       // td2_psp50.py:120-122
+            const CacheSlot& c0 = n->slots[n->fifo[0]];
+            run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, s);
+            if (run_attention(n, n->q_cur, c0.k, n->vp, L.atn[0].d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s)) return -1;
+        }
+        feat = n->feat;
+    } else {
+        // warm-up (td4_psp18.py:142-143): feat = v_cur; keep a copy so the "feat" stage is well defined
+        TD_HIP(hipMemcpyAsync(n->feat, n->v_cur, (size_t)n->Lq * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
+        feat = n->feat;
+    }
+    run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, s);
+    run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s);
+    run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s);
+    // Encoding, pre=True (transformer.py:34-50) -> FIFO push (td4_psp18.py:153-154, :123-134)
+    int slot = -1;
+    for (int i = 0; i < (int)n->slots.size(); ++i) {
+        bool used = false;
+        for (int f : n->fifo) used |= f == i;
+        if (!used) { slot = i; break; }
+    }
+    if (slot < 0) return td_fail("internal: no free cache slot");
+    CacheSlot& cs = n->slots[slot];
+    run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, s);
+    run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, s);
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
+    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, s, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
+    prof_end(n, s);
+    n->fifo.push_back(slot);
+    if ((int)n->fifo.size() > n->FIFO) n->fifo.erase(n->fifo.begin());
+    n->last_slot = slot;
+    return 0;
+}
+
+extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* logits, void* stream) {
+    if (!n || !img || !logits) return td_fail("tdnet_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (forward_lowres(n, img, pos_id, s)) return -1;
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_upsample, dim3(td_grid_for((long)n->cfg.nclass * n->H * n->W, 256, 256 * 16)), dim3(256), 0, s,
+              (const float*)n->lowres, logits, n->cfg.nclass, n->h, n->w, n->H, n->W);
+    prof_end(n, s);
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int tdnet_argmax(tdnet_t* n, const float* logits, int32_t* labels, void* stream) {
+    if (!n || !logits || !labels) return td_fail("tdnet_argmax: null argument");
+    TD_LAUNCH(k_argmax, dim3(td_grid_for((long)n->H * n->W)), dim3(256), 0, (hipStream_t)stream, logits, labels, n->cfg.nclass, (long)n->H * n->W);
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int tdnet_forward_labels(tdnet_t* n, const float* img, int pos_id, int32_t* labels, void* stream) {
+    if (!n || !img || !labels) return td_fail("tdnet_forward_labels: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (forward_lowres(n, img, pos_id, s)) return -1;
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_upsample_argmax, dim3(td_grid_for((long)n->H * n->W)), dim3(256), 0, s, (const float*)n->lowres, labels, n->cfg.nclass,
+              n->h, n->w, n->H, n->W);
+    prof_end(n, s);
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int tdnet_reset(tdnet_t* n) {
+    if (!n) return td_fail("tdnet_reset: null handle");
+    n->fifo.clear();
+    n->last_slot = -1;
+    return 0;
+}
+extern "C" int tdnet_fifo_len(const tdnet_t* n) { return n ? (int)n->fifo.size() : -1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// introspection
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_t capacity) {
+    if (!n || !name || !host) return td_fail("tdnet_get_stage: null argument");
+    const std::string s = name;
+    const float* src = nullptr;
+    long rows = n->Lq, C = 0;
+    bool nhwc_map = true, planar = false;
+    if (s == "c4") { src = n->bx; C = 512; }
+    else if (s == "z") { src = n->z; C = 512; }
+    else if (s == "v_cur") { src = n->v_cur; C = n->DV; }
+    else if (s == "feat") { src = n->feat; C = n->DV; }
+    else if (s == "ln") { src = n->ln; C = n->DV; }
+    else if (s == "q_cur") { src = n->q_cur; C = 64; nhwc_map = false; }
+    else if (s == "lowres") { src = n->lowres; C = n->cfg.nclass; planar = true; }
+    else if (s == "cache_q" || s == "cache_k" || s == "cache_v") {
+        if (n->last_slot < 0) return td_fail("tdnet_get_stage: no frame cached yet");
+        const CacheSlot& c = n->slots[n->last_slot];
+        src = s == "cache_q" ? c.q : s == "cache_k" ? c.k : c.v;
+        C = s == "cache_v" ? n->DV : 64; rows = n->Lk; nhwc_map = false;
+    } else return td_fail("tdnet_get_stage: unknown stage \"%s\"", name);
+    const size_t count = (size_t)rows * C;
+    if (capacity < count) return td_fail("tdnet_get_stage: capacity %zu < %zu", capacity, count);
+    TD_HIP(hipDeviceSynchronize());
+    if (nhwc_map && !planar) {                                         // [HW][C] -> [C][HW] like the reference's NCHW maps
+        TD_LAUNCH(k_nhwc_to_nchw, dim3(td_grid_for((long)count)), dim3(256), 0, (hipStream_t)0, src, n->stage_tmp, rows, (int)C);
+        TD_HIP(hipDeviceSynchronize());
+        TD_HIP(hipMemcpy(host, n->stage_tmp, count * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        TD_HIP(hipMemcpy(host, src, count * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return (long)count;
+}
+
+// Algorithmic FLOP of a steady-state frame, counted as the reference executes it (fc on Lq rows)
+static double frame_flops(const tdnet* n) {
+    const PathLayers& L = n->paths[0];
+    double f = L.stem.flops_per_pixel() * n->H1 * n->W1;
+    int ch = n->H2, cw = n->W2;
+    for (size_t i = 0; i < L.blocks.size(); ++i) {
+        const BlockSpec& s = n->bspec[i];
+        const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
+        const double M = (double)oh * ow;
+        f += M * (L.blocks[i].c1.flops_per_pixel() + L.blocks[i].c2.flops_per_pixel());
+        if (s.ds) f += M * L.blocks[i].ds.flops_per_pixel();
+        ch = oh; cw = ow;
+    }
+    const double Lq = n->Lq, Lk = n->Lk, DV = n->DV;
+    f += 2.0 * (1 + 4 + 9 + 36) * 128.0 * 512;                                          // pyramid 1x1 convs on the 50 bins
+    f += Lq * (2.0 * 512 * DV + 2.0 * 512 * 64 + 2.0 * 64 * 64);                           // enc pre=False
+    f += Lk * (2.0 * 512 * DV + 2 * (2.0 * 512 * 64 + 2.0 * 64 * 64));                     // enc pre=True (q_, k_, v_)
+    if (n->P == 4) {
+        f += 2 * (2.0 * Lk * Lk * (64 + DV) + 2.0 * Lk * DV * DV);                         // two cached-frame attentions + fc
+        f += 2.0 * Lq * Lk * (64 + DV) + 2.0 * Lq * DV * DV;                               // final attention + fc on Lq rows
+    } else {
+        f += 2.0 * Lq * Lk * (64 + DV) + 2.0 * Lq * DV * DV;
+    }
+    f += Lq * (2.0 * DV * 9 * n->MID + 2.0 * n->MID * n->cfg.nclass);                       // FCNHead
+    return f;
+}
+extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->finalized ? n->flops_frame : -1.0; }
+
+extern "C" int tdnet_set_profiling(tdnet_t* n, int on) {
+    if (!n) return td_fail("tdnet_set_profiling: null handle");
+    n->prof = on != 0;
+    n->nrec = 0;
+    return 0;
+}
+// which: 0 conv/GEMM kernels, 1 attention kernels, 2 everything else, 3 the dominant kernel only (128x128-tile 3x3 igemm).
+// mode : 0 -> summed device ms, 1 -> summed algorithmic FLOP, 2 -> launch count
+static double prof_query(const tdnet* n, int which, int mode) {
+    if (!n || !n->prof || n->nrec == 0) return -1.0;
+    double ms = 0.0, fl = 0.0, cnt = 0.0;
+    for (size_t i = 0; i < n->nrec; ++i) {
+        const ProfRec& r = n->recs[i];
+        const bool take = which == 3 ? (r.family == 0 && r.dominant) : r.family == which;
+        if (!take) continue;
+        if (mode == 0) {
+            hipEventSynchronize(r.e1);
+            float t = 0.f;
+            hipEventElapsedTime(&t, r.e0, r.e1);
+            ms += t;
+        }
+        fl += r.flops; cnt += 1.0;
+    }
+    return mode == 0 ? ms : mode == 1 ? fl : cnt;
+}
+extern "C" double tdnet_last_ms(const tdnet_t* n, int which) { return prof_query(n, which, 0); }
+extern "C" double tdnet_last_flops(const tdnet_t* n, int which) { return prof_query(n, which, 1); }
+extern "C" double tdnet_last_launches(const tdnet_t* n, int which) { return prof_query(n, which, 2); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// single-operator entry points (tests)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const float* w_host, const float* bias_host, int Cout, int KS,
+                               int stride, int dil, const float* resid, int act, float* out, void* stream) {
+    if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d: KS must be 1 or 3");
+    ConvLayer L;
+    std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
+    if (bias_host) b.assign(bias_host, bias_host + Cout);
+    const int pad = dil * (KS / 2);
+    const long M = (long)out_size(H, KS, stride, dil, pad) * out_size(W, KS, stride, dil, pad);
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M)) return -1;
+    run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
+    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TD_HIP(hipGetLastError());
+    free_conv_layer(L);
+    return 0;
+}
+extern "C" int tdnet_op_conv2d_tile(const float* in, int H, int W, int Cin, const float* w_host, const float* bias_host, int Cout,
+                                    int KS, int stride, int dil, const float* resid, int act, int tile, float* out, void* stream) {
+    // same as tdnet_op_conv2d with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64) -- test/tuning hook
+    if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_tile: KS must be 1 or 3");
+    if (tile < 0 || tile > 2) return td_fail("tdnet_op_conv2d_tile: tile must be 0..2");
+    ConvLayer L;
+    std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
+    if (bias_host) b.assign(bias_host, bias_host + Cout);
+    if (Cin % 32) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
+    L.Cin = Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = false; L.pad = dil * (KS / 2);
+    L.tile = (ConvTile)tile; L.CoutPad = conv_cout_pad(Cout, L.tile); L.nsteps = conv_nsteps(Cin, KS, false);
+    std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
+    conv_pack_weights(w.data(), Cout, Cin, KS, false, L.tile, packed.data());
+    if (upload(&L.d_wp, packed)) return -1;
+    std::vector<float> bb(Cout, 0.f);
+    if (!b.empty()) bb = b;
+    if (upload(&L.d_bias, bb)) return -1;
+    run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
+    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TD_HIP(hipGetLastError());
+    free_conv_layer(L);
+    return 0;
+}
+extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host, const float* bias_host, float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int H1 = (H - 1) / 2 + 1, W1 = (W - 1) / 2 + 1;
+    ConvLayer L;
+    std::vector<float> w(w_host, w_host + 64 * 3 * 49), b;
+    if (bias_host) b.assign(bias_host, bias_host + 64);
+    if (make_conv_layer(L, w, b, 64, 3, 7, 2, 1, 1, true, (long)H1 * W1)) return -1;
+    float *img4 = nullptr, *s1 = nullptr;
+    if (dev_alloc(&img4, (size_t)H * W * 4) || dev_alloc(&s1, (size_t)H1 * W1 * 64)) return -1;
+    run_stem_pre(nullptr, img, H, W, img4, s);
+    run_conv(nullptr, L, img4, H, W, nullptr, s1, s);
+    run_maxpool(nullptr, s1, H1, W1, 64, out, s);
+    TD_HIP(hipStreamSynchronize(s));
+    TD_HIP(hipGetLastError());
+    hipFree(img4); hipFree(s1);
+    free_conv_layer(L);
+    return 0;
+}
+extern "C" int tdnet_op_attention(const float* q, const float* k, const float* vp, const float* bias, const float* resid, int Lq,
+                                  int Lk, int DV, float* out, void* stream) {
+    if (Lk < 1 || Lq < 1) return td_fail("tdnet_op_attention: empty input");
+    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, (hipStream_t)stream)) return -1;
+    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int tdnet_op_layernorm_hw(const float* x, int HW, int C, const float* g, const float* b, float* out, void* stream) {
+    if (C % 4 || 256 % (C / 4)) return td_fail("tdnet_op_layernorm_hw: C must be one of 4*{1,2,4,...,256}");
+    float *part = nullptr, *mean = nullptr, *rstd = nullptr;
+    if (dev_alloc(&part, (size_t)512 * C) || dev_alloc(&mean, C) || dev_alloc(&rstd, C)) return -1;
+    run_layernorm(nullptr, x, HW, C, g, b, part, mean, rstd, out, (hipStream_t)stream);
+    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TD_HIP(hipGetLastError());
+    hipFree(part); hipFree(mean); hipFree(rstd);
+    return 0;
+}
+extern "C" int tdnet_op_ppm(const float* c4, int h, int w, const float* w_host, const float* b_host, int path_num, int pid, float* z,
+                            void* stream) {
+    const int C = 512, FS = C / (path_num * 4);
+    if (path_num != 2) return td_fail("tdnet_op_ppm: path_num must be 2 (td4 passes path_num//2, td2 passes 2)");
+    std::vector<float> pw((size_t)4 * FS * C), pb((size_t)4 * FS);
+    for (int j = 0; j < 4; ++j)
+        for (int o = 0; o < FS; ++o) {
+            memcpy(&pw[((size_t)j * FS + o) * C], &w_host[((size_t)j * 128 + pid * FS + o) * C], C * sizeof(float));
+            pb[j * FS + o] = b_host[j * 128 + pid * FS + o];
+        }
+    float *dw = nullptr, *db = nullptr, *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr;
+    if (upload(&dw, pw) || upload(&db, pb)) return -1;
+    if (dev_alloc(&rowpart, (size_t)h * 12 * C) || dev_alloc(&pooled, 50 * C) || dev_alloc(&ppmfeat, 50 * FS)) return -1;
+    run_ppm(nullptr, c4, h, w, dw, db, pid, rowpart, pooled, ppmfeat, z, (hipStream_t)stream);
+    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TD_HIP(hipGetLastError());
+    for (float* q : {dw, db, rowpart, pooled, ppmfeat}) hipFree(q);
+    return 0;
+}
+extern "C" int tdnet_op_upsample(const float* in, int C, int h, int w, int H, int W, float* out, void* stream) {
+    TD_LAUNCH(k_upsample, dim3(td_grid_for((long)C * H * W, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, in, out, C, h, w, H, W);
+    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    TD_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,82 @@
+"""Thin, torch-free owner of one tdnet handle (one video stream on one GPU).
+
+Pointers are plain integers: the model classes pass `tensor.data_ptr()` of torch-ROCm tensors; PyTorch is plumbing
+for device memory and streams only.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _capi
+
+
+def _ptr(a):
+    """int address of a numpy array / integer pointer / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    return a.ctypes.data
+
+
+class Engine:
+    def __init__(self, model, backbone, nclass, height, width, device=0, lib=None):
+        self.lib = lib or _capi.lib()
+        self.cfg = _capi.TdnetCfg(model, backbone, nclass, height, width, device)
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.tdnet_create(ctypes.byref(self.cfg), ctypes.byref(h)))
+        self.h = h
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tdnet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights: strict, like load_state_dict(strict=True) (td4_psp18.py:236-237)
+    def load_state_dict(self, sd):
+        for name, v in sd.items():
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32)).reshape(-1)
+            if a.size == 0:
+                a = np.zeros(1, np.float32)
+            self.lib.check(self.lib.tdnet_set_weight(self.h, name.encode(), a.ctypes.data, a.size))
+        self.lib.check(self.lib.tdnet_finalize_weights(self.h))
+        self.finalized = True
+
+    def forward(self, img_ptr, pos_id, logits_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_forward(self.h, _ptr(img_ptr), int(pos_id), _ptr(logits_ptr), stream))
+
+    def forward_labels(self, img_ptr, pos_id, labels_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_forward_labels(self.h, _ptr(img_ptr), int(pos_id), _ptr(labels_ptr), stream))
+
+    def argmax(self, logits_ptr, labels_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_argmax(self.h, _ptr(logits_ptr), _ptr(labels_ptr), stream))
+
+    def reset(self):
+        self.lib.check(self.lib.tdnet_reset(self.h))
+
+    def fifo_len(self):
+        return self.lib.tdnet_fifo_len(self.h)
+
+    def stage(self, name, shape):
+        out = np.empty(int(np.prod(shape)), np.float32)
+        n = self.lib.check(self.lib.tdnet_get_stage(self.h, name.encode(), out.ctypes.data, out.size))
+        assert n == out.size, (name, n, out.size)
+        return out.reshape(shape)
+
+    def flops_per_frame(self):
+        return self.lib.tdnet_flops_per_frame(self.h)
+
+    def set_profiling(self, on):
+        self.lib.check(self.lib.tdnet_set_profiling(self.h, int(on)))
+
+    def last(self, which):
+        """(ms, algorithmic flop, launches) of a kernel family in the last forward; see include/tdnet.h."""
+        return (self.lib.tdnet_last_ms(self.h, which), self.lib.tdnet_last_flops(self.h, which),
+                self.lib.tdnet_last_launches(self.h, which))

@@ -1,0 +1,27 @@
+"""Build tests/emu/_build/libtdnet_emu.so: the product sources compiled for the HOST against the test-only
+fiber emulator (tests/emu/td_device.h force-included ahead of the real header).  Test infrastructure only."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build", "libtdnet_emu.so")
+CXX = "/opt/rocm/lib/llvm/bin/clang++"
+SRCS = [os.path.join(ROOT, "tdnet_amd", "csrc", f) for f in ("td_model.hip", "td_device.h", "td_conv.h", "td_attn.h", "td_misc.h")] + \
+       [os.path.join(HERE, f) for f in ("td_device.h", "tdemu.cpp")] + [os.path.join(ROOT, "include", "tdnet.h")]
+
+
+def build(force=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SRCS):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-psabi",
+           "-include", os.path.join(HERE, "td_device.h"),
+           "-x", "c++", os.path.join(ROOT, "tdnet_amd", "csrc", "td_model.hip"), os.path.join(HERE, "tdemu.cpp"), "-o", OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv))

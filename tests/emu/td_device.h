@@ -1,0 +1,89 @@
+// tests/emu/td_device.h -- TEST-ONLY host stand-in for tdnet_amd/csrc/td_device.h.
+//
+// Purpose: execute the UNMODIFIED kernel sources (td_conv.h, td_attn.h, td_misc.h, td_model.hip) lane by lane on the
+// CPU so their index math (LDS images, MFMA operand/accumulator maps, k-permutation, weight packing, epilogues, the
+// whole per-frame orchestration) can be checked against the oracle in this GPU-less container before GPU minutes
+// are spent.  It is compiled only into tests/emu/_build/libtdnet_emu.so by tests/emu/build_emu.py and loaded only by
+// tests/test_emu_*.py.  Nothing under tdnet_amd/ references it; the product library is hipcc + the real header.
+//
+// Model: one workgroup = blockDim fibers (user-level contexts) run round-robin on one OS thread; __syncthreads and
+// the wave-collective ops (MFMA, shuffle) are barriers over fibers.  The MFMA follows the documented gfx950 maps:
+//   A lane l -> A[i=l&31][k=l>>5], B lane l -> B[k=l>>5][j=l&31], D reg r of lane l -> D[(r&3)+8(r>>2)+4(l>>5)][l&31],
+//   result = fma(a_k1, b_k1, fma(a_k0, b_k0, c))   (cdna_hip_programming.md §3).
+#ifndef TD_DEVICE_H   // same guard as the real header: the emu build force-includes this file first
+#define TD_DEVICE_H
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+// ---- HIP runtime stand-ins ("device" memory is host memory) ------------------------------------------------------
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+typedef void* hipStream_t;
+struct tdemu_event { double t; };
+typedef tdemu_event* hipEvent_t;
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+
+// ---- execution model ------------------------------------------------------------------------------------------------
+namespace tdemu {
+struct Idx { unsigned x, y, z; };
+struct Fiber {
+    void* sp;
+    Idx tidx;
+    unsigned seq;       // wave-collective sequence number (double-buffer selector)
+    bool done;
+};
+extern thread_local Fiber* cur;
+extern thread_local Idx g_blockIdx, g_gridDim, g_blockDim;
+extern thread_local char* g_lds;
+void syncthreads();
+f32x16 mfma32(float a, float b, f32x16 c);
+float shfl_xor(float v, int mask);
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
+}  // namespace tdemu
+
+#define threadIdx (tdemu::cur->tidx)
+#define blockIdx (tdemu::g_blockIdx)
+#define gridDim (tdemu::g_gridDim)
+#define blockDim (tdemu::g_blockDim)
+#define __syncthreads() tdemu::syncthreads()
+
+#define TD_KERNEL static
+#define TD_DEV static inline
+#define TD_HOSTDEV static inline
+#define TD_LAUNCH_BOUNDS(t, w)
+#define TD_DYN_LDS(name) char* name = tdemu::g_lds
+#define TD_LAUNCH(kern, grid, block, lds, stream, ...) \
+    tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds))
+
+TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }
+TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
+TD_DEV float td_exp2(float x) { return exp2f(x); }
+TD_DEV int td_lane() { return threadIdx.x & 63; }
+TD_DEV int td_wave() { return threadIdx.x >> 6; }
+#endif  // TD_DEVICE_H
