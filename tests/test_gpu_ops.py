@@ -1,0 +1,70 @@
+"""GPU parity, operator level: each hand-written HIP kernel family through the C ABI vs the same op in PyTorch fp32
+on CPU, on ragged small shapes and on the real TDNet shapes."""
+import pytest
+import torch
+
+import opcheck
+from tdnet_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available()
+    return _capi.lib()                      # the in-tree libtdnet_hip.so; raises if it is missing
+
+
+@pytest.fixture(scope="module")
+def mem():
+    return opcheck.TorchMem()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_conv_variants(lib, mem, tile):
+    opcheck.conv(lib, mem, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)
+    opcheck.conv(lib, mem, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)
+    opcheck.conv(lib, mem, 11, 19, 64, 19, 1, 1, 1, 2, False, tile)
+    opcheck.conv(lib, mem, 17, 9, 128, 64, 1, 2, 1, 0, True, tile)
+    opcheck.conv(lib, mem, 12, 30, 64, 160, 3, 1, 4, 1, False, tile)
+    opcheck.conv(lib, mem, 97, 193, 64, 128, 3, 1, 2, 1, True, tile)      # native 769x1537 feature size, many ragged tiles
+
+
+def test_conv_real_shapes(lib, mem):
+    opcheck.conv(lib, mem, 64, 128, 64, 64, 3, 1, 1, 1, True)             # layer1-like
+    opcheck.conv(lib, mem, 64, 128, 64, 128, 3, 2, 1, 1, False)           # layer2.0.conv1
+    opcheck.conv(lib, mem, 64, 128, 64, 128, 1, 2, 1, 0, False)           # layer2.0.downsample
+    opcheck.conv(lib, mem, 32, 64, 256, 256, 3, 1, 2, 1, True)            # layer3
+    opcheck.conv(lib, mem, 32, 64, 256, 512, 3, 1, 4, 1, False)           # layer4.0.conv1
+    opcheck.conv(lib, mem, 32, 64, 512, 512, 3, 1, 8, 1, True, tol=2e-4)  # layer4.1.conv1, K = 4608
+    opcheck.conv(lib, mem, 32, 64, 512, 512, 3, 1, 16, 1, True, tol=2e-4) # resnet34 multi-grid 16
+    opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tol=2e-4)   # the dominant kernel at its real size
+    opcheck.conv(lib, mem, 128, 256, 512, 64, 1, 4, 1, 2, False)          # w_ks.0 on the stride-4 key grid
+    opcheck.conv(lib, mem, 1, 2048, 512, 512, 1, 1, 1, 0, False)          # attention fc on the cached value matrix
+    opcheck.conv(lib, mem, 40, 40, 512, 128, 3, 1, 1, 1, False)           # FCNHead conv
+
+
+def test_stem(lib, mem):
+    opcheck.stem(lib, mem, 33, 65)
+    opcheck.stem(lib, mem, 257, 513)
+    opcheck.stem(lib, mem, 300, 422)
+
+
+def test_attention(lib, mem):
+    opcheck.attention(lib, mem, 45, 6, 512)
+    opcheck.attention(lib, mem, 300, 200, 512, spike=True)
+    opcheck.attention(lib, mem, 200, 131, 128, True, False, qk_scale=2.0)
+    opcheck.attention(lib, mem, 1, 1, 128)
+    opcheck.attention(lib, mem, 2048, 2048, 512)                           # cached-frame propagation step
+    opcheck.attention(lib, mem, 18721, 1225, 512)                          # native 769x1537: ragged Lq and Lk
+    opcheck.attention(lib, mem, 8192, 512, 128, qk_scale=1.5)              # td2 @512x1024
+    opcheck.attention(lib, mem, 32768, 2048, 512, spike=True)              # final step @1024x2048
+
+
+def test_layernorm_ppm_upsample(lib, mem):
+    for hw, c in [(45, 512), (153, 128), (1000, 512), (32768, 512), (18721, 128)]:
+        opcheck.layernorm(lib, mem, hw, c)
+    for h, w, pid in [(5, 9, 0), (9, 17, 1), (13, 25, 1), (97, 193, 0), (128, 256, 1)]:
+        opcheck.ppm(lib, mem, h, w, pid)
+    for c, h, w, H, W in [(19, 5, 9, 33, 65), (19, 97, 193, 769, 1537), (19, 128, 256, 1024, 2048)]:
+        opcheck.upsample(lib, mem, c, h, w, H, W)
