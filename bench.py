@@ -130,8 +130,7 @@ def main():
         # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) ------------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import tdnet_ref                                          # checker / baseline only
-            cores = os.cpu_count() or 1
-            torch.set_num_threads(cores)
+            cores = tdnet_ref.tune_threads()          # threads actually used (fastest of 8..128 on a probe conv)
             ref = tdnet_ref.TDNetRef(spec, sd)
             model.reset()
             nwarm, nsteady = P, max(1, args.cpu_frames)
@@ -154,8 +153,8 @@ def main():
             iu = np.diag(hist) / np.maximum(1, hist.sum(1) + hist.sum(0) - np.diag(hist))
             res["cpu_baseline"] = {"value": round(nsteady / cpu_t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d steady-state frames of the same clip (after %d warm-up frames), oracle/tdnet_ref.py "
-                                             "= the reference's op graph on torch-CPU %s with %d threads"
-                                             % (nsteady, nwarm, torch.__version__, cores)}
+                                             "= the reference's op graph on torch-CPU %s with %d threads (host has %d)"
+                                             % (nsteady, nwarm, torch.__version__, cores, os.cpu_count() or 1)}
             res["parity"] = {"frames": nwarm + nsteady, "max_abs_dlogit": float("%.3e" % worst), "label_mismatches": flips,
                              "pixels": npx, "miou_vs_cpu": round(float(iu[hist.sum(1) > 0].mean()), 6)}
         print(json.dumps(res), flush=True)

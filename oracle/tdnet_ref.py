@@ -181,6 +181,27 @@ class TDNetRef:
         return F.interpolate(out, (h, w), mode="bilinear", align_corners=True)
 
 
+def tune_threads(candidates=(8, 16, 32, 64, 128)):
+    """Pick the torch-CPU thread count that runs a representative dilated conv fastest (oneDNN collapses when it is
+    given every SMT thread of a 256-thread host: measured 42 s/frame vs ~2.5 s on 8 cores).  Returns the count set."""
+    import time
+    cores = os.cpu_count() or 1
+    cands = sorted({min(c, cores) for c in candidates})
+    x, w = torch.randn(1, 256, 64, 128), torch.randn(256, 256, 3, 3)
+    best, best_t = cands[0], None
+    for n in cands:
+        torch.set_num_threads(n)
+        F.conv2d(x, w, None, 1, 2, 2)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            F.conv2d(x, w, None, 1, 2, 2)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = n, dt
+    torch.set_num_threads(best)
+    return best
+
+
 def confusion_miou(pred, ref, n_class):
     """mIoU of `pred` against `ref` labels via the confusion-matrix formula of Training/ptsemseg/metrics.py:12-35."""
     import numpy as np

@@ -59,26 +59,22 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int q0 = (blockIdx.x * QW + qw) * 32;                  // first query of this wave's tile
 
     // ---- this lane's query row, pre-scaled so that exp(s/8 - max) = exp2(S - M) -------------------------------
+    // Out-of-range rows/keys are CLAMPED to the last valid one instead of branched around: the loads stay
+    // unconditional (so they can be issued far ahead of their MFMAs) and the results are masked where they matter.
     f32x4 qf[8];
     {
-        const int q = q0 + l31;
+        const int q = (q0 + l31 < p.Lq) ? q0 + l31 : p.Lq - 1;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < p.Lq) v = td_ld4(p.q + (size_t)q * 64 + 8 * g + 4 * half);
-            qf[g] = v * p.scale_log2e;
-        }
+        for (int g = 0; g < 8; ++g) qf[g] = td_ld4(p.q + (size_t)q * 64 + 8 * g + 4 * half) * p.scale_log2e;
     }
-    // S^T tile of 32 keys starting at kb: returns this lane's 16 scores (query l31, keys (r&3)+8(r>>2)+4half)
-    auto score_tile = [&](int kb) -> f32x16 {
-        f32x4 kf[8];
-        const int key = kb + l31;
+    const int key_last = p.Lk - 1;
+    auto load_k = [&](int kb, f32x4 (&kf)[8]) {
+        const int key = (kb + l31 < p.Lk) ? kb + l31 : key_last;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (key < p.Lk) v = td_ld4(p.k + (size_t)key * 64 + 8 * g + 4 * half);
-            kf[g] = v;
-        }
+        for (int g = 0; g < 8; ++g) kf[g] = td_ld4(p.k + (size_t)key * 64 + 8 * g + 4 * half);
+    };
+    // S^T tile of 32 keys: this lane's 16 scores (query l31, keys kb + (r&3)+8(r>>2)+4half)
+    auto score_tile = [&](const f32x4 (&kf)[8]) -> f32x16 {
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -92,16 +88,22 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int nsuper = (p.Lk + SK - 1) / SK;
     const float NEG = -3.0e38f;
 
-    // ---- pass 1: row maxima ----------------------------------------------------------------------------------
+    // ---- pass 1: row maxima (next key tile in flight while the current one is multiplied) ----------------------
     float mx = NEG;
-    for (int st = 0; st < nsuper; ++st) {
-        const int kb = st * SK + cw * 32;
-        if (kb >= p.Lk) break;
-        const f32x16 s = score_tile(kb);
+    {
+        f32x4 kf[8], kn[8];
+        load_k(cw * 32, kf);
+        for (int st = 0; st < nsuper; ++st) {
+            const int kb = st * SK + cw * 32;
+            if (st + 1 < nsuper) load_k(kb + SK, kn);
+            const f32x16 s = score_tile(kf);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-            mx = (key < p.Lk && s[r] > mx) ? s[r] : mx;
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                mx = (key < p.Lk && s[r] > mx) ? s[r] : mx;
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) kf[g] = kn[g];
         }
     }
     mx = fmaxf(mx, td_shfl_xor(mx, 32));
@@ -119,21 +121,30 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float lsum = 0.f;
     const int cb = cw * (NT * 32) + l31 * NT;                     // this lane's first output channel
+    const float* vbase = p.vp + cb;
+    // V' rows of k-group G of the super-tile starting at kbase: 4 keys per lane-half, one float4 (4 channels) each
+    auto load_v = [&](int kbase, int G, f32x4 (&b)[4]) {
+        const int key0 = kbase + 4 * (2 * G + half);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int key = (key0 + e < p.Lk) ? key0 + e : key_last;     // P is exactly 0 for masked keys
+            b[e] = td_ld4(vbase + (size_t)key * DV);
+        }
+    };
+    f32x4 kf[8];
+    load_k(cw * 32, kf);
     for (int st = 0; st < nsuper; ++st) {
-        const int kb = st * SK + cw * 32;
+        const int kbase = st * SK, kb = kbase + cw * 32;
+        f32x4 bb[2][4];
+        load_v(kbase, 0, bb[0]);                                  // in flight under the 32 score MFMAs
+        const f32x16 s = score_tile(kf);
         f32x16 pr;
-        if (kb < p.Lk) {
-            const f32x16 s = score_tile(kb);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float e = (key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
-                pr[r] = e;
-                lsum += e;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pr[r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float e = (key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
+            pr[r] = e;
+            lsum += e;
         }
         float* Pw = Ps + (st & 1) * L::P_FLOATS + qw * (8 * CW * 128);
 #pragma unroll
@@ -142,18 +153,17 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             td_st4(Pw + ((cw * 8 + 2 * u + half) * 32 + l31) * 4, v);
         }
         __syncthreads();
-        const int kbase = st * SK;
-#pragma unroll 4
+        if (st + 1 < nsuper) load_k(kb + SK, kf);                 // next key tile, hidden under the P V' MFMAs
+#pragma unroll
         for (int G = 0; G < 4 * CW; ++G) {
+            if (G + 1 < 4 * CW) load_v(kbase, G + 1, bb[(G + 1) & 1]);
             const f32x4 a4 = td_ld4(Pw + ((2 * G + half) * 32 + l31) * 4);
-            const int key0 = kbase + 4 * (2 * G + half);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                if (key0 + e < p.Lk) b4 = td_ld4(p.vp + (size_t)(key0 + e) * DV + cb);
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = td_mfma32(a4[e], b4[j], acc[j]);
-            }
+                for (int j = 0; j < NT; ++j) acc[j] = td_mfma32(a4[e], bb[G & 1][e][j], acc[j]);
+            if (G + 1 < 4 * CW) { TD_SCHED_GROUP(0x020, 4); TD_SCHED_GROUP(0x100, 1); }
+            TD_SCHED_GROUP(0x008, 4 * NT);
         }
     }
     // ---- row sums -> 1/l, epilogue ---------------------------------------------------------------------------

@@ -143,19 +143,37 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         }
         const float* As = lds + (step & 1) * L::BUF_FLOATS + (wm * WM + l31) * 4;
         const float* Bs = lds + (step & 1) * L::BUF_FLOATS + L::A_FLOATS + (wn * WN + l31) * 4;
+        // operand fragments are fetched one k-group ahead of the MFMAs that consume them (register double buffer)
+        f32x4 af[2][MT], bf[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = td_ld4(As + half * L::A_STRIDE + i * 128);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[0][j] = td_ld4(Bs + half * L::B_STRIDE + j * 128);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 af[MT], bf[NT];
+            if (g < 3) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = td_ld4(As + (2 * g + half) * L::A_STRIDE + i * 128);
+                for (int i = 0; i < MT; ++i) af[(g + 1) & 1][i] = td_ld4(As + (2 * g + 2 + half) * L::A_STRIDE + i * 128);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = td_ld4(Bs + (2 * g + half) * L::B_STRIDE + j * 128);
+                for (int j = 0; j < NT; ++j) bf[(g + 1) & 1][j] = td_ld4(Bs + (2 * g + 2 + half) * L::B_STRIDE + j * 128);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = td_mfma32(af[i][s], bf[j][s], acc[i][j]);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = td_mfma32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j]);
+            // pin the interleave: the next group's LDS reads are spread between this group's MFMAs instead of being
+            // sunk to their first use (where every group would start with an exposed LDS round trip)
+            if (g < 3) {
+#pragma unroll
+                for (int r = 0; r < MT + NT; ++r) {
+                    TD_SCHED_GROUP(0x100, 1);
+                    TD_SCHED_GROUP(0x008, (4 * MT * NT) / (MT + NT));
+                }
+            } else {
+                TD_SCHED_GROUP(0x008, 4 * MT * NT);
+            }
         }
         if (more) store_tile((step + 1) & 1);
         __syncthreads();

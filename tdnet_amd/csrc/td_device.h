@@ -24,6 +24,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
+#define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
 TD_DEV float td_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 TD_DEV float td_exp2(float x) { return exp2f(x); }
 TD_DEV int td_lane() { return threadIdx.x & 63; }

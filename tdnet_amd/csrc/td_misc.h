@@ -50,20 +50,16 @@ TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ ou
 TD_HOSTDEV int td_bin_lo(int i, int n, int o) { return (i * n) / o; }
 TD_HOSTDEV int td_bin_hi(int i, int n, int o) { return ((i + 1) * n + o - 1) / o; }
 
-// grid = h rows, block = C/4 threads; rowpart [h][12][C]
+// grid = h rows x 12 x-bins (one workgroup per (row, bin): 1536 groups at 128x256), block = C/4 threads; rowpart [h][12][C]
 TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C) {
-    const int y = blockIdx.x, cv = threadIdx.x;
+    const int y = blockIdx.x / 12, b = blockIdx.x % 12, cv = threadIdx.x;
+    const int o = b >= 6 ? 6 : b >= 3 ? 3 : b >= 1 ? 2 : 1;
+    const int i = b >= 6 ? b - 6 : b >= 3 ? b - 3 : b >= 1 ? b - 1 : 0;
     const float* row = c4 + (size_t)y * w * C + cv * 4;
-    int b = 0;
-    for (int lvl = 0; lvl < 4; ++lvl) {
-        const int o = lvl == 0 ? 1 : lvl == 1 ? 2 : lvl == 2 ? 3 : 6;
-        for (int i = 0; i < o; ++i, ++b) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
-            for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
-            td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
-        }
-    }
+    const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
+    td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
 }
 // grid = 50 bins, block = C/4; pooled [50][C] = mean over the bin.  bin order: level-major, then by, then bx.
 TD_KERNEL void k_ppm_bins(const float* __restrict__ rowpart, float* __restrict__ pooled, int h, int w, int C) {
@@ -85,10 +81,10 @@ TD_KERNEL void k_ppm_conv(const float* __restrict__ pooled, const float* __restr
                           float* __restrict__ feat, int C, int FS) {
     const int bin = blockIdx.x, f = threadIdx.x;
     const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
-    const float* wr = wgt + ((size_t)lvl * FS + f) * C;
+    const float* wr = wgt + (size_t)lvl * C * FS + f;            // weights stored [lvl][c][f]: lanes read consecutive f
     const float* pv = pooled + (size_t)bin * C;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(wr[c], pv[c], s);
+    for (int c = 0; c < C; ++c) s = fmaf(wr[(size_t)c * FS], pv[c], s);
     s += bias[lvl * FS + f];
     feat[(size_t)bin * FS + f] = s > 0.f ? s : 0.f;
 }
@@ -148,15 +144,26 @@ TD_KERNEL void k_ln_partial(const float* __restrict__ x, const float* __restrict
         td_st4(part + (size_t)blockIdx.x * C + cv * 4, s);
     }
 }
-// pass B: out[c] = mode 0: sum/HW (mean) ; mode 1: 1/sqrt(sum/HW + eps) (rstd).  one thread per channel.
+// pass B: out[c] = mode 0: sum/HW (mean) ; mode 1: 1/sqrt(sum/HW + eps) (rstd).
+// grid = C/16, block = 256 = 16 channels x 16 strip slices; fixed summation order (deterministic).
 TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int HW, int C, int mode, float eps,
                              float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    TD_DYN_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);               // [16 slices][16 channels]
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int k = 0; k < nstrips; ++k) s += part[(size_t)k * C + c];
-    s /= (float)HW;
-    out[c] = mode ? 1.0f / sqrtf(s + eps) : s;
+    if (c < C)
+        for (int k = sl; k < nstrips; k += 16) s += part[(size_t)k * C + c];
+    red[sl * 16 + cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
+        t /= (float)HW;
+        out[c] = mode ? 1.0f / sqrtf(t + eps) : t;
+    }
 }
 // pass C: y = (x - mean[c]) * rstd[c] * g[p] + b[p]
 TD_KERNEL void k_ln_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -224,6 +231,29 @@ TD_KERNEL void k_upsample(const float* __restrict__ in, float* __restrict__ out,
         const float v00 = pl[cy.i0 * w + cx.i0], v01 = pl[cy.i0 * w + cx.i1];
         const float v10 = pl[cy.i1 * w + cx.i0], v11 = pl[cy.i1 * w + cx.i1];
         out[i] = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
+    }
+}
+// same arithmetic, 4 consecutive output columns per lane and one 16-byte store (W % 4 == 0): the 159 MB logits write
+// of a 1024x2048 frame is the largest single HBM stream of the path
+TD_KERNEL void k_upsample_x4(const float* __restrict__ in, float* __restrict__ out, int C, int h, int w, int H, int W) {
+    const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const int W4 = W >> 2;
+    const long total = (long)C * H * W4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int X4 = (int)(i % W4);
+        const long t = i / W4;
+        const int Y = (int)(t % H), c = (int)(t / H);
+        const UpCoef cy = td_up_coef(Y, sy, h);
+        const float* r0 = in + ((size_t)c * h + cy.i0) * w;
+        const float* r1 = in + ((size_t)c * h + cy.i1) * w;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const UpCoef cx = td_up_coef(X4 * 4 + e, sx, w);
+            o[e] = (1.f - cy.l) * ((1.f - cx.l) * r0[cx.i0] + cx.l * r0[cx.i1]) + cy.l * ((1.f - cx.l) * r1[cx.i0] + cx.l * r1[cx.i1]);
+        }
+        td_st4(out + ((size_t)c * H + Y) * W + X4 * 4, o);
     }
 }
 // argmax over classes, first maximum wins (== output.max(1)[1], test.py:61); labels int32 [H][W]

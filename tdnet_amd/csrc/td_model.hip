@@ -385,7 +385,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             snprintf(b, sizeof(b), "psp%d.conv%d", p + 1, j + 1);
             Folded f = fold(n, std::string(b) + ".0.weight", "", std::string(b) + ".1", 128);
             for (int o = 0; o < FS; ++o) {
-                memcpy(&pw[((size_t)j * FS + o) * C], &f.w[(size_t)(L.pid * FS + o) * C], C * sizeof(float));
+                for (int c = 0; c < C; ++c) pw[((size_t)j * C + c) * FS + o] = f.w[(size_t)(L.pid * FS + o) * C + c];   // [lvl][c][f]
                 pb[j * FS + o] = f.b[L.pid * FS + o];
             }
         }
@@ -484,9 +484,9 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
     const int lds = rows * C * 4;
     prof_begin(n, 2, false, 0, s);
     TD_LAUNCH(k_ln_partial, dim3(nstr), dim3(256), lds, s, x, (const float*)nullptr, part, HW, C, 0);
-    TD_LAUNCH(k_ln_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)part, nstr, HW, C, 0, 1e-5f, mean);
+    TD_LAUNCH(k_ln_finalize, dim3((C + 15) / 16), dim3(256), 1024, s, (const float*)part, nstr, HW, C, 0, 1e-5f, mean);
     TD_LAUNCH(k_ln_partial, dim3(nstr), dim3(256), lds, s, x, (const float*)mean, part, HW, C, 1);
-    TD_LAUNCH(k_ln_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)part, nstr, HW, C, 1, 1e-5f, rstd);
+    TD_LAUNCH(k_ln_finalize, dim3((C + 15) / 16), dim3(256), 1024, s, (const float*)part, nstr, HW, C, 1, 1e-5f, rstd);
     TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
     prof_end(n, s);
 }
@@ -495,7 +495,7 @@ static void run_ppm(tdnet* n, const float* c4, int h, int w, const float* wgt, c
                     float* pooled, float* ppmfeat, float* z, hipStream_t s) {
     const int C = 512, XS = 256, FS = 64;
     prof_begin(n, 2, false, 0, s);
-    TD_LAUNCH(k_ppm_rowsum, dim3(h), dim3(C / 4), 0, s, c4, rowpart, w, C);
+    TD_LAUNCH(k_ppm_rowsum, dim3(h * 12), dim3(C / 4), 0, s, c4, rowpart, w, C);
     TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
     TD_LAUNCH(k_ppm_conv, dim3(50), dim3(FS), 0, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
     TD_LAUNCH(k_ppm_assemble, dim3(td_grid_for((long)h * w * (C / 4))), dim3(256), 0, s, c4, (const float*)ppmfeat, z, h, w, C,
@@ -521,6 +521,11 @@ static int run_classifier(tdnet* n, const float* x, int HW, int C, int NC, const
     else TD_LAUNCH((k_classifier<32>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
     prof_end(n, s);
     return 0;
+}
+
+static void launch_upsample(const float* in, int C, int h, int w, int H, int W, float* out, hipStream_t s) {
+    if (W % 4 == 0) TD_LAUNCH(k_upsample_x4, dim3(td_grid_for((long)C * H * (W / 4), 256, 256 * 16)), dim3(256), 0, s, in, out, C, h, w, H, W);
+    else TD_LAUNCH(k_upsample, dim3(td_grid_for((long)C * H * W, 256, 256 * 16)), dim3(256), 0, s, in, out, C, h, w, H, W);
 }
 
 // low-resolution logits of one frame (planar [nclass][h*w]) + FIFO update
@@ -600,8 +605,7 @@ extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* lo
     hipStream_t s = (hipStream_t)stream;
     if (forward_lowres(n, img, pos_id, s)) return -1;
     prof_begin(n, 2, false, 0, s);
-    TD_LAUNCH(k_upsample, dim3(td_grid_for((long)n->cfg.nclass * n->H * n->W, 256, 256 * 16)), dim3(256), 0, s,
-              (const float*)n->lowres, logits, n->cfg.nclass, n->h, n->w, n->H, n->W);
+    launch_upsample(n->lowres, n->cfg.nclass, n->h, n->w, n->H, n->W, logits, s);
     prof_end(n, s);
     TD_HIP(hipGetLastError());
     return 0;
@@ -807,7 +811,7 @@ extern "C" int tdnet_op_ppm(const float* c4, int h, int w, const float* w_host, 
     std::vector<float> pw((size_t)4 * FS * C), pb((size_t)4 * FS);
     for (int j = 0; j < 4; ++j)
         for (int o = 0; o < FS; ++o) {
-            memcpy(&pw[((size_t)j * FS + o) * C], &w_host[((size_t)j * 128 + pid * FS + o) * C], C * sizeof(float));
+            for (int c = 0; c < C; ++c) pw[((size_t)j * C + c) * FS + o] = w_host[((size_t)j * 128 + pid * FS + o) * C + c];
             pb[j * FS + o] = b_host[j * 128 + pid * FS + o];
         }
     float *dw = nullptr, *db = nullptr, *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr;
@@ -820,7 +824,7 @@ extern "C" int tdnet_op_ppm(const float* c4, int h, int w, const float* w_host, 
     return 0;
 }
 extern "C" int tdnet_op_upsample(const float* in, int C, int h, int w, int H, int W, float* out, void* stream) {
-    TD_LAUNCH(k_upsample, dim3(td_grid_for((long)C * H * W, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, in, out, C, h, w, H, W);
+    launch_upsample(in, C, h, w, H, W, out, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
     return 0;

@@ -8,7 +8,9 @@ a counter-based generator (numpy Philox) keyed by (seed, crc32(tensor name)).
 BN statistics/affine, conv biases and the LayerNorm affine are randomised on purpose: with default
 (identity-like) BN a wrong BN fold would go unnoticed (SURVEY.md §7 "hard parts").
 """
+import re
 import zlib
+
 import numpy as np
 
 from . import arch
@@ -66,9 +68,25 @@ def synth_tensor(name, shape, seed):
     raise ValueError("no rule for %s %s" % (name, shape))
 
 
+_BN2 = re.compile(r"^pretrained\d+\.layer\d\.\d+\.bn2\.weight$")
+
+
 def synth_state_dict(spec, h, w, seed=0):
-    """{name: np.ndarray} with exactly the reference's keys for `spec` at feature size h x w."""
-    return {k: synth_tensor(k, s, seed) for k, s in arch.state_dict_shapes(spec, h, w).items()}
+    """{name: np.ndarray} with exactly the reference's keys for `spec` at feature size h x w.
+
+    The gamma of every residual branch's last BN is scaled by (8 / n_blocks)^0.77: each BasicBlock adds its branch
+    variance to the trunk, so an un-normalised 16-block ResNet-34 ends ~2x hotter than the 8-block ResNet-18, the
+    attention scores grow with it and fp32 evaluations of the same graph drift apart (see QK_GAIN above).  The factor
+    is 1 for ResNet-18."""
+    nblocks = len(arch.backbone_blocks(spec.backbone))
+    g2 = np.float32((8.0 / nblocks) ** 0.77)          # measured: keeps c4 rms of ResNet-34 at the ResNet-18 level
+    out = {}
+    for k, s in arch.state_dict_shapes(spec, h, w).items():
+        t = synth_tensor(k, s, seed)
+        if g2 != 1.0 and _BN2.match(k):
+            t = t * g2
+        out[k] = t
+    return out
 
 
 def synth_video(H, W, n_frames, seed=0):

@@ -16,7 +16,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SRCS):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-Wno-psabi",
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-ffp-contract=off", "-Wno-psabi",
            "-include", os.path.join(HERE, "td_device.h"),
            "-x", "c++", os.path.join(ROOT, "tdnet_amd", "csrc", "td_model.hip"), os.path.join(HERE, "tdemu.cpp"), "-o", OUT]
     subprocess.run(cmd, check=True)

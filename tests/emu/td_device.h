@@ -81,6 +81,8 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
 #define TD_LAUNCH(kern, grid, block, lds, stream, ...) \
     tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds))
 
+#define TD_SCHED_GROUP(mask, n) ((void)0)
+
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }
 TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
 TD_DEV float td_exp2(float x) { return exp2f(x); }

@@ -63,7 +63,7 @@ def _vs_oracle(name, bb, H, W, T):
     spec = arch.model_spec(name, 19, bb)
     ref = tdnet_ref.TDNetRef(spec, weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0))
     m = make_model(name, bb)
-    torch.set_num_threads(os.cpu_count() or 8)
+    tdnet_ref.tune_threads()
     worst, flips = 0.0, 0
     with torch.no_grad():
         for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
