@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--backbone", default="resnet18")
     ap.add_argument("--size", default="1024x2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch (default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="steady-state frames timed on the CPU oracle")
     args = ap.parse_args()
     H, W = (int(v) for v in args.size.lower().split("x"))
@@ -55,6 +56,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.conv_pipeline is not None:
+        from tdnet_amd import _capi
+        _capi.lib().tdnet_set_conv_pipeline(args.conv_pipeline)
     spec = arch.model_spec(args.model, 19, args.backbone)
     P = spec.path_num
     h, w = arch.feat_size(H), arch.feat_size(W)

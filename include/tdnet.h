@@ -74,6 +74,15 @@ double tdnet_last_ms(const tdnet_t* h, int which);
 double tdnet_last_flops(const tdnet_t* h, int which);
 double tdnet_last_launches(const tdnet_t* h, int which);
 
+/* Tuning hook (process-wide): conv software pipeline used by handles finalized after the call.
+ * 0 = one-stage prefetch (tile s+1 in flight), 1 = two-stage (tile s+2 in flight, LDS writes between the MFMAs).     */
+int tdnet_set_conv_pipeline(int deep);
+
+/* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
+ * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */
+double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* stream);
+double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile, int iters, void* stream);
+
 const char* tdnet_last_error(void);
 const char* tdnet_version(void);
 
@@ -82,7 +91,7 @@ const char* tdnet_version(void);
  * [Ho,Wo,Cout] or NULL, act 0 none / 1 ReLU / 2 LeakyReLU(0.01); out [Ho,Wo,Cout] dev.                           */
 int tdnet_op_conv2d(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
                     int Cout, int KS, int stride, int dil, const float* resid_dev, int act, float* out_dev, void* stream);
-/* the same with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64) -- lets tests cover every variant */
+/* the same with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64; 3..5: the same tiles on the two-stage pipeline) -- lets tests cover every variant */
 int tdnet_op_conv2d_tile(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
                          int Cout, int KS, int stride, int dil, const float* resid_dev, int act, int tile,
                          float* out_dev, void* stream);

@@ -9,7 +9,8 @@
 //   A[m][k] is gathered on the fly from the NHWC input (zero outside the image), B is the pre-packed weight.
 //
 // Data movement per block (256 threads = 4 waves, BM x BN output tile, BK = 32 reduction slice per step):
-//   global -> registers (float4, issued one step ahead) -> LDS (double buffered, one barrier per step) -> MFMA operands.
+//   HBM/L2 -> registers (buffer_load_dwordx4; padded taps use an out-of-range offset, so the hardware bounds check
+//   returns the zeros -- no branch) -> LDS (double buffered, one barrier per step) -> MFMA operands.
 //   LDS images are [kq = 8 groups of 4 consecutive k][row][4 floats]: an MFMA lane (row = lane&31, half = lane>>5) reads
 //   ONE ds_read_b128 per operand per 4 MFMAs, conflict free (consecutive rows = consecutive 16-B slots).  Inside a group
 //   of 8 k the two lane-halves take k = 4*half + s, s = 0..3: a fixed permutation of the reduction order, applied to A
@@ -17,8 +18,16 @@
 //   The K loop runs channel-chunk outer / tap inner so the 9 shifted re-reads of an input slab hit L2 back to back.
 //   Output columns are permuted inside a wave (lane j owns NT consecutive channels j*NT..j*NT+NT-1) by the weight
 //   packer, so the epilogue stores NT*4 contiguous bytes per lane instead of 4.
+//
+// Two software pipelines over the same tile code (template DEEP):
+//   DEEP = false: tile s+1 is fetched while tile s is multiplied and written to LDS after the MFMAs (1 register set).
+//   DEEP = true : tile s+2 is fetched while tile s is multiplied; tile s+1 (fetched a whole step earlier, so already
+//                 landed) is written to LDS in between the MFMAs of step s (2 register sets, +32 VGPRs): no exposed
+//                 vmcnt wait and no ds_write tail in front of the barrier.
 #pragma once
 #include "td_device.h"
+
+#include <type_traits>
 
 struct ConvArgs {
     const float* in;      // [H][W][Cin]            (STEM: [H][W][4], channel 3 = 0)
@@ -54,11 +63,12 @@ struct ConvLds {
     static constexpr int BYTES = 2 * BUF_FLOATS * 4;
 };
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool STEM>
+template <int BM, int BN, int WGM, int WGN, int KS, bool STEM, bool DEEP>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
     constexpr int AL = BM / 32, BL = BN / 32;          // float4 slots per thread per step
+    static_assert((AL == 2 || AL == 4) && (BL == 2 || BL == 4), "staging slots are spread over the 4 k-groups");
     using L = ConvLds<BM, BN>;
     constexpr int NTAPS = STEM ? 1 : KS * KS;
     TD_DYN_LDS(smem);
@@ -72,55 +82,64 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- per-thread gather geometry: slot i -> row (tid>>3) + 32 i, k-group tid&7
+    // ---- per-thread gather geometry: slot i -> row (tid>>3) + 32 i, k-group tid&7 ------------------------------
     const int a_row = tid >> 3, a_kq = tid & 7;
     int a_by[AL], a_bx[AL];
+    unsigned a_off[AL];                                 // byte offset of the slot's top-left tap (may wrap; see below)
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         const int m = m0 + a_row + 32 * i;
         const int oy = m / p.Wo, ox = m - oy * p.Wo;
         a_by[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 28);
         a_bx[i] = ox * p.stride - p.pad;
+        a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (STEM ? 0u : (unsigned)a_kq * 4u)) * 4u;
     }
-    const float* wbase = p.wp + (size_t)n0 * 4;
+    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 4u);
+    const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
+    unsigned b_off[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
+        b_off[i] = (unsigned)(kq * p.CoutPad + n0 + n) * 16u;
+    }
+    const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
 
-    f32x4 ra[AL], rb[BL];
-    auto load_tile = [&](int step, int chunk, int tap) {
-        int dy, dx, coff;
+    // (chunk, tap) of the NEXT tile to fetch; advanced after every load_tile
+    int l_step = 0, l_chunk = 0, l_tap = 0;
+    auto load_tile = [&](f32x4 (&ra)[AL], f32x4 (&rb)[BL]) {
+        int dy, dx;
+        unsigned delta;                                 // byte offset of this tap/chunk relative to the slot's top-left tap
         bool tap_ok = true;
         if (STEM) {
-            const int t = step * 8 + a_kq;             // one 4-channel pixel per k-group: 8 taps per step
+            const int t = l_step * 8 + a_kq;            // one 4-channel pixel per k-group: 8 taps per step
             const int ky = t / 7;
-            dy = ky; dx = t - ky * 7; coff = 0; tap_ok = t < 49;
+            dy = ky; dx = t - ky * 7; tap_ok = t < 49;
+            delta = (unsigned)((dy * p.W + dx) * 4) * 4u;
         } else {
-            const int ky = tap / KS;
-            dy = ky * p.dil; dx = (tap - ky * KS) * p.dil; coff = chunk * 32 + a_kq * 4;
+            const int ky = l_tap / KS;
+            dy = ky * p.dil; dx = (l_tap - ky * KS) * p.dil;
+            delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 32) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
             const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = td_ld4(p.in + ((size_t)(iy * p.W + ix) * p.Cin + coff));
-            ra[i] = v;
+            // valid taps: a_off + delta is the exact non-negative byte offset (mod 2^32 arithmetic); padded taps read zeros
+            ra[i] = td_buf_ld4(in_buf, ok ? a_off[i] + delta : TD_BUF_OOB, 0u);
         }
-        const float* wsrc = wbase + (size_t)step * 8 * p.CoutPad * 4;
+        const unsigned wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;
 #pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
-            rb[i] = td_ld4(wsrc + ((size_t)kq * p.CoutPad + n) * 4);
-        }
+        for (int i = 0; i < BL; ++i) rb[i] = td_buf_ld4(w_buf, b_off[i], wsoff);
+        ++l_step;
+        if (++l_tap == NTAPS) { l_tap = 0; ++l_chunk; }
     };
-    auto store_tile = [&](int buf) {
-        float* As = lds + buf * L::BUF_FLOATS;
-        float* Bs = As + L::A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < AL; ++i) td_st4(As + a_kq * L::A_STRIDE + (a_row + 32 * i) * 4, ra[i]);
-#pragma unroll
-        for (int i = 0; i < BL; ++i) {
-            const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
-            td_st4(Bs + kq * L::B_STRIDE + n * 4, rb[i]);
-        }
+    // staging slot i of A / B -> LDS image of buffer `buf`
+    auto store_a = [&](int buf, int i, const f32x4 (&ra)[AL]) {
+        td_st4(lds + buf * L::BUF_FLOATS + a_kq * L::A_STRIDE + (a_row + 32 * i) * 4, ra[i]);
+    };
+    auto store_b = [&](int buf, int i, const f32x4 (&rb)[BL]) {
+        const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
+        td_st4(lds + buf * L::BUF_FLOATS + L::A_FLOATS + kq * L::B_STRIDE + n * 4, rb[i]);
     };
 
     f32x16 acc[MT][NT];
@@ -131,19 +150,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int chunk = 0, tap = 0;
-    load_tile(0, 0, 0);
-    store_tile(0);
-    __syncthreads();
-    for (int step = 0; step < p.nsteps; ++step) {
-        const bool more = step + 1 < p.nsteps;
-        if (more) {
-            if (++tap == NTAPS) { tap = 0; ++chunk; }
-            load_tile(step + 1, chunk, tap);            // global loads in flight while the MFMAs below run
-        }
-        const float* As = lds + (step & 1) * L::BUF_FLOATS + (wm * WM + l31) * 4;
-        const float* Bs = lds + (step & 1) * L::BUF_FLOATS + L::A_FLOATS + (wn * WN + l31) * 4;
-        // operand fragments are fetched one k-group ahead of the MFMAs that consume them (register double buffer)
+    // One K step: 16*MT*NT MFMAs on LDS buffer `buf`; operand fragments are fetched one k-group ahead of their MFMAs
+    // (register double buffer).  With `st`, staging registers (sa, sb) are written to LDS buffer buf^1 in between.
+    auto compute = [&](int buf, auto st, const f32x4 (&sa)[AL], const f32x4 (&sb)[BL]) {
+        const float* As = lds + buf * L::BUF_FLOATS + (wm * WM + l31) * 4;
+        const float* Bs = lds + buf * L::BUF_FLOATS + L::A_FLOATS + (wn * WN + l31) * 4;
         f32x4 af[2][MT], bf[2][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[0][i] = td_ld4(As + half * L::A_STRIDE + i * 128);
@@ -157,15 +168,29 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bf[(g + 1) & 1][j] = td_ld4(Bs + (2 * g + 2 + half) * L::B_STRIDE + j * 128);
             }
+            if constexpr (decltype(st)::value) {
+#pragma unroll
+                for (int i = 0; i < AL; ++i) if (i * (4 / AL) == g) store_a(buf ^ 1, i, sa);
+#pragma unroll
+                for (int i = 0; i < BL; ++i) if (i * (4 / BL) == g) store_b(buf ^ 1, i, sb);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = td_mfma32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j]);
-            // pin the interleave: the next group's LDS reads are spread between this group's MFMAs instead of being
-            // sunk to their first use (where every group would start with an exposed LDS round trip)
-            if (g < 3) {
+            // pin the interleave: LDS traffic of the NEXT group is spread between this group's MFMAs instead of being
+            // sunk to its first use (where every group would start with an exposed LDS round trip)
+            if (decltype(st)::value && MT == 2 && NT == 2 && AL == 4 && BL == 4) {
+                TD_SCHED_GROUP(0x008, 2); TD_SCHED_GROUP(0x200, 1); TD_SCHED_GROUP(0x008, 2); TD_SCHED_GROUP(0x200, 1);
+                if (g < 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { TD_SCHED_GROUP(0x100, 1); TD_SCHED_GROUP(0x008, 3); }
+                } else {
+                    TD_SCHED_GROUP(0x008, 12);
+                }
+            } else if (g < 3) {
 #pragma unroll
                 for (int r = 0; r < MT + NT; ++r) {
                     TD_SCHED_GROUP(0x100, 1);
@@ -175,8 +200,48 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
                 TD_SCHED_GROUP(0x008, 4 * MT * NT);
             }
         }
-        if (more) store_tile((step + 1) & 1);
+    };
+
+    f32x4 ra[AL], rb[BL];
+    if (!DEEP) {
+        load_tile(ra, rb);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) store_a(0, i, ra);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) store_b(0, i, rb);
         __syncthreads();
+        for (int step = 0; step < p.nsteps; ++step) {
+            const bool more = step + 1 < p.nsteps;
+            if (more) load_tile(ra, rb);                // global loads in flight while the MFMAs below run
+            compute(step & 1, std::false_type{}, ra, rb);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < AL; ++i) store_a((step + 1) & 1, i, ra);
+#pragma unroll
+                for (int i = 0; i < BL; ++i) store_b((step + 1) & 1, i, rb);
+            }
+            __syncthreads();
+        }
+    } else {
+        // Branch-free: every step loads and stores unconditionally.  Past the last tile the weight step is clamped and
+        // the activation offsets are either valid addresses or out of range (-> zeros); the surplus LDS image is never read.
+        f32x4 ra2[AL], rb2[BL];
+        load_tile(ra, rb);                              // tile 0
+#pragma unroll
+        for (int i = 0; i < AL; ++i) store_a(0, i, ra);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) store_b(0, i, rb);
+        load_tile(ra, rb);                              // tile 1 -> set 1, lands during step 0
+        __syncthreads();
+        for (int step = 0; step < p.nsteps; step += 2) {
+            load_tile(ra2, rb2);                        // even step: set 1 holds tile step+1, set 2 receives tile step+2
+            compute(0, std::true_type{}, ra, rb);
+            __syncthreads();
+            if (step + 1 >= p.nsteps) break;
+            load_tile(ra, rb);                          // odd step: set 2 holds tile step+2, set 1 receives tile step+3
+            compute(1, std::true_type{}, ra2, rb2);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane owns channels nb .. nb+NT-1 of row m (see weight packer) ----
@@ -207,23 +272,34 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side: tile configuration, weight packing, launch
 // ------------------------------------------------------------------------------------------------------------------
-enum ConvTile { CT_128x128 = 0, CT_64x128 = 1, CT_128x64 = 2 };
+enum ConvTile { CT_128x128 = 0, CT_64x128 = 1, CT_128x64 = 2, CT_128x128_DEEP = 3, CT_64x128_DEEP = 4, CT_128x64_DEEP = 5,
+                CT_COUNT = 6 };
 
-struct ConvTileDims { int BM, BN, WGM, WGN; };
+struct ConvTileDims { int BM, BN, WGM, WGN; bool deep; };
 static inline ConvTileDims conv_tile_dims(ConvTile t) {
     switch (t) {
-        case CT_128x128: return {128, 128, 2, 2};
-        case CT_64x128: return {64, 128, 2, 2};
-        default: return {128, 64, 4, 1};
+        case CT_128x128: return {128, 128, 2, 2, false};
+        case CT_64x128: return {64, 128, 2, 2, false};
+        case CT_128x64: return {128, 64, 4, 1, false};
+        case CT_128x128_DEEP: return {128, 128, 2, 2, true};
+        case CT_64x128_DEEP: return {64, 128, 2, 2, true};
+        default: return {128, 64, 4, 1, true};
     }
 }
 
+// Set by tdnet_set_conv_pipeline (tuning hook): 0 = single-stage prefetch, 1 = two-stage ("deep") pipeline.
+static int g_conv_deep = 0;
+
 // Choose the tile: 128-wide N when Cout allows, and the smaller M tile when 128x128 would leave CUs idle.
 static inline ConvTile conv_pick_tile(int M, int Cout) {
-    if (Cout <= 64) return CT_128x64;
-    const int tn = (Cout + 127) / 128;
-    const long blocks = (long)((M + 127) / 128) * tn;
-    return blocks >= 512 ? CT_128x128 : CT_64x128;
+    ConvTile t;
+    if (Cout <= 64) t = CT_128x64;
+    else {
+        const int tn = (Cout + 127) / 128;
+        const long blocks = (long)((M + 127) / 128) * tn;
+        t = blocks >= 512 ? CT_128x128 : CT_64x128;
+    }
+    return g_conv_deep ? (ConvTile)(t + 3) : t;
 }
 
 static inline int conv_cout_pad(int Cout, ConvTile t) {
@@ -262,21 +338,24 @@ static inline void conv_pack_weights(const float* w, int Cout, int Cin, int KS, 
             }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool DEEP>
 static inline void conv_launch_t(const ConvArgs& a, int KS, bool stem, hipStream_t s) {
     const int grid = ((a.M + BM - 1) / BM) * a.tiles_n;
     const int lds = ConvLds<BM, BN>::BYTES;
-    if (stem) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 7, true>), dim3(grid), dim3(256), lds, s, a);
-    else if (KS == 3) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, false>), dim3(grid), dim3(256), lds, s, a);
-    else TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 1, false>), dim3(grid), dim3(256), lds, s, a);
+    if (stem) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 7, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
+    else if (KS == 3) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, false, DEEP>), dim3(grid), dim3(256), lds, s, a);
+    else TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 1, false, DEEP>), dim3(grid), dim3(256), lds, s, a);
 }
 
 static inline void conv_launch(ConvArgs a, ConvTile tile, int KS, bool stem, hipStream_t s) {
     const ConvTileDims d = conv_tile_dims(tile);
     a.tiles_n = a.CoutPad / d.BN;
     switch (tile) {
-        case CT_128x128: conv_launch_t<128, 128, 2, 2>(a, KS, stem, s); break;
-        case CT_64x128: conv_launch_t<64, 128, 2, 2>(a, KS, stem, s); break;
-        default: conv_launch_t<128, 64, 4, 1>(a, KS, stem, s); break;
+        case CT_128x128: conv_launch_t<128, 128, 2, 2, false>(a, KS, stem, s); break;
+        case CT_64x128: conv_launch_t<64, 128, 2, 2, false>(a, KS, stem, s); break;
+        case CT_128x64: conv_launch_t<128, 64, 4, 1, false>(a, KS, stem, s); break;
+        case CT_128x128_DEEP: conv_launch_t<128, 128, 2, 2, true>(a, KS, stem, s); break;
+        case CT_64x128_DEEP: conv_launch_t<64, 128, 2, 2, true>(a, KS, stem, s); break;
+        default: conv_launch_t<128, 64, 4, 1, true>(a, KS, stem, s); break;
     }
 }

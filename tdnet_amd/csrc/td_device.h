@@ -24,6 +24,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
+// Raw buffer access (SRD built from kernel arguments = SGPRs).  A 16-byte load whose byte offset is >= the buffer size
+// returns zeros: the hardware bounds check replaces the branch around zero-padded conv taps (offset TD_BUF_OOB).
+struct TdBuf { __amdgpu_buffer_rsrc_t r; };
+#define TD_BUF_OOB 0x80000000u
+TD_DEV TdBuf td_make_buf(const float* p, unsigned bytes) {
+    TdBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+    return b;
+}
+TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff_bytes, soff_bytes, 0));
+}
+
 // compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
 #define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 

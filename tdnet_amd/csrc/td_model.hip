@@ -456,7 +456,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0;
-    prof_begin(n, 0, L.tile == CT_128x128 && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
+    prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;
@@ -698,6 +698,9 @@ static double frame_flops(const tdnet* n) {
 }
 extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->finalized ? n->flops_frame : -1.0; }
 
+// Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
+extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }
+
 extern "C" int tdnet_set_profiling(tdnet_t* n, int on) {
     if (!n) return td_fail("tdnet_set_profiling: null handle");
     n->prof = on != 0;
@@ -749,7 +752,7 @@ extern "C" int tdnet_op_conv2d_tile(const float* in, int H, int W, int Cin, cons
                                     int KS, int stride, int dil, const float* resid, int act, int tile, float* out, void* stream) {
     // same as tdnet_op_conv2d with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64) -- test/tuning hook
     if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_tile: KS must be 1 or 3");
-    if (tile < 0 || tile > 2) return td_fail("tdnet_op_conv2d_tile: tile must be 0..2");
+    if (tile < 0 || tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_tile: tile must be 0..%d", CT_COUNT - 1);
     ConvLayer L;
     std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
     if (bias_host) b.assign(bias_host, bias_host + Cout);
@@ -828,4 +831,77 @@ extern "C" int tdnet_op_upsample(const float* in, int C, int h, int w, int H, in
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tuning / roofline hooks (not on the product path)
+// ---------------------------------------------------------------------------------------------------------------
+// Pure-MFMA loop: the practical fp32-MFMA ceiling of THIS chip at its sustained clock (4 independent accumulators per
+// wave, `waves_per_simd` waves per SIMD, no memory traffic).
+TD_KERNEL void k_mfma_peak(float* out, int iters) {
+    f32x16 a0, a1, a2, a3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 1.f; a2[r] = 2.f; a3[r] = 3.f; }
+    float x = 1.0f + (float)(threadIdx.x & 7) * 1e-3f, y = 1.0f - (float)(threadIdx.x & 3) * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = td_mfma32(x, y, a0); a1 = td_mfma32(y, x, a1); a2 = td_mfma32(x, x, a2); a3 = td_mfma32(y, y, a3);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    if (s == 123.456f) out[0] = s;                      // keep the accumulators live
+}
+// returns achieved TFLOP/s (fp32 MFMA) or <0
+extern "C" double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, 256) != hipSuccess) return -1.0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 256 * waves_per_simd;            // 256 CUs x (4 SIMDs = one 256-thread block) x waves_per_simd
+    TD_LAUNCH(k_mfma_peak, dim3(blocks), dim3(256), 0, s, d, 16);
+    hipEventRecord(e0, s);
+    TD_LAUNCH(k_mfma_peak, dim3(blocks), dim3(256), 0, s, d, iters);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
+    const double flop = (double)blocks * 4 /*waves*/ * (double)iters * 32 /*mfma per iter*/ * 4096.0;
+    return ms > 0.f ? flop / (ms * 1e-3) / 1e12 : -1.0;
+}
+// Average device time (ms, HIP events on `stream`) of `iters` launches of one conv configuration on random data.
+extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile, int iters, void* stream) {
+    if ((KS != 1 && KS != 3) || Cin % 32 || tile < 0 || tile >= CT_COUNT) { td_fail("tdnet_bench_conv: bad arguments"); return -1.0; }
+    hipStream_t s = (hipStream_t)stream;
+    ConvLayer L;
+    L.Cin = Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = 1; L.stem = false; L.pad = dil * (KS / 2);
+    L.tile = (ConvTile)tile; L.CoutPad = conv_cout_pad(Cout, L.tile); L.nsteps = conv_nsteps(Cin, KS, false);
+    std::vector<float> w((size_t)Cout * Cin * KS * KS), x((size_t)H * W * Cin), b(Cout, 0.1f);
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
+    for (auto& v : w) v = rnd() * 0.05f;
+    for (auto& v : x) v = rnd();
+    std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
+    conv_pack_weights(w.data(), Cout, Cin, KS, false, L.tile, packed.data());
+    float *din = nullptr, *dout = nullptr;
+    if (upload(&L.d_wp, packed) || upload(&L.d_bias, b) || upload(&din, x)) return -1.0;
+    const int Ho = out_size(H, KS, stride, dil, L.pad), Wo = out_size(W, KS, stride, dil, L.pad);
+    if (dev_alloc(&dout, (size_t)Ho * Wo * Cout)) return -1.0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) run_conv(nullptr, L, din, H, W, nullptr, dout, s);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) run_conv(nullptr, L, din, H, W, nullptr, dout, s);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(din); hipFree(dout);
+    free_conv_layer(L);
+    return ms / iters;
 }

@@ -83,6 +83,18 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
 
 #define TD_SCHED_GROUP(mask, n) ((void)0)
 
+struct TdBuf { const char* p; unsigned bytes; };
+#define TD_BUF_OOB 0x80000000u
+TD_DEV TdBuf td_make_buf(const float* p, unsigned bytes) { return TdBuf{(const char*)p, bytes}; }
+TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned long long)voff_bytes + 16 <= b.bytes) {       // the hardware range check ignores soffset ...
+        if ((unsigned long long)voff_bytes + soff_bytes + 16 > b.bytes) abort();   // ... so kernels must keep the sum in range themselves
+        memcpy(&v, b.p + soff_bytes + voff_bytes, 16);
+    }
+    return v;
+}
+
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }
 TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
 TD_DEV float td_exp2(float x) { return exp2f(x); }

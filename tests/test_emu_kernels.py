@@ -19,13 +19,16 @@ def lib():
     return emu_util.emu_lib()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_conv_variants(lib, tile):
     opcheck.conv(lib, MEM, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)       # dilated 3x3 + residual + ReLU
     opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)       # stride 2, Cout not a tile multiple
     opcheck.conv(lib, MEM, 11, 19, 64, 19, 1, 1, 1, 2, False, tile)       # 1x1, 19 channels, LeakyReLU
     opcheck.conv(lib, MEM, 17, 9, 128, 64, 1, 2, 1, 0, True, tile)        # 1x1 stride-2 downsample
     opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, False, tile)      # dilation 4, two N tiles
+    opcheck.conv(lib, MEM, 7, 9, 32, 64, 1, 1, 1, 0, False, tile)         # a single K step (pipeline prologue only)
+    opcheck.conv(lib, MEM, 7, 9, 64, 64, 1, 1, 1, 0, True, tile)          # two K steps
+    opcheck.conv(lib, MEM, 7, 9, 96, 64, 1, 1, 1, 1, False, tile)         # three K steps (odd tail of the 2-stage loop)
 
 
 def test_conv_auto_tile_and_edges(lib):

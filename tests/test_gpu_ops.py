@@ -20,7 +20,7 @@ def mem():
     return opcheck.TorchMem()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_conv_variants(lib, mem, tile):
     opcheck.conv(lib, mem, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)
     opcheck.conv(lib, mem, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)
@@ -28,6 +28,10 @@ def test_conv_variants(lib, mem, tile):
     opcheck.conv(lib, mem, 17, 9, 128, 64, 1, 2, 1, 0, True, tile)
     opcheck.conv(lib, mem, 12, 30, 64, 160, 3, 1, 4, 1, False, tile)
     opcheck.conv(lib, mem, 97, 193, 64, 128, 3, 1, 2, 1, True, tile)      # native 769x1537 feature size, many ragged tiles
+    opcheck.conv(lib, mem, 7, 9, 32, 64, 1, 1, 1, 0, False, tile)         # 1, 2, 3 K steps: pipeline prologue / odd tail
+    opcheck.conv(lib, mem, 7, 9, 64, 64, 1, 1, 1, 0, True, tile)
+    opcheck.conv(lib, mem, 7, 9, 96, 64, 1, 1, 1, 1, False, tile)
+    opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tile, tol=2e-4)   # the dominant layer4 shape on every variant
 
 
 def test_conv_real_shapes(lib, mem):
