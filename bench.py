@@ -35,6 +35,16 @@ from tdnet_amd.model import td2_psp50, td4_psp18  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
 
+def traffic_from_profiles():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+    gfx950 calibration + WRITE_SIZE; counters cannot be read live inside bench.py).  None if no profile is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")) as f:
+            return round(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +133,7 @@ def main():
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2,3> (3x3 dilated conv, fp32 MFMA)",
                                "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic_from_profiles(),
                                "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nprof,
                                "gflop_per_launch": round(dom_fl / dom_n / 1e9, 2)}
         res["breakdown_ms_per_frame"] = {"conv_gemm": round(acc[0][0] / nprof, 3), "attention": round(acc[1][0] / nprof, 3),

@@ -58,6 +58,7 @@ TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ ro
     const float* row = c4 + (size_t)y * w * C + cv * 4;
     const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
     td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
 }
@@ -72,21 +73,31 @@ TD_KERNEL void k_ppm_bins(const float* __restrict__ rowpart, float* __restrict__
     const int ylo = td_bin_lo(by, h, o), yhi = td_bin_hi(by, h, o);
     const int cnt = (yhi - ylo) * (td_bin_hi(bx, w, o) - td_bin_lo(bx, w, o));
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowpart + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
     td_st4(pooled + (size_t)blockIdx.x * C + cv * 4, s * (1.0f / (float)cnt));
 }
 // pyramid 1x1 conv (BN folded) + ReLU on the 50 pooled vectors, only the FS channels this path keeps:
-// feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][f][c] pooled[bin][c]).  grid = 50, block = FS (64).
+// feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][c][f] pooled[bin][c]).  grid = 50, block = 4*FS: thread (f, slice) sums a
+// quarter of the channels with 8 loads in flight, LDS combines the four slices in a fixed order.
 TD_KERNEL void k_ppm_conv(const float* __restrict__ pooled, const float* __restrict__ wgt, const float* __restrict__ bias,
                           float* __restrict__ feat, int C, int FS) {
-    const int bin = blockIdx.x, f = threadIdx.x;
+    TD_DYN_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);               // [4][FS]
+    const int bin = blockIdx.x, f = threadIdx.x % FS, sl = threadIdx.x / FS;
     const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
-    const float* wr = wgt + (size_t)lvl * C * FS + f;            // weights stored [lvl][c][f]: lanes read consecutive f
-    const float* pv = pooled + (size_t)bin * C;
+    const int cq = C >> 2;
+    const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
+    const float* pv = pooled + (size_t)bin * C + sl * cq;
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(wr[(size_t)c * FS], pv[c], s);
-    s += bias[lvl * FS + f];
-    feat[(size_t)bin * FS + f] = s > 0.f ? s : 0.f;
+#pragma unroll 8
+    for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pv[c], s);
+    red[sl * FS + f] = s;
+    __syncthreads();
+    if (sl == 0) {
+        s = ((red[f] + red[FS + f]) + red[2 * FS + f]) + red[3 * FS + f] + bias[lvl * FS + f];
+        feat[(size_t)bin * FS + f] = s > 0.f ? s : 0.f;
+    }
 }
 // z[p] = [ c4[p][pid*XS : +XS] | bilinear(feat_l)(p)[0:FS] for l = 0..3 ]   (align_corners=True, td4_psp18.py:273-284)
 TD_KERNEL void k_ppm_assemble(const float* __restrict__ c4, const float* __restrict__ feat, float* __restrict__ z,
@@ -192,6 +203,7 @@ TD_KERNEL void k_classifier(const float* __restrict__ x, const float* __restrict
     float acc[NC_MAX];
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k) acc[k] = 0.f;
+#pragma unroll 4
     for (int c = 0; c < C; c += 4) {
         const f32x4 v = td_ld4(x + (size_t)p * C + c);
 #pragma unroll

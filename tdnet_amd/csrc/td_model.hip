@@ -157,6 +157,9 @@ struct tdnet {
     std::vector<int> fifo;                                             // slot ids, oldest first
     int last_slot = -1;
     // profiling
+    // cache-only work (V' GEMMs + the two cached-frame attention steps) runs on a side stream under the backbone
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool prof = false;
     std::vector<ProfRec> recs;
     size_t nrec = 0;
@@ -269,6 +272,9 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
         if (q) hipFree(q);
     for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
     for (auto& r : n->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    if (n->side) hipStreamDestroy(n->side);
+    if (n->ev_fork) hipEventDestroy(n->ev_fork);
+    if (n->ev_join) hipEventDestroy(n->ev_join);
     delete n;
 }
 
@@ -423,6 +429,9 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
     TD_HIP(hipDeviceSynchronize());
+    TD_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+    TD_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+    TD_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     n->finalized = true;
     n->flops_frame = frame_flops(n);
     return 0;
@@ -497,7 +506,7 @@ static void run_ppm(tdnet* n, const float* c4, int h, int w, const float* wgt, c
     prof_begin(n, 2, false, 0, s);
     TD_LAUNCH(k_ppm_rowsum, dim3(h * 12), dim3(C / 4), 0, s, c4, rowpart, w, C);
     TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
-    TD_LAUNCH(k_ppm_conv, dim3(50), dim3(FS), 0, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
+    TD_LAUNCH(k_ppm_conv, dim3(50), dim3(4 * FS), 4 * FS * 4, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
     TD_LAUNCH(k_ppm_assemble, dim3(td_grid_for((long)h * w * (C / 4))), dim3(256), 0, s, c4, (const float*)ppmfeat, z, h, w, C,
               pid * XS, XS, FS);
     prof_end(n, s);
@@ -535,6 +544,25 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     PathLayers& L = n->paths[pos_id];
     n->nrec = 0;
     const int DV = n->DV;
+    // ---- fork: everything that depends only on CACHED frames (td4_psp18.py:145-146 and the fc of :147) runs on the side
+    // stream while the backbone of the current frame runs on `s`; joined right before the final attention.
+    const bool steady = (int)n->fifo.size() >= n->FIFO;
+    if (steady) {
+        hipStream_t c = n->side;
+        TD_HIP(hipEventRecord(n->ev_fork, s));
+        TD_HIP(hipStreamWaitEvent(c, n->ev_fork, 0));
+        if (n->P == 4) {
+            const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
+            run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c);
+            if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c)) return -1;   // v2 + V[1]
+            run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c);
+            if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c)) return -1;   // v3 + V[2]
+            run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c);                                              // (v3 + V[2]) W^T
+        } else {
+            run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c);
+        }
+        TD_HIP(hipEventRecord(n->ev_join, c));
+    }
     // backbone (resnet.py:204-215)
     run_stem_pre(n, img, n->H, n->W, n->img4, s);
     run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s);
@@ -556,20 +584,11 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s);
     run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, s);
     const float* feat = n->v_cur;
-    if ((int)n->fifo.size() >= n->FIFO) {
-        if (n->P == 4) {                                               // td4_psp18.py:145-151
-            const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
-            run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, s);
-            if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, s)) return -1;   // v2 + V[1]
-            run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, s);
-            if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, s)) return -1;   // v3 + V[2]
-            run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, s);
-            if (run_attention(n, n->q_cur, c2.k, n->vp, L.atn[2].d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s)) return -1;   // v4 + v_cur
-        } else {                                                       // td2_psp50.py:120-122
-            const CacheSlot& c0 = n->slots[n->fifo[0]];
-            run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, s);
-            if (run_attention(n, n->q_cur, c0.k, n->vp, L.atn[0].d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s)) return -1;
-        }
+    if (steady) {
+        TD_HIP(hipStreamWaitEvent(s, n->ev_join, 0));                   // join: v' of the newest cached frame is ready
+        const CacheSlot& ck = n->slots[n->fifo[n->FIFO - 1]];
+        const AtnLayer& A = L.atn[n->P == 4 ? 2 : 0];                   // td4_psp18.py:147 / td2_psp50.py:120
+        if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s)) return -1;   // v4 + v_cur
         feat = n->feat;
     } else {
         // warm-up (td4_psp18.py:142-143): feat = v_cur; keep a copy so the "feat" stage is well defined

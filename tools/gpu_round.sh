@@ -8,6 +8,8 @@ timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -x 2>&1 | tail -15 
 timeout 300 python tools/kernel_probe.py > $R/probe.log 2>&1
 timeout 300 python bench.py --no-cpu-baseline --steps 40 --conv-pipeline 0 > $R/bench_p0.log 2>&1
 timeout 300 python bench.py --no-cpu-baseline --steps 40 --conv-pipeline 1 > $R/bench_p1.log 2>&1
+timeout 300 python bench.py --model td2 --steps 40 > $R/bench_td2.log 2>&1
+timeout 300 python bench.py --size 769x1537 --steps 40 --no-cpu-baseline > $R/bench_native.log 2>&1
 timeout 900 python -m pytest tests/test_gpu_model.py -q -m gpu -s 2>&1 | tail -30 > $R/model.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1
 timeout 600 python bench.py > $R/bench.log 2>&1
