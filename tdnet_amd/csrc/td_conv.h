@@ -291,15 +291,25 @@ static inline ConvTileDims conv_tile_dims(ConvTile t) {
 static int g_conv_deep = 1;      // measured on MI355X: +4..6 % on every layer shape (profiles/r1_kernel_probe.txt)
 
 // Choose the tile: 128-wide N when Cout allows, and the smaller M tile when 128x128 would leave CUs idle.
+// Cost model: the launch ends when the busiest CU has finished its share of the workgroups, so what matters is the
+// per-CU quantisation ceil(blocks / 256 CUs) times the work of one block, divided by the tile's measured relative
+// throughput (profiles/r01b_kernel_probe.txt: 128x128 1.00, 64x128 0.97, 128x64 0.95).  At 1024x2048 this picks 128x128
+// for layers 3-4 (1024 blocks = 4 per CU); at the native 769x1537 (147 M-tiles -> 588 blocks = 2.3 per CU) it picks
+// 64x128 (1172 blocks = 4.6 per CU), which removes most of the last-round idle time.
 static inline ConvTile conv_pick_tile(int M, int Cout) {
-    ConvTile t;
-    if (Cout <= 64) t = CT_128x64;
-    else {
-        const int tn = (Cout + 127) / 128;
-        const long blocks = (long)((M + 127) / 128) * tn;
-        t = blocks >= 512 ? CT_128x128 : CT_64x128;
+    ConvTile best = CT_128x64;
+    if (Cout > 64) {
+        static const struct { ConvTile t; int bm, bn; double eff; } cand[3] = {
+            {CT_128x128, 128, 128, 1.00}, {CT_64x128, 64, 128, 0.97}, {CT_128x64, 128, 64, 0.95}};
+        double best_cost = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const long blocks = (long)((M + cand[i].bm - 1) / cand[i].bm) * ((Cout + cand[i].bn - 1) / cand[i].bn);
+            const double occ = blocks >= 512 ? 1.0 : 0.8;      // fewer than 2 workgroups per CU: no co-resident wave to hide stalls
+            const double cost = (double)((blocks + 255) / 256) * cand[i].bm * cand[i].bn / (cand[i].eff * occ);
+            if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].t; }
+        }
     }
-    return g_conv_deep ? (ConvTile)(t + 3) : t;
+    return g_conv_deep ? (ConvTile)(best + 3) : best;
 }
 
 static inline int conv_cout_pad(int Cout, ConvTile t) {
