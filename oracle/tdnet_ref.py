@@ -46,13 +46,29 @@ def basic_block(x, sd, pre, b):
     return F.relu(out + res)
 
 
+def bottleneck_block(x, sd, pre, b):
+    """resnet.py:62-111: 1x1 -> BN -> ReLU -> 3x3(stride, dilation) -> BN -> ReLU -> 1x1 (x4) -> BN -> + residual -> ReLU."""
+    out = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv1.weight"]), sd, pre + ".bn1"))
+    out = F.relu(bn_eval(F.conv2d(out, sd[pre + ".conv2.weight"], None, b.stride, b.dil1, b.dil1), sd, pre + ".bn2"))
+    out = bn_eval(F.conv2d(out, sd[pre + ".conv3.weight"]), sd, pre + ".bn3")
+    res = x
+    if b.downsample:
+        res = bn_eval(F.conv2d(x, sd[pre + ".downsample.0.weight"], None, b.stride), sd, pre + ".downsample.1")
+    return F.relu(out + res)
+
+
 def backbone(x, sd, pre, blocks):
-    """resnet.py:204-215: 7x7 s2 p3 stem, BN, ReLU, max-pool 3x3 s2 p1, layer1..4 -> c4."""
-    x = F.conv2d(x, sd[pre + ".conv1.weight"], None, 2, 3)
+    """resnet.py:204-215: stem (7x7 s2 p3, or the deep_base 3-conv stem :122-131), BN, ReLU, max-pool 3x3 s2 p1, layer1..4 -> c4."""
+    if pre + ".conv1.0.weight" in sd:               # deep_base (ResNet-50)
+        x = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv1.0.weight"], None, 2, 1), sd, pre + ".conv1.1"))
+        x = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv1.3.weight"], None, 1, 1), sd, pre + ".conv1.4"))
+        x = F.conv2d(x, sd[pre + ".conv1.6.weight"], None, 1, 1)
+    else:
+        x = F.conv2d(x, sd[pre + ".conv1.weight"], None, 2, 3)
     x = F.relu(bn_eval(x, sd, pre + ".bn1"))
     x = F.max_pool2d(x, 3, 2, 1)
     for b in blocks:
-        x = basic_block(x, sd, "%s.%s" % (pre, b.name), b)
+        x = (bottleneck_block if b.kind == "bottleneck" else basic_block)(x, sd, "%s.%s" % (pre, b.name), b)
     return x
 
 

@@ -11,9 +11,20 @@ Reference (read-only, /root/reference):
 """
 from collections import namedtuple
 
-BlockSpec = namedtuple("BlockSpec", "name cin cout stride dil1 dil2 downsample")
+# kind "basic": conv3x3(cin->cout, stride, dil1) - conv3x3(cout->cout, dil2)               (resnet.py:25-59)
+# kind "bottleneck": conv1x1(cin->planes) - conv3x3(planes->planes, stride, dil1) - conv1x1(planes->cout = 4 planes); dil2 unused
+#                    (resnet.py:62-111: Bottleneck ignores previous_dilation)
+BlockSpec = namedtuple("BlockSpec", "name cin cout stride dil1 dil2 downsample kind planes")
 
-_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3)}
+
+
+def is_bottleneck(backbone):
+    return backbone == "resnet50"
+
+
+def expansion(backbone):
+    return 4 if is_bottleneck(backbone) else 1
 
 
 def feat_size(n):
@@ -36,10 +47,12 @@ def backbone_blocks(backbone):
     conv2 uses `previous_dilation` (resnet.py:32-37); the first block of layer3 uses dilation 1 (resnet.py:183-185).
     """
     if backbone not in _LAYERS:
-        raise ValueError("backbone must be resnet18 or resnet34 on the HIP path (BasicBlock); got %r" % (backbone,))
+        raise ValueError("backbone must be resnet18, resnet34 or resnet50; got %r" % (backbone,))
     nb = _LAYERS[backbone]
+    bott = is_bottleneck(backbone)
+    exp = 4 if bott else 1
     blocks = []
-    inpl = 64
+    inpl = 128 if bott else 64                      # deep_base stem ends in 128 channels (resnet.py:117,122-131)
     # (planes, blocks, stride, dilation, multi_grid)
     for li, (planes, n, stride, dil, mg) in enumerate(
             [(64, nb[0], 1, 1, False), (128, nb[1], 2, 1, False), (256, nb[2], 1, 2, False), (512, nb[3], 1, 4, True)], 1):
@@ -51,10 +64,10 @@ def backbone_blocks(backbone):
                 d1 = 1 if dil in (1, 2) else 2
             else:
                 d1 = dil
-            ds = first and (stride != 1 or inpl != planes)
-            blocks.append(BlockSpec("layer%d.%d" % (li, b), inpl if first else planes, planes,
-                                    stride if first else 1, d1, dil, ds))
-        inpl = planes
+            ds = first and (stride != 1 or inpl != planes * exp)
+            blocks.append(BlockSpec("layer%d.%d" % (li, b), inpl if first else planes * exp, planes * exp,
+                                    stride if first else 1, d1, dil, ds, "bottleneck" if bott else "basic", planes))
+        inpl = planes * exp
     return blocks
 
 
@@ -65,15 +78,18 @@ def model_spec(name, nclass=19, backbone=None):
     """name: 'td4' (td4_psp18.py) or 'td2' (td2_psp50.py with a BasicBlock backbone)."""
     if name == "td4":
         bb = backbone or "resnet18"
+        if is_bottleneck(bb):
+            raise ValueError("td4 with a Bottleneck backbone is not a shipped configuration (td4_psp18.py:85-88 would need d_v = 2048)")
         # td4_psp18.py:80-83 -> PyramidPooling(path_num=path_num//2, pid=0,1,0,1); :85-88 d_v = 512
         atn = {0: ("atn1_2", "atn1_3", "atn1_4"), 1: ("atn2_3", "atn2_4", "atn2_1"),
                2: ("atn3_4", "atn3_1", "atn3_2"), 3: ("atn4_1", "atn4_2", "atn4_3")}
         return ModelSpec("td4", 4, bb, 512, 64, 512, 2, (0, 1, 0, 1), 512 // 4, nclass, 3, atn)
     if name == "td2":
         bb = backbone or "resnet18"
-        # td2_psp50.py:76-82 -> PyramidPooling(path_num=2, pid=0,1); d_v = 512*exp//4 = 128; head chn_down=2 (:88-89)
+        e = expansion(bb)
+        # td2_psp50.py:76-82 -> PyramidPooling(path_num=2, pid=0,1); d_v = 512*exp//4 (128 | 512); head chn_down=2 (:88-89)
         atn = {0: ("atn1",), 1: ("atn2",)}
-        return ModelSpec("td2", 2, bb, 512, 64, 128, 2, (0, 1), 128 // 2, nclass, 1, atn)
+        return ModelSpec("td2", 2, bb, 512 * e, 64, 128 * e, 2, (0, 1), 128 * e // 2, nclass, 1, atn)
     raise ValueError(name)
 
 
@@ -93,19 +109,37 @@ def state_dict_shapes(spec, h, w):
         out[prefix + ".num_batches_tracked"] = ()
 
     P = spec.path_num
+    bott = is_bottleneck(spec.backbone)
     for p in range(1, P + 1):
         pre = "pretrained%d" % p
-        out[pre + ".conv1.weight"] = (64, 3, 7, 7)
-        bn(pre + ".bn1", 64)
+        if bott:                                     # deep_base stem: resnet.py:122-131
+            out[pre + ".conv1.0.weight"] = (64, 3, 3, 3)
+            bn(pre + ".conv1.1", 64)
+            out[pre + ".conv1.3.weight"] = (64, 64, 3, 3)
+            bn(pre + ".conv1.4", 64)
+            out[pre + ".conv1.6.weight"] = (128, 64, 3, 3)
+            bn(pre + ".bn1", 128)
+        else:
+            out[pre + ".conv1.weight"] = (64, 3, 7, 7)
+            bn(pre + ".bn1", 64)
         for b in backbone_blocks(spec.backbone):
-            out["%s.%s.conv1.weight" % (pre, b.name)] = (b.cout, b.cin, 3, 3)
-            bn("%s.%s.bn1" % (pre, b.name), b.cout)
-            out["%s.%s.conv2.weight" % (pre, b.name)] = (b.cout, b.cout, 3, 3)
-            bn("%s.%s.bn2" % (pre, b.name), b.cout)
+            bp = "%s.%s" % (pre, b.name)
+            if b.kind == "basic":
+                out[bp + ".conv1.weight"] = (b.cout, b.cin, 3, 3)
+                bn(bp + ".bn1", b.cout)
+                out[bp + ".conv2.weight"] = (b.cout, b.cout, 3, 3)
+                bn(bp + ".bn2", b.cout)
+            else:
+                out[bp + ".conv1.weight"] = (b.planes, b.cin, 1, 1)
+                bn(bp + ".bn1", b.planes)
+                out[bp + ".conv2.weight"] = (b.planes, b.planes, 3, 3)
+                bn(bp + ".bn2", b.planes)
+                out[bp + ".conv3.weight"] = (b.cout, b.planes, 1, 1)
+                bn(bp + ".bn3", b.cout)
             if b.downsample:
-                out["%s.%s.downsample.0.weight" % (pre, b.name)] = (b.cout, b.cin, 1, 1)
-                bn("%s.%s.downsample.1" % (pre, b.name), b.cout)
-        out[pre + ".fc.weight"] = (1000, 512)
+                out[bp + ".downsample.0.weight"] = (b.cout, b.cin, 1, 1)
+                bn(bp + ".downsample.1", b.cout)
+        out[pre + ".fc.weight"] = (1000, 512 * expansion(spec.backbone))
         out[pre + ".fc.bias"] = (1000,)
     dm, dk, dv = spec.d_model, spec.d_k, spec.d_v
     for p in range(1, P + 1):

@@ -2,7 +2,7 @@
 //
 // Covers every conv on the TDNet hot path: 3x3 with stride 1/2 and dilation
 // 1..16 (resnet.py:32-37), 1x1 with stride 1/2/4 (downsample resnet.py:172-177, Encoding transformer.py:18-26,36),
-// and the 7x7-s2 stem (resnet.py:132-133) through the STEM variant.  BN is folded into weight/bias on the host, so the
+// and the 7x7-s2 stem (resnet.py:132-133) / the 3x3-s2 first conv of the deep stem (:123) through the STEM variant.  BN is folded into weight/bias on the host, so the
 // epilogue is  out = act(acc + bias[n] (+ residual[m][n])).
 //
 //   GEMM view:  M = Ho*Wo output pixels, N = Cout, K = taps * Cin.   D[m][n] = sum_k A[m][k] * B[k][n]
@@ -39,7 +39,7 @@ struct ConvArgs {
     int Wo, Cout, CoutPad;
     int stride, dil, pad;
     int M;                // Ho*Wo
-    int nsteps;           // (Cin/32)*KS*KS, STEM: 7
+    int nsteps;           // (Cin/32)*KS*KS, STEM: ceil(KS*KS/8)
     int act;              // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
     int tiles_n;          // CoutPad / BN
 };
@@ -112,8 +112,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         bool tap_ok = true;
         if (STEM) {
             const int t = l_step * 8 + a_kq;            // one 4-channel pixel per k-group: 8 taps per step
-            const int ky = t / 7;
-            dy = ky; dx = t - ky * 7; tap_ok = t < 49;
+            const int ky = t / KS;
+            dy = ky; dx = t - ky * KS; tap_ok = t < KS * KS;
             delta = (unsigned)((dy * p.W + dx) * 4) * 4u;
         } else {
             const int ky = l_tap / KS;
@@ -316,7 +316,7 @@ static inline int conv_cout_pad(int Cout, ConvTile t) {
     const int BN = conv_tile_dims(t).BN;
     return (Cout + BN - 1) / BN * BN;
 }
-static inline int conv_nsteps(int Cin, int KS, bool stem) { return stem ? 7 : (Cin / 32) * KS * KS; }
+static inline int conv_nsteps(int Cin, int KS, bool stem) { return stem ? (KS * KS + 7) / 8 : (Cin / 32) * KS * KS; }
 
 // Pack BN-folded OIHW weights into the LDS image order of `tile`: [step][kq][slot][4], where packed column `slot`
 // holds output channel  tile_n*BN + wn*WN + j*NT + nt   for  slot = tile_n*BN + wn*WN + nt*32 + j.
@@ -337,7 +337,7 @@ static inline void conv_pack_weights(const float* w, int Cout, int Cin, int KS, 
                     if (n < Cout) {
                         if (stem) {
                             const int t = step * 8 + kq;
-                            if (t < 49 && e < 3) v = w[((size_t)n * 3 + e) * 49 + t];
+                            if (t < ntaps && e < 3) v = w[((size_t)n * 3 + e) * ntaps + t];
                         } else {
                             const int chunk = step / ntaps, tap = step % ntaps, ci = chunk * 32 + kq * 4 + e;
                             v = w[((size_t)n * Cin + ci) * ntaps + tap];
@@ -352,7 +352,8 @@ template <int BM, int BN, int WGM, int WGN, bool DEEP>
 static inline void conv_launch_t(const ConvArgs& a, int KS, bool stem, hipStream_t s) {
     const int grid = ((a.M + BM - 1) / BM) * a.tiles_n;
     const int lds = ConvLds<BM, BN>::BYTES;
-    if (stem) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 7, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
+    if (stem && KS == 7) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 7, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
+    else if (stem) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
     else if (KS == 3) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, false, DEEP>), dim3(grid), dim3(256), lds, s, a);
     else TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 1, false, DEEP>), dim3(grid), dim3(256), lds, s, a);
 }

@@ -78,13 +78,14 @@ TD_KERNEL void k_ppm_bins(const float* __restrict__ rowpart, float* __restrict__
     td_st4(pooled + (size_t)blockIdx.x * C + cv * 4, s * (1.0f / (float)cnt));
 }
 // pyramid 1x1 conv (BN folded) + ReLU on the 50 pooled vectors, only the FS channels this path keeps:
-// feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][c][f] pooled[bin][c]).  grid = 50, block = 4*FS: thread (f, slice) sums a
-// quarter of the channels with 8 loads in flight, LDS combines the four slices in a fixed order.
+// feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][c][f] pooled[bin][c]).  grid = 50 bins x FS/64 channel groups, block = 256:
+// thread (f, slice) sums a quarter of the input channels with 8 loads in flight, LDS combines the four slices in a fixed order.
 TD_KERNEL void k_ppm_conv(const float* __restrict__ pooled, const float* __restrict__ wgt, const float* __restrict__ bias,
                           float* __restrict__ feat, int C, int FS) {
     TD_DYN_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);               // [4][FS]
-    const int bin = blockIdx.x, f = threadIdx.x % FS, sl = threadIdx.x / FS;
+    float* red = reinterpret_cast<float*>(smem);               // [4][64]
+    const int groups = FS >> 6, bin = blockIdx.x / groups, fl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int f = (blockIdx.x % groups) * 64 + fl;
     const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
     const int cq = C >> 2;
     const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
@@ -92,10 +93,10 @@ TD_KERNEL void k_ppm_conv(const float* __restrict__ pooled, const float* __restr
     float s = 0.f;
 #pragma unroll 8
     for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pv[c], s);
-    red[sl * FS + f] = s;
+    red[sl * 64 + fl] = s;
     __syncthreads();
     if (sl == 0) {
-        s = ((red[f] + red[FS + f]) + red[2 * FS + f]) + red[3 * FS + f] + bias[lvl * FS + f];
+        s = ((red[fl] + red[64 + fl]) + red[128 + fl]) + red[192 + fl] + bias[lvl * FS + f];
         feat[(size_t)bin * FS + f] = s > 0.f ? s : 0.f;
     }
 }

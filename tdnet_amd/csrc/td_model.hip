@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -43,14 +44,17 @@ extern "C" const char* tdnet_version(void) { return "tdnet_amd 0.1 (gfx950, fp32
 // ---------------------------------------------------------------------------------------------------------------
 // architecture description (same rules as tdnet_amd/arch.py; resnet.py:114-202)
 // ---------------------------------------------------------------------------------------------------------------
-struct BlockSpec { std::string name; int cin, cout, stride, dil1, dil2; bool ds; };
+// bott: conv1x1(cin->planes) conv3x3(planes->planes, stride, dil1) conv1x1(planes->cout); Bottleneck ignores dil2 (resnet.py:62-111)
+struct BlockSpec { std::string name; int cin, cout, stride, dil1, dil2; bool ds; bool bott; int planes; };
 
 static std::vector<BlockSpec> backbone_blocks(int backbone) {
     const int nb18[4] = {2, 2, 2, 2}, nb34[4] = {3, 4, 6, 3};
-    const int* nb = backbone == 18 ? nb18 : nb34;
+    const int* nb = backbone == 18 ? nb18 : nb34;                      // ResNet-50 has the ResNet-34 block counts
+    const bool bott = backbone == 50;
+    const int exp = bott ? 4 : 1;
     const int planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 1, 1}, dils[4] = {1, 1, 2, 4};
     std::vector<BlockSpec> out;
-    int inpl = 64;
+    int inpl = bott ? 128 : 64;                                      // deep_base stem ends in 128 channels (resnet.py:117)
     for (int li = 0; li < 4; ++li) {
         for (int b = 0; b < nb[li]; ++b) {
             const bool first = b == 0, mg = li == 3;
@@ -62,15 +66,17 @@ static std::vector<BlockSpec> backbone_blocks(int backbone) {
             char nm[32];
             snprintf(nm, sizeof(nm), "layer%d.%d", li + 1, b);
             s.name = nm;
-            s.cin = first ? inpl : planes[li];
-            s.cout = planes[li];
+            s.cin = first ? inpl : planes[li] * exp;
+            s.cout = planes[li] * exp;
+            s.bott = bott;
+            s.planes = planes[li];
             s.stride = first ? strides[li] : 1;
             s.dil1 = d1;
             s.dil2 = dils[li];
-            s.ds = first && (strides[li] != 1 || inpl != planes[li]);
+            s.ds = first && (strides[li] != 1 || inpl != planes[li] * exp);
             out.push_back(s);
         }
-        inpl = planes[li];
+        inpl = planes[li] * exp;
     }
     return out;
 }
@@ -87,7 +93,7 @@ struct ConvLayer {
     int CoutPad = 0, nsteps = 0;
     float* d_wp = nullptr;
     float* d_bias = nullptr;
-    double flops_per_pixel() const { return 2.0 * Cout * (stem ? 147.0 : (double)Cin * KS * KS); }
+    double flops_per_pixel() const { return 2.0 * Cout * (stem ? 3.0 * KS * KS : (double)Cin * KS * KS); }
 };
 
 static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2 * pad - dil * (KS - 1) - 1) / stride + 1; }
@@ -96,7 +102,7 @@ static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2
 static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& b, int Cout, int Cin, int KS,
                            int stride, int dil, int act, bool stem, long M) {
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
-    L.pad = stem ? 3 : dil * (KS / 2);
+    L.pad = stem ? KS / 2 : dil * (KS / 2);
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
     L.tile = conv_pick_tile((int)M, Cout);
     L.CoutPad = conv_cout_pad(Cout, L.tile);
@@ -120,10 +126,10 @@ static void free_conv_layer(ConvLayer& L) {
 // ---------------------------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------------------------
-struct BlockLayers { ConvLayer c1, c2, ds; bool has_ds = false; };
+struct BlockLayers { ConvLayer c1, c2, c3, ds; bool has_ds = false, bott = false; };
 struct AtnLayer { ConvLayer fc; float* d_bias = nullptr; };          // fc applied to the value matrix (no bias), bias added after P V'
 struct PathLayers {
-    ConvLayer stem;
+    ConvLayer stem, stem2, stem3;                                      // stem2/3: deep_base only (resnet.py:122-131)
     std::vector<BlockLayers> blocks;
     float* d_ppm_w = nullptr; float* d_ppm_b = nullptr;                // [4][FS][512], [4][FS]
     ConvLayer enc_v, enc_q0, enc_q1, enc_k0, enc_k1;
@@ -138,7 +144,8 @@ struct ProfRec { int family; bool dominant; hipEvent_t e0, e1; double flops; };
 
 struct tdnet {
     tdnet_cfg cfg;
-    int P = 0, DV = 0, MID = 0, FIFO = 0;
+    int P = 0, DV = 0, MID = 0, FIFO = 0, C = 512, SC = 64;            // C = backbone output channels, SC = stem output channels
+    bool deep = false;
     int H = 0, W = 0, H1 = 0, W1 = 0, H2 = 0, W2 = 0, h = 0, w = 0, hk = 0, wk = 0, Lq = 0, Lk = 0;
     std::vector<BlockSpec> bspec;
     std::map<std::string, std::vector<float>> sd;                      // host state_dict until finalize
@@ -146,7 +153,7 @@ struct tdnet {
     bool finalized = false;
     std::vector<PathLayers> paths;
     // workspace
-    float *img4 = nullptr, *s1 = nullptr, *bx = nullptr, *bt = nullptr, *br = nullptr;
+    float *img4 = nullptr, *s1 = nullptr, *s1b = nullptr, *bx = nullptr, *bt = nullptr, *br = nullptr, *bu = nullptr;
     float *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr, *z = nullptr;
     float *v_cur = nullptr, *q1 = nullptr, *q_cur = nullptr, *k1 = nullptr;
     float *vp = nullptr, *chain_a = nullptr, *chain_b = nullptr, *feat = nullptr;
@@ -194,30 +201,40 @@ static void build_expected(tdnet* n) {
     for (int p = 1; p <= n->P; ++p) {
         snprintf(b, sizeof(b), "pretrained%d", p);
         std::string pre = b;
-        e[pre + ".conv1.weight"] = 64 * 3 * 49;
-        add_bn(e, pre + ".bn1", 64);
+        if (n->deep) {
+            e[pre + ".conv1.0.weight"] = 64 * 3 * 9; add_bn(e, pre + ".conv1.1", 64);
+            e[pre + ".conv1.3.weight"] = 64 * 64 * 9; add_bn(e, pre + ".conv1.4", 64);
+            e[pre + ".conv1.6.weight"] = 128 * 64 * 9; add_bn(e, pre + ".bn1", 128);
+        } else {
+            e[pre + ".conv1.weight"] = 64 * 3 * 49;
+            add_bn(e, pre + ".bn1", 64);
+        }
         for (auto& s : n->bspec) {
             std::string bp = pre + "." + s.name;
-            e[bp + ".conv1.weight"] = (size_t)s.cout * s.cin * 9;
-            add_bn(e, bp + ".bn1", s.cout);
-            e[bp + ".conv2.weight"] = (size_t)s.cout * s.cout * 9;
-            add_bn(e, bp + ".bn2", s.cout);
+            if (s.bott) {
+                e[bp + ".conv1.weight"] = (size_t)s.planes * s.cin; add_bn(e, bp + ".bn1", s.planes);
+                e[bp + ".conv2.weight"] = (size_t)s.planes * s.planes * 9; add_bn(e, bp + ".bn2", s.planes);
+                e[bp + ".conv3.weight"] = (size_t)s.cout * s.planes; add_bn(e, bp + ".bn3", s.cout);
+            } else {
+                e[bp + ".conv1.weight"] = (size_t)s.cout * s.cin * 9; add_bn(e, bp + ".bn1", s.cout);
+                e[bp + ".conv2.weight"] = (size_t)s.cout * s.cout * 9; add_bn(e, bp + ".bn2", s.cout);
+            }
             if (s.ds) { e[bp + ".downsample.0.weight"] = (size_t)s.cout * s.cin; add_bn(e, bp + ".downsample.1", s.cout); }
         }
-        e[pre + ".fc.weight"] = 1000 * 512; e[pre + ".fc.bias"] = 1000;
+        e[pre + ".fc.weight"] = (size_t)1000 * n->C; e[pre + ".fc.bias"] = 1000;
         for (int j = 1; j <= 4; ++j) {
             snprintf(b, sizeof(b), "psp%d.conv%d", p, j);
-            e[std::string(b) + ".0.weight"] = 128 * 512;
-            add_bn(e, std::string(b) + ".1", 128);
+            e[std::string(b) + ".0.weight"] = (size_t)(n->C / 4) * n->C;
+            add_bn(e, std::string(b) + ".1", n->C / 4);
         }
         for (const char* br : {"w_qs", "w_ks"}) {
             snprintf(b, sizeof(b), "enc%d.%s", p, br);
             std::string ep = b;
-            e[ep + ".0.conv.weight"] = 64 * 512; e[ep + ".0.conv.bias"] = 64; add_bn(e, ep + ".0.bn", 64);
+            e[ep + ".0.conv.weight"] = (size_t)64 * n->C; e[ep + ".0.conv.bias"] = 64; add_bn(e, ep + ".0.bn", 64);
             e[ep + ".1.conv.weight"] = 64 * 64; e[ep + ".1.conv.bias"] = 64;
         }
         snprintf(b, sizeof(b), "enc%d.w_vs.0.conv", p);
-        e[std::string(b) + ".weight"] = (size_t)n->DV * 512; e[std::string(b) + ".bias"] = n->DV;
+        e[std::string(b) + ".weight"] = (size_t)n->DV * n->C; e[std::string(b) + ".bias"] = n->DV;
         snprintf(b, sizeof(b), "layer_norm%d.ln", p);
         e[std::string(b) + ".weight"] = (size_t)n->h * n->w; e[std::string(b) + ".bias"] = (size_t)n->h * n->w;
         snprintf(b, sizeof(b), "head%d.conv5", p);
@@ -233,16 +250,22 @@ static void build_expected(tdnet* n) {
 extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) {
     if (!cfg || !out) return td_fail("tdnet_create: null argument");
     if (cfg->model != 4 && cfg->model != 2) return td_fail("tdnet_create: model must be 4 (td4) or 2 (td2), got %d", cfg->model);
-    if (cfg->backbone != 18 && cfg->backbone != 34)
-        return td_fail("tdnet_create: backbone must be 18 or 34 (BasicBlock ResNets), got %d", cfg->backbone);
+    if (cfg->backbone != 18 && cfg->backbone != 34 && cfg->backbone != 50)
+        return td_fail("tdnet_create: backbone must be 18, 34 or 50, got %d", cfg->backbone);
+    if (cfg->backbone == 50 && cfg->model != 2)
+        return td_fail("tdnet_create: the Bottleneck backbone is only shipped with td2 (td2_psp50.py); td4 would need d_v = 2048");
     if (cfg->nclass < 1 || cfg->nclass > 32) return td_fail("tdnet_create: nclass must be in 1..32");
     if (cfg->height < 9 || cfg->width < 9) return td_fail("tdnet_create: input too small");
     TD_HIP(hipSetDevice(cfg->device));
     tdnet* n = new tdnet();
     n->cfg = *cfg;
     n->P = cfg->model;
-    n->DV = cfg->model == 4 ? 512 : 128;                               // td4_psp18.py:85 / td2_psp50.py:79
-    n->MID = cfg->model == 4 ? 128 : 64;                               // FCNHead chn_down 4 / 2
+    const int exp = cfg->backbone == 50 ? 4 : 1;                       // Bottleneck expansion (td2_psp50.py:63-66)
+    n->deep = cfg->backbone == 50;
+    n->C = 512 * exp;
+    n->SC = n->deep ? 128 : 64;
+    n->DV = cfg->model == 4 ? 512 : 128 * exp;                         // td4_psp18.py:85 / td2_psp50.py:79 (512*exp//4)
+    n->MID = cfg->model == 4 ? n->DV / 4 : n->DV / 2;                  // FCNHead chn_down 4 / 2
     n->FIFO = cfg->model == 4 ? 3 : 1;
     n->H = cfg->height; n->W = cfg->width;
     n->H1 = (n->H - 1) / 2 + 1; n->W1 = (n->W - 1) / 2 + 1;
@@ -257,8 +280,8 @@ extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) {
 }
 
 static void free_path(PathLayers& p) {
-    free_conv_layer(p.stem);
-    for (auto& b : p.blocks) { free_conv_layer(b.c1); free_conv_layer(b.c2); free_conv_layer(b.ds); }
+    free_conv_layer(p.stem); free_conv_layer(p.stem2); free_conv_layer(p.stem3);
+    for (auto& b : p.blocks) { free_conv_layer(b.c1); free_conv_layer(b.c2); free_conv_layer(b.c3); free_conv_layer(b.ds); }
     for (ConvLayer* c : {&p.enc_v, &p.enc_q0, &p.enc_q1, &p.enc_k0, &p.enc_k1, &p.head3}) free_conv_layer(*c);
     for (auto& a : p.atn) { free_conv_layer(a.fc); if (a.d_bias) hipFree(a.d_bias); }
     for (float* q : {p.d_ppm_w, p.d_ppm_b, p.d_ln_g, p.d_ln_b, p.d_cls_w, p.d_cls_b}) if (q) hipFree(q);
@@ -266,7 +289,7 @@ static void free_path(PathLayers& p) {
 extern "C" void tdnet_destroy(tdnet_t* n) {
     if (!n) return;
     for (auto& p : n->paths) free_path(p);
-    for (float* q : {n->img4, n->s1, n->bx, n->bt, n->br, n->rowpart, n->pooled, n->ppmfeat, n->z, n->v_cur, n->q1, n->q_cur,
+    for (float* q : {n->img4, n->s1, n->s1b, n->bx, n->bt, n->br, n->bu, n->rowpart, n->pooled, n->ppmfeat, n->z, n->v_cur, n->q1, n->q_cur,
                      n->k1, n->vp, n->chain_a, n->chain_b, n->feat, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, n->headmid,
                      n->lowres, n->stage_tmp, n->logits_tmp})
         if (q) hipFree(q);
@@ -324,18 +347,30 @@ static int upload(float** d, const std::vector<float>& v) {
 
 static int alloc_workspace(tdnet* n) {
     const size_t hw = (size_t)n->Lq, lk = (size_t)n->Lk;
-    size_t bmax = (size_t)n->H2 * n->W2 * 64;
-    if (hw * 512 > bmax) bmax = hw * 512;
+    const size_t C = n->C, FS = C / 8;
+    size_t bmax = (size_t)n->H2 * n->W2 * n->SC, cmax = (size_t)n->H2 * n->W2 * 64;   // bmax: block in/out, cmax: inner (planes) maps
+    {
+        int ch = n->H2, cw = n->W2;
+        for (auto& s : n->bspec) {
+            const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
+            bmax = std::max(bmax, (size_t)oh * ow * s.cout);
+            cmax = std::max(cmax, (size_t)ch * cw * (s.bott ? s.planes : s.cout));     // Bottleneck conv1 output is at the INPUT resolution
+            ch = oh; cw = ow;
+        }
+    }
     if (dev_alloc(&n->img4, (size_t)n->H * n->W * 4)) return -1;
     if (dev_alloc(&n->s1, (size_t)n->H1 * n->W1 * 64)) return -1;
-    if (dev_alloc(&n->bx, bmax) || dev_alloc(&n->bt, bmax) || dev_alloc(&n->br, bmax)) return -1;
-    if (dev_alloc(&n->rowpart, (size_t)n->h * 12 * 512) || dev_alloc(&n->pooled, 50 * 512) || dev_alloc(&n->ppmfeat, 50 * 64)) return -1;
-    if (dev_alloc(&n->z, hw * 512) || dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
+    if (n->deep && dev_alloc(&n->s1b, (size_t)n->H1 * n->W1 * 64)) return -1;
+    if (n->deep) bmax = std::max(bmax, (size_t)n->H1 * n->W1 * 128);   // br also holds the deep stem output
+    if (dev_alloc(&n->bx, bmax) || dev_alloc(&n->br, bmax) || dev_alloc(&n->bt, std::max(cmax, n->bspec[0].bott ? (size_t)0 : bmax))) return -1;
+    if (n->deep && dev_alloc(&n->bu, cmax)) return -1;
+    if (dev_alloc(&n->rowpart, (size_t)n->h * 12 * C) || dev_alloc(&n->pooled, 50 * C) || dev_alloc(&n->ppmfeat, 50 * FS)) return -1;
+    if (dev_alloc(&n->z, hw * C) || dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
     if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass)) return -1;
-    n->stage_tmp_floats = hw * 512;
+    n->stage_tmp_floats = hw * C;
     if (dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
     n->slots.resize(n->FIFO + 1);
     for (auto& s : n->slots)
@@ -354,7 +389,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         if (k.size() > 19 && k.compare(k.size() - 19, 19, "num_batches_tracked") == 0) continue;
         if (!n->sd.count(k)) return td_fail("Missing key in state_dict: \"%s\"", k.c_str());
     }
-    const int C = 512, DV = n->DV, FS = C / (2 * 4), NC = n->cfg.nclass;
+    const int C = n->C, DV = n->DV, FS = C / (2 * 4), NC = n->cfg.nclass;
     n->paths.resize(n->P);
     char b[160];
     for (int p = 0; p < n->P; ++p) {
@@ -362,7 +397,14 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         L.pid = p & 1;                                                 // td4_psp18.py:80-83 / td2_psp50.py:76-77
         snprintf(b, sizeof(b), "pretrained%d", p + 1);
         const std::string pre = b;
-        {
+        if (n->deep) {                                                 // conv3x3 s2 3->64, conv3x3 64->64, conv3x3 64->128 (+bn1)
+            Folded f0 = fold(n, pre + ".conv1.0.weight", "", pre + ".conv1.1", 64);
+            if (make_conv_layer(L.stem, f0.w, f0.b, 64, 3, 3, 2, 1, 1, true, (long)n->H1 * n->W1)) return -1;
+            Folded f1 = fold(n, pre + ".conv1.3.weight", "", pre + ".conv1.4", 64);
+            if (make_conv_layer(L.stem2, f1.w, f1.b, 64, 64, 3, 1, 1, 1, false, (long)n->H1 * n->W1)) return -1;
+            Folded f2 = fold(n, pre + ".conv1.6.weight", "", pre + ".bn1", 128);
+            if (make_conv_layer(L.stem3, f2.w, f2.b, 128, 64, 3, 1, 1, 1, false, (long)n->H1 * n->W1)) return -1;
+        } else {
             Folded f = fold(n, pre + ".conv1.weight", "", pre + ".bn1", 64);
             if (make_conv_layer(L.stem, f.w, f.b, 64, 3, 7, 2, 1, 1, true, (long)n->H1 * n->W1)) return -1;
         }
@@ -372,10 +414,20 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             const std::string bp = pre + "." + s.name;
             const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
             const long M = (long)oh * ow;
-            Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.cout);
-            if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M)) return -1;
-            Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.cout);
-            if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M)) return -1;
+            B.bott = s.bott;
+            if (s.bott) {
+                Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.planes);
+                if (make_conv_layer(B.c1, f1.w, f1.b, s.planes, s.cin, 1, 1, 1, 1, false, (long)ch * cw)) return -1;
+                Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.planes);
+                if (make_conv_layer(B.c2, f2.w, f2.b, s.planes, s.planes, 3, s.stride, s.dil1, 1, false, M)) return -1;
+                Folded f3 = fold(n, bp + ".conv3.weight", "", bp + ".bn3", s.cout);
+                if (make_conv_layer(B.c3, f3.w, f3.b, s.cout, s.planes, 1, 1, 1, 1, false, M)) return -1;   // ReLU after the residual add
+            } else {
+                Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.cout);
+                if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M)) return -1;
+                Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.cout);
+                if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M)) return -1;
+            }
             B.has_ds = s.ds;
             if (s.ds) {
                 Folded fd = fold(n, bp + ".downsample.0.weight", "", bp + ".downsample.1", s.cout);
@@ -389,7 +441,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         std::vector<float> pw((size_t)4 * FS * C), pb((size_t)4 * FS);
         for (int j = 0; j < 4; ++j) {
             snprintf(b, sizeof(b), "psp%d.conv%d", p + 1, j + 1);
-            Folded f = fold(n, std::string(b) + ".0.weight", "", std::string(b) + ".1", 128);
+            Folded f = fold(n, std::string(b) + ".0.weight", "", std::string(b) + ".1", C / 4);
             for (int o = 0; o < FS; ++o) {
                 for (int c = 0; c < C; ++c) pw[((size_t)j * C + c) * FS + o] = f.w[(size_t)(L.pid * FS + o) * C + c];   // [lvl][c][f]
                 pb[j * FS + o] = f.b[L.pid * FS + o];
@@ -500,13 +552,13 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
     prof_end(n, s);
 }
 
-static void run_ppm(tdnet* n, const float* c4, int h, int w, const float* wgt, const float* bias, int pid, float* rowpart,
+static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, const float* wgt, const float* bias, int pid, float* rowpart,
                     float* pooled, float* ppmfeat, float* z, hipStream_t s) {
-    const int C = 512, XS = 256, FS = 64;
+    const int XS = C / 2, FS = C / 8;                                  // x slice c/path_num, pyramid slices c/(4 path_num), path_num = 2
     prof_begin(n, 2, false, 0, s);
     TD_LAUNCH(k_ppm_rowsum, dim3(h * 12), dim3(C / 4), 0, s, c4, rowpart, w, C);
     TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
-    TD_LAUNCH(k_ppm_conv, dim3(50), dim3(4 * FS), 4 * FS * 4, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
+    TD_LAUNCH(k_ppm_conv, dim3(50 * (FS / 64)), dim3(256), 256 * 4, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
     TD_LAUNCH(k_ppm_assemble, dim3(td_grid_for((long)h * w * (C / 4))), dim3(256), 0, s, c4, (const float*)ppmfeat, z, h, w, C,
               pid * XS, XS, FS);
     prof_end(n, s);
@@ -565,20 +617,34 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     }
     // backbone (resnet.py:204-215)
     run_stem_pre(n, img, n->H, n->W, n->img4, s);
-    run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s);
-    run_maxpool(n, n->s1, n->H1, n->W1, 64, n->bx, s);
+    if (n->deep) {                                                     // resnet.py:122-131
+        run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1b, s);
+        run_conv(n, L.stem2, n->s1b, n->H1, n->W1, nullptr, n->s1, s);
+        run_conv(n, L.stem3, n->s1, n->H1, n->W1, nullptr, n->br, s);   // 128 ch at H1 x W1 -> br (sized for it below)
+    } else {
+        run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s);
+    }
+    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s);
     int ch = n->H2, cw = n->W2;
     for (auto& B : L.blocks) {
         int oh, ow;
-        run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow);
-        const float* res = n->bx;
-        if (B.has_ds) { run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s); res = n->br; }
-        run_conv(n, B.c2, n->bt, oh, ow, res, n->bx, s);                // in-place on bx when res == bx (same element)
+        if (B.bott) {                                                  // resnet.py:91-111
+            run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s);                        // 1x1, input resolution
+            run_conv(n, B.c2, n->bt, ch, cw, nullptr, n->bu, s, &oh, &ow);              // 3x3 (stride, dilation)
+            const float* res = n->bx;
+            if (B.has_ds) { run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s); res = n->br; }
+            run_conv(n, B.c3, n->bu, oh, ow, res, n->bx, s);                            // 1x1 x4 + residual + ReLU (in place when res == bx)
+        } else {
+            run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow);
+            const float* res = n->bx;
+            if (B.has_ds) { run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s); res = n->br; }
+            run_conv(n, B.c2, n->bt, oh, ow, res, n->bx, s);            // in-place on bx when res == bx (same element)
+        }
         ch = oh; cw = ow;
     }
     float* c4 = n->bx;
     // pyramid pooling slice (td4_psp18.py:271-284)
-    run_ppm(n, c4, n->h, n->w, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
+    run_ppm(n, c4, n->h, n->w, n->C, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
     // Encoding, pre=False (transformer.py:52-56)
     run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s);
     run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s);
@@ -663,8 +729,8 @@ extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_
     const float* src = nullptr;
     long rows = n->Lq, C = 0;
     bool nhwc_map = true, planar = false;
-    if (s == "c4") { src = n->bx; C = 512; }
-    else if (s == "z") { src = n->z; C = 512; }
+    if (s == "c4") { src = n->bx; C = n->C; }
+    else if (s == "z") { src = n->z; C = n->C; }
     else if (s == "v_cur") { src = n->v_cur; C = n->DV; }
     else if (s == "feat") { src = n->feat; C = n->DV; }
     else if (s == "ln") { src = n->ln; C = n->DV; }
@@ -693,19 +759,22 @@ extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_
 static double frame_flops(const tdnet* n) {
     const PathLayers& L = n->paths[0];
     double f = L.stem.flops_per_pixel() * n->H1 * n->W1;
+    if (n->deep) f += (L.stem2.flops_per_pixel() + L.stem3.flops_per_pixel()) * n->H1 * n->W1;
     int ch = n->H2, cw = n->W2;
     for (size_t i = 0; i < L.blocks.size(); ++i) {
         const BlockSpec& s = n->bspec[i];
         const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
         const double M = (double)oh * ow;
-        f += M * (L.blocks[i].c1.flops_per_pixel() + L.blocks[i].c2.flops_per_pixel());
+        if (s.bott) f += (double)ch * cw * L.blocks[i].c1.flops_per_pixel() + M * (L.blocks[i].c2.flops_per_pixel() + L.blocks[i].c3.flops_per_pixel());
+        else f += M * (L.blocks[i].c1.flops_per_pixel() + L.blocks[i].c2.flops_per_pixel());
         if (s.ds) f += M * L.blocks[i].ds.flops_per_pixel();
         ch = oh; cw = ow;
     }
+    const double C = n->C;
     const double Lq = n->Lq, Lk = n->Lk, DV = n->DV;
-    f += 2.0 * (1 + 4 + 9 + 36) * 128.0 * 512;                                          // pyramid 1x1 convs on the 50 bins
-    f += Lq * (2.0 * 512 * DV + 2.0 * 512 * 64 + 2.0 * 64 * 64);                           // enc pre=False
-    f += Lk * (2.0 * 512 * DV + 2 * (2.0 * 512 * 64 + 2.0 * 64 * 64));                     // enc pre=True (q_, k_, v_)
+    f += 2.0 * (1 + 4 + 9 + 36) * (C / 4) * C;                                          // pyramid 1x1 convs on the 50 bins
+    f += Lq * (2.0 * C * DV + 2.0 * C * 64 + 2.0 * 64 * 64);                           // enc pre=False
+    f += Lk * (2.0 * C * DV + 2 * (2.0 * C * 64 + 2.0 * 64 * 64));                     // enc pre=True (q_, k_, v_)
     if (n->P == 4) {
         f += 2 * (2.0 * Lk * Lk * (64 + DV) + 2.0 * Lk * DV * DV);                         // two cached-frame attentions + fc
         f += 2.0 * Lq * Lk * (64 + DV) + 2.0 * Lq * DV * DV;                               // final attention + fc on Lq rows
@@ -839,7 +908,7 @@ extern "C" int tdnet_op_ppm(const float* c4, int h, int w, const float* w_host, 
     float *dw = nullptr, *db = nullptr, *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr;
     if (upload(&dw, pw) || upload(&db, pb)) return -1;
     if (dev_alloc(&rowpart, (size_t)h * 12 * C) || dev_alloc(&pooled, 50 * C) || dev_alloc(&ppmfeat, 50 * FS)) return -1;
-    run_ppm(nullptr, c4, h, w, dw, db, pid, rowpart, pooled, ppmfeat, z, (hipStream_t)stream);
+    run_ppm(nullptr, c4, h, w, C, dw, db, pid, rowpart, pooled, ppmfeat, z, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
     for (float* q : {dw, db, rowpart, pooled, ppmfeat}) hipFree(q);

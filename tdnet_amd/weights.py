@@ -19,6 +19,7 @@ from . import arch
 # Gain on the second (output) conv of the q and k branches, calibrated once with the CPU oracle so that the
 # attention scores q.k^T/8 have an rms of ~2-3 at 1024x2048 (softmax neither uniform nor one-hot).
 QK_GAIN = 0.3
+BOTTLENECK_GAIN = 1.0
 
 
 def _is_qk_out(name):
@@ -62,13 +63,14 @@ def synth_tensor(name, shape, seed):
     if leaf == "bias" and _is_qk_out(name):
         return (0.05 * QK_GAIN * g.standard_normal(shape)).astype(np.float32)
     if leaf == "bias":
-        is_bn = name.endswith(("bn1.bias", "bn2.bias", "bn.bias")) or ".downsample.1." in name \
+        is_bn = name.endswith(("bn1.bias", "bn2.bias", "bn3.bias", "bn.bias", "conv1.1.bias", "conv1.4.bias")) or ".downsample.1." in name \
             or (".conv5.1." in name) or (name.startswith("psp") and ".1." in name)
         return ((0.1 if is_bn else 0.05) * g.standard_normal(shape)).astype(np.float32)
     raise ValueError("no rule for %s %s" % (name, shape))
 
 
-_BN2 = re.compile(r"^pretrained\d+\.layer\d\.\d+\.bn2\.weight$")
+_BN_LAST = {False: re.compile(r"^pretrained\d+\.layer\d\.\d+\.bn2\.weight$"),      # BasicBlock: bn2 closes the branch
+            True: re.compile(r"^pretrained\d+\.layer\d\.\d+\.bn3\.weight$")}       # Bottleneck: bn3
 
 
 def synth_state_dict(spec, h, w, seed=0):
@@ -79,11 +81,12 @@ def synth_state_dict(spec, h, w, seed=0):
     attention scores grow with it and fp32 evaluations of the same graph drift apart (see QK_GAIN above).  The factor
     is 1 for ResNet-18."""
     nblocks = len(arch.backbone_blocks(spec.backbone))
-    g2 = np.float32((8.0 / nblocks) ** 0.77)          # measured: keeps c4 rms of ResNet-34 at the ResNet-18 level
+    # measured with the CPU oracle: these factors keep c4 rms of ResNet-34 / ResNet-50 at the ResNet-18 level (~9 at full size)
+    g2 = np.float32(BOTTLENECK_GAIN if arch.is_bottleneck(spec.backbone) else (8.0 / nblocks) ** 0.77)
     out = {}
     for k, s in arch.state_dict_shapes(spec, h, w).items():
         t = synth_tensor(k, s, seed)
-        if g2 != 1.0 and _BN2.match(k):
+        if g2 != 1.0 and _BN_LAST[arch.is_bottleneck(spec.backbone)].match(k):
             t = t * g2
         out[k] = t
     return out

@@ -60,7 +60,7 @@ thread_local char* g_lds = nullptr;
 
 static constexpr size_t STACK_BYTES = 96 * 1024;
 static constexpr size_t LDS_BYTES = 160 * 1024;
-static constexpr int MAX_THREADS = 256;
+static constexpr int MAX_THREADS = 512;
 
 struct WaveCtx {
     float a[2][64], b[2][64];

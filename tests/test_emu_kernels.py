@@ -63,7 +63,7 @@ def test_layernorm_ppm_upsample(lib):
         opcheck.upsample(lib, MEM, c, h, w, H, W)
 
 
-CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65)]
+CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet50", 33, 65)]
 
 
 @pytest.mark.parametrize("name,bb,H,W", CASES)
@@ -75,7 +75,7 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
     T = 1 + max(int(k.split("_")[0][1:]) for k in g.files if k.startswith("f"))
     e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib)
     e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
-    shapes = {"c4": (1, 512, h, w), "z": (1, 512, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64),
+    shapes = {"c4": (1, spec.d_model, h, w), "z": (1, spec.d_model, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64),
               "ln": (1, spec.d_v, h, w), "lowres": (1, 19, h, w), "cache_q": (1, hk * wk, 64), "cache_k": (1, hk * wk, 64),
               "cache_v": (1, hk * wk, spec.d_v)}
     for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):

@@ -37,14 +37,14 @@ def check_frame(out, ref, tag):
 
 
 @pytest.mark.parametrize("name,bb,H,W", [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet34", 33, 65),
-                                         ("td4", "resnet18", 65, 129), ("td2", "resnet18", 49, 81)])
+                                         ("td4", "resnet18", 65, 129), ("td2", "resnet18", 49, 81), ("td2", "resnet50", 33, 65)])
 def test_against_reference_goldens(golden_dir, name, bb, H, W):
     g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
     T = 1 + max(int(k.split("_")[0][1:]) for k in g.files if k.startswith("f"))
     spec = arch.model_spec(name, 19, bb)
     h, w = arch.feat_size(H), arch.feat_size(W)
     hk, wk = arch.key_size(h), arch.key_size(w)
-    shapes = {"c4": (1, 512, h, w), "z": (1, 512, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64),
+    shapes = {"c4": (1, spec.d_model, h, w), "z": (1, spec.d_model, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64),
               "ln": (1, spec.d_v, h, w), "lowres": (1, 19, h, w), "cache_q": (1, hk * wk, 64), "cache_k": (1, hk * wk, 64),
               "cache_v": (1, hk * wk, spec.d_v)}
     m = make_model(name, bb)
@@ -86,6 +86,10 @@ def test_vs_oracle_c1_512x1024():
 
 def test_vs_oracle_full_size_td4_1024x2048():
     _vs_oracle("td4", "resnet18", 1024, 2048, 5)           # configs[2]: all four paths cold + first steady-state frame
+
+
+def test_vs_oracle_td2_psp50_native():
+    _vs_oracle("td2", "resnet50", 769, 1537, 3)            # the reference's shipped td2-psp50 at its native resolution (test.py:28-32)
 
 
 def test_vs_oracle_native_769x1537():

@@ -10,7 +10,7 @@ from oracle import tdnet_ref
 from tdnet_amd import arch, weights
 
 CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet34", 33, 65),
-         ("td4", "resnet18", 65, 129), ("td2", "resnet18", 49, 81)]
+         ("td4", "resnet18", 65, 129), ("td2", "resnet18", 49, 81), ("td2", "resnet50", 33, 65)]
 
 
 def _run(name, bb, H, W, T):

@@ -89,7 +89,7 @@ def main():
     # ---- small, fully traced cases (every stage boundary) -------------------------------------------------
     cases = [("td4", "resnet18", 33, 65, 6, True), ("td2", "resnet18", 33, 65, 4, True),
              ("td2", "resnet34", 33, 65, 3, False), ("td4", "resnet18", 65, 129, 6, False),
-             ("td2", "resnet18", 49, 81, 3, False)]
+             ("td2", "resnet18", 49, 81, 3, False), ("td2", "resnet50", 33, 65, 3, True)]
     for name, bb, H, W, T, full in cases:
         spec, m = build_reference(name, bb, H, W, seed=0)
         frames = weights.synth_video(H, W, T, seed=1)
@@ -107,7 +107,8 @@ def main():
     # ---- full-size digests (statistics + strided samples only) --------------------------------------------
     digests = {}
     for name, bb, H, W, T in [("td2", "resnet18", 512, 1024, 4), ("td4", "resnet18", 1024, 2048, 6),
-                              ("td4", "resnet18", 769, 1537, 5), ("td2", "resnet34", 720, 960, 3)]:
+                              ("td4", "resnet18", 769, 1537, 5), ("td2", "resnet34", 720, 960, 3),
+                              ("td2", "resnet50", 769, 1537, 3)]:
         spec, m = build_reference(name, bb, H, W, seed=0)
         frames = weights.synth_video(H, W, T, seed=1)
         with torch.no_grad():
