@@ -30,7 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from tdnet_amd import arch, parallel, weights  # noqa: E402
-from tdnet_amd.model import td2_psp50, td4_psp18  # noqa: E402
+from tdnet_amd.model import pspnet, td2_psp50, td4_psp18  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 
@@ -50,8 +50,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--model", default="td4", choices=["td4", "td2"])
-    ap.add_argument("--backbone", default="resnet18")
+    ap.add_argument("--model", default="td4", choices=["td4", "td2", "psp"])
+    ap.add_argument("--backbone", default=None, help="resnet18 (default) | resnet34 | resnet50 (td2) | resnet101 (psp)")
     ap.add_argument("--size", default="1024x2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch (default: library default)")
@@ -69,13 +69,18 @@ def main():
     if args.conv_pipeline is not None:
         from tdnet_amd import _capi
         _capi.lib().tdnet_set_conv_pipeline(args.conv_pipeline)
+    if args.backbone is None:
+        args.backbone = "resnet101" if args.model == "psp" else "resnet18"
     spec = arch.model_spec(args.model, 19, args.backbone)
     P = spec.path_num
     h, w = arch.feat_size(H), arch.feat_size(W)
     sd = weights.synth_state_dict(spec, h, w, 0) if rank == 0 else None
     sd = parallel.broadcast_state_dict(spec, h, w, sd, dev)                       # the one RCCL collective on the data path
-    cls = td4_psp18.td4_psp18 if args.model == "td4" else td2_psp50.td2_psp50
-    model = cls(nclass=19, path_num=P, model_path=None, backbone=args.backbone).eval().to(dev)
+    if args.model == "psp":                                                       # the reference's comparison model (test.py:34-38)
+        model = pspnet.pspnet(nclass=19, model_path=None, backbone=args.backbone).eval().to(dev)
+    else:
+        cls = td4_psp18.td4_psp18 if args.model == "td4" else td2_psp50.td2_psp50
+        model = cls(nclass=19, path_num=P, model_path=None, backbone=args.backbone).eval().to(dev)
     model.load_state_dict(sd)
 
     # one clip per rank (different seeds), pre-staged on the device; frames cycle, pos_id keeps counting
@@ -103,12 +108,13 @@ def main():
     tmax = parallel.allreduce_max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()
     fps = world * args.steps / tmax
 
-    res = {"metric": "frames/sec (%s-psp%s, %dx%d, full-resolution logits)" % (args.model, args.backbone[6:], H, W),
+    mname = ("psp%s" if args.model == "psp" else args.model + "-psp%s") % args.backbone[6:]
+    res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, P + 2),
            "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%s-psp%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, 1 clip per GPU"
-                                  % (args.model, args.backbone[6:], H, W, spec.fifo),
+           "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, 1 clip per GPU"
+                                  % (mname, H, W, spec.fifo),
                       "parallelism": "clip-parallel x%d, RCCL weight broadcast only" % world, "target_fps_per_gpu": 30}}
 
     if rank == 0:
@@ -145,7 +151,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import tdnet_ref                                          # checker / baseline only
             cores = tdnet_ref.tune_threads()          # threads actually used (fastest of 8..128 on a probe conv)
-            ref = tdnet_ref.TDNetRef(spec, sd)
+            ref = (tdnet_ref.PSPNetRef if args.model == "psp" else tdnet_ref.TDNetRef)(spec, sd)
             model.reset()
             nwarm, nsteady = P, max(1, args.cpu_frames)
             cpu_t, worst, flips, npx = 0.0, 0.0, 0, 0

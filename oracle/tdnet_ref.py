@@ -197,6 +197,32 @@ class TDNetRef:
         return F.interpolate(out, (h, w), mode="bilinear", align_corners=True)
 
 
+class PSPNetRef:
+    """Stateless single-frame PSPNet (the comparison model `--model psp101`, test.py:34-38): pspnet.py:73-89 forward,
+    PSPHead pspnet.py:102-115 = full pyramid pooling (:118-157, no slicing) -> conv3x3 -> BN -> ReLU -> conv1x1."""
+
+    def __init__(self, spec, state_dict):
+        self.spec = spec
+        self.sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in state_dict.items()}
+        self.blocks = arch.backbone_blocks(spec.backbone)
+        self.trace = None
+
+    def reset(self):
+        pass
+
+    @torch.no_grad()
+    def forward(self, img, pos_id=None):
+        sd = self.sd
+        h, w = img.shape[-2:]
+        c4 = backbone(img[-1:], sd, "pretrained", self.blocks)
+        z = pyramid_pooling(c4, sd, "head.conv5.0", 1, 0)             # path_num 1, pid 0 = every channel (pspnet.py:157)
+        y = F.relu(bn_eval(F.conv2d(z, sd["head.conv5.1.weight"], None, 1, 1), sd, "head.conv5.2"))
+        low = F.conv2d(y, sd["head.conv5.5.weight"], sd["head.conv5.5.bias"])
+        if self.trace is not None:
+            self.trace.update(c4=c4, z=z, lowres=low)
+        return F.interpolate(low, (h, w), mode="bilinear", align_corners=True)
+
+
 def tune_threads(candidates=(8, 16, 32, 64, 128)):
     """Pick the torch-CPU thread count that runs a representative dilated conv fastest (oneDNN collapses when it is
     given every SMT thread of a 256-thread host: measured 42 s/frame vs ~2.5 s on 8 cores).  Returns the count set."""

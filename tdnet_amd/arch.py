@@ -16,11 +16,11 @@ from collections import namedtuple
 #                    (resnet.py:62-111: Bottleneck ignores previous_dilation)
 BlockSpec = namedtuple("BlockSpec", "name cin cout stride dil1 dil2 downsample kind planes")
 
-_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3)}
+_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
 
 
 def is_bottleneck(backbone):
-    return backbone == "resnet50"
+    return backbone in ("resnet50", "resnet101")
 
 
 def expansion(backbone):
@@ -47,7 +47,7 @@ def backbone_blocks(backbone):
     conv2 uses `previous_dilation` (resnet.py:32-37); the first block of layer3 uses dilation 1 (resnet.py:183-185).
     """
     if backbone not in _LAYERS:
-        raise ValueError("backbone must be resnet18, resnet34 or resnet50; got %r" % (backbone,))
+        raise ValueError("backbone must be resnet18/34/50/101; got %r" % (backbone,))
     nb = _LAYERS[backbone]
     bott = is_bottleneck(backbone)
     exp = 4 if bott else 1
@@ -90,6 +90,12 @@ def model_spec(name, nclass=19, backbone=None):
         # td2_psp50.py:76-82 -> PyramidPooling(path_num=2, pid=0,1); d_v = 512*exp//4 (128 | 512); head chn_down=2 (:88-89)
         atn = {0: ("atn1",), 1: ("atn2",)}
         return ModelSpec("td2", 2, bb, 512 * e, 64, 128 * e, 2, (0, 1), 128 * e // 2, nclass, 1, atn)
+    if name == "psp":
+        # pspnet.py:31-70: single-frame PSPNet (the comparison model of test.py:34-38); full pyramid pooling, no attention
+        bb = backbone or "resnet101"
+        if not is_bottleneck(bb):
+            raise ValueError("psp is shipped with resnet101 (pspnet.py:36); only Bottleneck backbones are implemented for it")
+        return ModelSpec("psp", 1, bb, 2048, 0, 0, 1, (0,), 512, nclass, 0, {})
     raise ValueError(name)
 
 
@@ -111,7 +117,7 @@ def state_dict_shapes(spec, h, w):
     P = spec.path_num
     bott = is_bottleneck(spec.backbone)
     for p in range(1, P + 1):
-        pre = "pretrained%d" % p
+        pre = "pretrained%d" % p if spec.name != "psp" else "pretrained"
         if bott:                                     # deep_base stem: resnet.py:122-131
             out[pre + ".conv1.0.weight"] = (64, 3, 3, 3)
             bn(pre + ".conv1.1", 64)
@@ -142,6 +148,15 @@ def state_dict_shapes(spec, h, w):
         out[pre + ".fc.weight"] = (1000, 512 * expansion(spec.backbone))
         out[pre + ".fc.bias"] = (1000,)
     dm, dk, dv = spec.d_model, spec.d_k, spec.d_v
+    if spec.name == "psp":                          # pspnet.py:102-115: PSPHead = PyramidPooling + conv3x3 + BN + ReLU + Dropout + conv1x1
+        for j in range(1, 5):
+            out["head.conv5.0.conv%d.0.weight" % j] = (dm // 4, dm, 1, 1)
+            bn("head.conv5.0.conv%d.1" % j, dm // 4)
+        out["head.conv5.1.weight"] = (dm // 4, 2 * dm, 3, 3)
+        bn("head.conv5.2", dm // 4)
+        out["head.conv5.5.weight"] = (spec.nclass, dm // 4, 1, 1)
+        out["head.conv5.5.bias"] = (spec.nclass,)
+        return out
     for p in range(1, P + 1):
         for j in range(1, 5):
             out["psp%d.conv%d.0.weight" % (p, j)] = (dm // 4, dm, 1, 1)

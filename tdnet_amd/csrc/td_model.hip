@@ -49,8 +49,9 @@ struct BlockSpec { std::string name; int cin, cout, stride, dil1, dil2; bool ds;
 
 static std::vector<BlockSpec> backbone_blocks(int backbone) {
     const int nb18[4] = {2, 2, 2, 2}, nb34[4] = {3, 4, 6, 3};
-    const int* nb = backbone == 18 ? nb18 : nb34;                      // ResNet-50 has the ResNet-34 block counts
-    const bool bott = backbone == 50;
+    const int nb101[4] = {3, 4, 23, 3};
+    const int* nb = backbone == 18 ? nb18 : backbone == 101 ? nb101 : nb34;   // ResNet-50 has the ResNet-34 block counts
+    const bool bott = backbone == 50 || backbone == 101;
     const int exp = bott ? 4 : 1;
     const int planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 1, 1}, dils[4] = {1, 1, 2, 4};
     std::vector<BlockSpec> out;
@@ -200,7 +201,7 @@ static void build_expected(tdnet* n) {
     char b[160];
     for (int p = 1; p <= n->P; ++p) {
         snprintf(b, sizeof(b), "pretrained%d", p);
-        std::string pre = b;
+        std::string pre = n->cfg.model == 1 ? std::string("pretrained") : std::string(b);   // pspnet.py:51-64: self.pretrained
         if (n->deep) {
             e[pre + ".conv1.0.weight"] = 64 * 3 * 9; add_bn(e, pre + ".conv1.1", 64);
             e[pre + ".conv1.3.weight"] = 64 * 64 * 9; add_bn(e, pre + ".conv1.4", 64);
@@ -222,6 +223,16 @@ static void build_expected(tdnet* n) {
             if (s.ds) { e[bp + ".downsample.0.weight"] = (size_t)s.cout * s.cin; add_bn(e, bp + ".downsample.1", s.cout); }
         }
         e[pre + ".fc.weight"] = (size_t)1000 * n->C; e[pre + ".fc.bias"] = 1000;
+        if (n->cfg.model == 1) {                                       // PSPHead: pspnet.py:102-115
+            for (int j = 1; j <= 4; ++j) {
+                snprintf(b, sizeof(b), "head.conv5.0.conv%d", j);
+                e[std::string(b) + ".0.weight"] = (size_t)(n->C / 4) * n->C;
+                add_bn(e, std::string(b) + ".1", n->C / 4);
+            }
+            e["head.conv5.1.weight"] = (size_t)(n->C / 4) * 2 * n->C * 9; add_bn(e, "head.conv5.2", n->C / 4);
+            e["head.conv5.5.weight"] = (size_t)n->cfg.nclass * (n->C / 4); e["head.conv5.5.bias"] = n->cfg.nclass;
+            continue;
+        }
         for (int j = 1; j <= 4; ++j) {
             snprintf(b, sizeof(b), "psp%d.conv%d", p, j);
             e[std::string(b) + ".0.weight"] = (size_t)(n->C / 4) * n->C;
@@ -242,6 +253,7 @@ static void build_expected(tdnet* n) {
         e[hp + ".0.weight"] = (size_t)n->MID * n->DV * 9; add_bn(e, hp + ".1", n->MID);
         e[hp + ".4.weight"] = (size_t)n->cfg.nclass * n->MID; e[hp + ".4.bias"] = n->cfg.nclass;
     }
+    if (n->cfg.model != 1)
     for (auto& a : atn_module_names(n->cfg.model)) {
         e[a + ".fc.0.conv.weight"] = (size_t)n->DV * n->DV; e[a + ".fc.0.conv.bias"] = n->DV;
     }
@@ -249,24 +261,28 @@ static void build_expected(tdnet* n) {
 
 extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) {
     if (!cfg || !out) return td_fail("tdnet_create: null argument");
-    if (cfg->model != 4 && cfg->model != 2) return td_fail("tdnet_create: model must be 4 (td4) or 2 (td2), got %d", cfg->model);
-    if (cfg->backbone != 18 && cfg->backbone != 34 && cfg->backbone != 50)
-        return td_fail("tdnet_create: backbone must be 18, 34 or 50, got %d", cfg->backbone);
-    if (cfg->backbone == 50 && cfg->model != 2)
+    if (cfg->model != 4 && cfg->model != 2 && cfg->model != 1)
+        return td_fail("tdnet_create: model must be 4 (td4), 2 (td2) or 1 (single-frame PSPNet), got %d", cfg->model);
+    if (cfg->backbone != 18 && cfg->backbone != 34 && cfg->backbone != 50 && cfg->backbone != 101)
+        return td_fail("tdnet_create: backbone must be 18, 34, 50 or 101, got %d", cfg->backbone);
+    if (cfg->backbone == 50 && cfg->model == 4)
         return td_fail("tdnet_create: the Bottleneck backbone is only shipped with td2 (td2_psp50.py); td4 would need d_v = 2048");
+    if ((cfg->backbone == 101) != (cfg->model == 1) && !(cfg->model == 1 && cfg->backbone == 50))
+        return td_fail("tdnet_create: resnet101 is the PSPNet baseline's backbone (pspnet.py:36); psp accepts 50 or 101");
     if (cfg->nclass < 1 || cfg->nclass > 32) return td_fail("tdnet_create: nclass must be in 1..32");
     if (cfg->height < 9 || cfg->width < 9) return td_fail("tdnet_create: input too small");
     TD_HIP(hipSetDevice(cfg->device));
     tdnet* n = new tdnet();
     n->cfg = *cfg;
     n->P = cfg->model;
-    const int exp = cfg->backbone == 50 ? 4 : 1;                       // Bottleneck expansion (td2_psp50.py:63-66)
-    n->deep = cfg->backbone == 50;
+    const int exp = cfg->backbone >= 50 ? 4 : 1;                       // Bottleneck expansion (td2_psp50.py:63-66)
+    n->deep = cfg->backbone >= 50;
     n->C = 512 * exp;
     n->SC = n->deep ? 128 : 64;
     n->DV = cfg->model == 4 ? 512 : 128 * exp;                         // td4_psp18.py:85 / td2_psp50.py:79 (512*exp//4)
     n->MID = cfg->model == 4 ? n->DV / 4 : n->DV / 2;                  // FCNHead chn_down 4 / 2
-    n->FIFO = cfg->model == 4 ? 3 : 1;
+    if (cfg->model == 1) { n->DV = 2 * n->C; n->MID = n->C / 4; }      // PSPHead: conv3x3 on the 2C-channel concat -> C/4 (pspnet.py:105-109)
+    n->FIFO = cfg->model == 4 ? 3 : cfg->model == 2 ? 1 : 0;
     n->H = cfg->height; n->W = cfg->width;
     n->H1 = (n->H - 1) / 2 + 1; n->W1 = (n->W - 1) / 2 + 1;
     n->H2 = (n->H1 - 1) / 2 + 1; n->W2 = (n->W1 - 1) / 2 + 1;
@@ -347,7 +363,8 @@ static int upload(float** d, const std::vector<float>& v) {
 
 static int alloc_workspace(tdnet* n) {
     const size_t hw = (size_t)n->Lq, lk = (size_t)n->Lk;
-    const size_t C = n->C, FS = C / 8;
+    const bool psp = n->cfg.model == 1;
+    const size_t C = n->C, FS = psp ? C / 4 : C / 8, ZC = psp ? 2 * C : C;
     size_t bmax = (size_t)n->H2 * n->W2 * n->SC, cmax = (size_t)n->H2 * n->W2 * 64;   // bmax: block in/out, cmax: inner (planes) maps
     {
         int ch = n->H2, cw = n->W2;
@@ -365,13 +382,14 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->bx, bmax) || dev_alloc(&n->br, bmax) || dev_alloc(&n->bt, std::max(cmax, n->bspec[0].bott ? (size_t)0 : bmax))) return -1;
     if (n->deep && dev_alloc(&n->bu, cmax)) return -1;
     if (dev_alloc(&n->rowpart, (size_t)n->h * 12 * C) || dev_alloc(&n->pooled, 50 * C) || dev_alloc(&n->ppmfeat, 50 * FS)) return -1;
-    if (dev_alloc(&n->z, hw * C) || dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
+    if (dev_alloc(&n->z, hw * ZC)) return -1;
+    n->stage_tmp_floats = hw * ZC;
+    if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass) || dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
+    if (psp) return 0;
+    if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
-    if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass)) return -1;
-    n->stage_tmp_floats = hw * C;
-    if (dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
     n->slots.resize(n->FIFO + 1);
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -396,7 +414,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         PathLayers& L = n->paths[p];
         L.pid = p & 1;                                                 // td4_psp18.py:80-83 / td2_psp50.py:76-77
         snprintf(b, sizeof(b), "pretrained%d", p + 1);
-        const std::string pre = b;
+        const std::string pre = n->cfg.model == 1 ? std::string("pretrained") : std::string(b);
         if (n->deep) {                                                 // conv3x3 s2 3->64, conv3x3 64->64, conv3x3 64->128 (+bn1)
             Folded f0 = fold(n, pre + ".conv1.0.weight", "", pre + ".conv1.1", 64);
             if (make_conv_layer(L.stem, f0.w, f0.b, 64, 3, 3, 2, 1, 1, true, (long)n->H1 * n->W1)) return -1;
@@ -437,6 +455,23 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             ch = oh; cw = ow;
         }
         if (ch != n->h || cw != n->w) return td_fail("internal: feature size mismatch %dx%d vs %dx%d", ch, cw, n->h, n->w);
+        if (n->cfg.model == 1) {                                       // PSPHead (pspnet.py:102-115): full pyramid, conv3x3, classifier
+            const int F4 = C / 4;
+            std::vector<float> pw((size_t)4 * F4 * C), pb((size_t)4 * F4);
+            for (int j = 0; j < 4; ++j) {
+                snprintf(b, sizeof(b), "head.conv5.0.conv%d", j + 1);
+                Folded f = fold(n, std::string(b) + ".0.weight", "", std::string(b) + ".1", F4);
+                for (int o = 0; o < F4; ++o) {
+                    for (int c = 0; c < C; ++c) pw[((size_t)j * C + c) * F4 + o] = f.w[(size_t)o * C + c];
+                    pb[j * F4 + o] = f.b[o];
+                }
+            }
+            if (upload(&L.d_ppm_w, pw) || upload(&L.d_ppm_b, pb)) return -1;
+            Folded fh = fold(n, "head.conv5.1.weight", "", "head.conv5.2", n->MID);
+            if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, 2 * C, 3, 1, 1, 1, false, n->Lq)) return -1;
+            if (upload(&L.d_cls_w, T(n, "head.conv5.5.weight")) || upload(&L.d_cls_b, T(n, "head.conv5.5.bias"))) return -1;
+            continue;
+        }
         // pyramid convs: keep only the FS output channels this path's slice uses (td4_psp18.py:279-282)
         std::vector<float> pw((size_t)4 * FS * C), pb((size_t)4 * FS);
         for (int j = 0; j < 4; ++j) {
@@ -552,9 +587,9 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
     prof_end(n, s);
 }
 
-static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, const float* wgt, const float* bias, int pid, float* rowpart,
-                    float* pooled, float* ppmfeat, float* z, hipStream_t s) {
-    const int XS = C / 2, FS = C / 8;                                  // x slice c/path_num, pyramid slices c/(4 path_num), path_num = 2
+// XS = channels of c4 kept (c/path_num, offset pid*XS), FS = channels kept of each pyramid conv (c/(4 path_num))
+static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int FS, const float* wgt, const float* bias, int pid,
+                    float* rowpart, float* pooled, float* ppmfeat, float* z, hipStream_t s) {
     prof_begin(n, 2, false, 0, s);
     TD_LAUNCH(k_ppm_rowsum, dim3(h * 12), dim3(C / 4), 0, s, c4, rowpart, w, C);
     TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
@@ -598,7 +633,7 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     const int DV = n->DV;
     // ---- fork: everything that depends only on CACHED frames (td4_psp18.py:145-146 and the fc of :147) runs on the side
     // stream while the backbone of the current frame runs on `s`; joined right before the final attention.
-    const bool steady = (int)n->fifo.size() >= n->FIFO;
+    const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
     if (steady) {
         hipStream_t c = n->side;
         TD_HIP(hipEventRecord(n->ev_fork, s));
@@ -644,7 +679,13 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     }
     float* c4 = n->bx;
     // pyramid pooling slice (td4_psp18.py:271-284)
-    run_ppm(n, c4, n->h, n->w, n->C, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
+    if (n->cfg.model == 1) {                                           // pspnet.py:73-89: PSPHead on c4, no temporal state
+        run_ppm(n, c4, n->h, n->w, n->C, n->C, n->C / 4, L.d_ppm_w, L.d_ppm_b, 0, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
+        run_conv(n, L.head3, n->z, n->h, n->w, nullptr, n->headmid, s);
+        run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s);
+        return 0;
+    }
+    run_ppm(n, c4, n->h, n->w, n->C, n->C / 2, n->C / 8, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
     // Encoding, pre=False (transformer.py:52-56)
     run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s);
     run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s);
@@ -730,12 +771,13 @@ extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_
     long rows = n->Lq, C = 0;
     bool nhwc_map = true, planar = false;
     if (s == "c4") { src = n->bx; C = n->C; }
-    else if (s == "z") { src = n->z; C = n->C; }
+    else if (s == "z") { src = n->z; C = n->cfg.model == 1 ? 2 * n->C : n->C; }
+    else if (s == "lowres") { src = n->lowres; C = n->cfg.nclass; planar = true; }
+    else if (n->cfg.model == 1) return td_fail("tdnet_get_stage: stage \"%s\" does not exist in the single-frame PSPNet", name);
     else if (s == "v_cur") { src = n->v_cur; C = n->DV; }
     else if (s == "feat") { src = n->feat; C = n->DV; }
     else if (s == "ln") { src = n->ln; C = n->DV; }
     else if (s == "q_cur") { src = n->q_cur; C = 64; nhwc_map = false; }
-    else if (s == "lowres") { src = n->lowres; C = n->cfg.nclass; planar = true; }
     else if (s == "cache_q" || s == "cache_k" || s == "cache_v") {
         if (n->last_slot < 0) return td_fail("tdnet_get_stage: no frame cached yet");
         const CacheSlot& c = n->slots[n->last_slot];
@@ -771,6 +813,8 @@ static double frame_flops(const tdnet* n) {
         ch = oh; cw = ow;
     }
     const double C = n->C;
+    if (n->cfg.model == 1)
+        return f + 2.0 * 50 * (C / 4) * C * 4 / 4 + (double)n->Lq * (2.0 * 2 * C * 9 * n->MID + 2.0 * n->MID * n->cfg.nclass);
     const double Lq = n->Lq, Lk = n->Lk, DV = n->DV;
     f += 2.0 * (1 + 4 + 9 + 36) * (C / 4) * C;                                          // pyramid 1x1 convs on the 50 bins
     f += Lq * (2.0 * C * DV + 2.0 * C * 64 + 2.0 * 64 * 64);                           // enc pre=False
@@ -908,7 +952,7 @@ extern "C" int tdnet_op_ppm(const float* c4, int h, int w, const float* w_host, 
     float *dw = nullptr, *db = nullptr, *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr;
     if (upload(&dw, pw) || upload(&db, pb)) return -1;
     if (dev_alloc(&rowpart, (size_t)h * 12 * C) || dev_alloc(&pooled, 50 * C) || dev_alloc(&ppmfeat, 50 * FS)) return -1;
-    run_ppm(nullptr, c4, h, w, C, dw, db, pid, rowpart, pooled, ppmfeat, z, (hipStream_t)stream);
+    run_ppm(nullptr, c4, h, w, C, C / 2, FS, dw, db, pid, rowpart, pooled, ppmfeat, z, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
     for (float* q : {dw, db, rowpart, pooled, ppmfeat}) hipFree(q);

@@ -83,6 +83,8 @@ class _TDNetBase(nn.Module):
                 raise RuntimeError("no weights loaded: give model_path or synthetic_seed (the HIP path never runs on "
                                    "unspecified random init)")
             sd = weights.synth_state_dict(self.spec, h, w, self.synthetic_seed)
+        if self._model_id == 1:
+            sd = {k: v for k, v in sd.items()}
         ln = sd.get("layer_norm1.ln.weight")
         if ln is not None and tuple(ln.shape) != (h, w):
             # same failure the reference raises from nn.LayerNorm (td4_psp18.py:107-110 hard-codes [97,193])

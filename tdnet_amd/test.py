@@ -34,8 +34,12 @@ def test(args):
         path_num = 2
         model = td2_psp50.td2_psp50(nclass=19, path_num=path_num, model_path=args._td2_psp50_path,
                                     backbone="resnet" + args.model[-2:], synthetic_seed=args.synthetic_seed)
+    elif args.model == "psp101":                                        # test.py:34-38
+        path_num = 1
+        from tdnet_amd.model import pspnet
+        model = pspnet.pspnet(nclass=19, model_path=args._psp101_path, synthetic_seed=args.synthetic_seed)
     else:
-        raise SystemExit("model must be one of td4-psp18, td2-psp50, td2-psp18, td2-psp34 (psp101 is out of scope)")
+        raise SystemExit("model must be one of td4-psp18, td2-psp50, td2-psp18, td2-psp34, psp101")
     model.eval()
     model.to(device)
     timer, i = 0.0, -1
@@ -73,6 +77,7 @@ if __name__ == "__main__":
     parser.add_argument("--output_path", nargs="?", type=str, default="./output/", help="Path_to_Save")
     parser.add_argument("--_td4_psp18_path", nargs="?", type=str, default="./checkpoint/td4-psp18.pkl", help="Path_to_PSP_Model")
     parser.add_argument("--_td2_psp50_path", nargs="?", type=str, default="./checkpoint/td2-psp50.pkl", help="Path_to_PSP_Model")
+    parser.add_argument("--_psp101_path", nargs="?", type=str, default="./checkpoint/psp101.pkl", help="Path_to_PSP_Model")
     parser.add_argument("--gpu", nargs="?", type=str, default="0", help="gpu_id")
     parser.add_argument("--model", nargs="?", type=str, default="td4-psp18", help="model in [td4-psp18, td2-psp50, td2-psp18, td2-psp34]")
     parser.add_argument("--in_size", nargs="?", type=str, default="769x1537", help="HxW fed to the network (test.py:24)")

@@ -20,6 +20,7 @@ from . import arch
 # attention scores q.k^T/8 have an rms of ~2-3 at 1024x2048 (softmax neither uniform nor one-hot).
 QK_GAIN = 0.3
 BOTTLENECK_GAIN = 1.0
+BOTTLENECK_DEPTH_EXP = 0.54      # ResNet-101 (33 blocks) vs ResNet-50 (16): keeps c4 at the same scale
 
 
 def _is_qk_out(name):
@@ -27,7 +28,7 @@ def _is_qk_out(name):
 
 
 def _is_linear_conv(name):
-    return ".w_vs.0." in name or ".fc.0." in name or _is_qk_out(name) or ".conv5.4." in name
+    return ".w_vs.0." in name or ".fc.0." in name or _is_qk_out(name) or ".conv5.4." in name or name.startswith("head.conv5.5.")
 
 
 def _rng(seed, name):
@@ -39,7 +40,7 @@ def synth_tensor(name, shape, seed):
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":
         return np.zeros((), dtype=np.int64)
-    if ".fc." in name and name.startswith("pretrained"):
+    if ".fc." in name and name.startswith("pretrained"):       # also "pretrained.fc.*" of pspnet
         return np.zeros(shape, dtype=np.float32)            # unused classifier (resnet.py:159-160), kept for strict load
     if ".ln." in name:
         if leaf == "weight":
@@ -64,13 +65,14 @@ def synth_tensor(name, shape, seed):
         return (0.05 * QK_GAIN * g.standard_normal(shape)).astype(np.float32)
     if leaf == "bias":
         is_bn = name.endswith(("bn1.bias", "bn2.bias", "bn3.bias", "bn.bias", "conv1.1.bias", "conv1.4.bias")) or ".downsample.1." in name \
-            or (".conv5.1." in name) or (name.startswith("psp") and ".1." in name)
+            or (".conv5.1." in name) or (".conv5.2." in name) or (name.startswith("psp") and ".1." in name) \
+            or (name.startswith("head.conv5.0.conv") and ".1." in name)
         return ((0.1 if is_bn else 0.05) * g.standard_normal(shape)).astype(np.float32)
     raise ValueError("no rule for %s %s" % (name, shape))
 
 
-_BN_LAST = {False: re.compile(r"^pretrained\d+\.layer\d\.\d+\.bn2\.weight$"),      # BasicBlock: bn2 closes the branch
-            True: re.compile(r"^pretrained\d+\.layer\d\.\d+\.bn3\.weight$")}       # Bottleneck: bn3
+_BN_LAST = {False: re.compile(r"^pretrained\d*\.layer\d\.\d+\.bn2\.weight$"),      # BasicBlock: bn2 closes the branch
+            True: re.compile(r"^pretrained\d*\.layer\d\.\d+\.bn3\.weight$")}       # Bottleneck: bn3
 
 
 def synth_state_dict(spec, h, w, seed=0):
@@ -82,7 +84,7 @@ def synth_state_dict(spec, h, w, seed=0):
     is 1 for ResNet-18."""
     nblocks = len(arch.backbone_blocks(spec.backbone))
     # measured with the CPU oracle: these factors keep c4 rms of ResNet-34 / ResNet-50 at the ResNet-18 level (~9 at full size)
-    g2 = np.float32(BOTTLENECK_GAIN if arch.is_bottleneck(spec.backbone) else (8.0 / nblocks) ** 0.77)
+    g2 = np.float32(BOTTLENECK_GAIN * (16.0 / nblocks) ** BOTTLENECK_DEPTH_EXP if arch.is_bottleneck(spec.backbone) else (8.0 / nblocks) ** 0.77)
     out = {}
     for k, s in arch.state_dict_shapes(spec, h, w).items():
         t = synth_tensor(k, s, seed)

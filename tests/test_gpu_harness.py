@@ -1,0 +1,55 @@
+"""N2 on the GPU: PNG frames -> cityscapesLoader -> checkpoint file -> the reference's frame loop (tdnet_amd/test.py,
+mirror of Testing/test.py) -> colour PNGs, checked against the CPU oracle fed with the same loader output."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tdnet_ref
+from tdnet_amd import arch, weights
+from tdnet_amd.dataloader import cityscapesLoader
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_cli_end_to_end(tmp_path):
+    from PIL import Image
+    H, W, T = 129, 257, 7
+    frames_dir = tmp_path / "data" / "vid1"
+    frames_dir.mkdir(parents=True)
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, (64, 128, 3), dtype=np.uint8)
+    for t in range(T):
+        img = np.roll(base, 3 * t, axis=1)
+        Image.fromarray(img).resize((512, 256), Image.BILINEAR).save(frames_dir / ("frame_%06d_leftImg8bit.png" % t))
+    spec = arch.model_spec("td4", 19, "resnet18")
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    sd = weights.synth_state_dict(spec, h, w, 0)
+    ckpt = tmp_path / "td4-psp18.pkl"
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, str(ckpt))
+    out_dir = tmp_path / "output"
+    out_dir.mkdir()
+    r = subprocess.run([sys.executable, "-m", "tdnet_amd.test", "--model", "td4-psp18", "--img_path", str(tmp_path / "data"),
+                        "--output_path", str(out_dir), "--_td4_psp18_path", str(ckpt), "--in_size", "%dx%d" % (H, W)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Average  RunningTime/Latency" in r.stdout and " Frame  7" in r.stdout
+    # the oracle on the loader's tensors must produce the same quarter-resolution colour maps
+    ld = cityscapesLoader(img_path=str(tmp_path / "data"), in_size=(H, W))
+    ld.load_frames()
+    ref = tdnet_ref.TDNetRef(spec, sd)
+    mism = 0
+    for t, (img, name, folder, size) in enumerate(ld.data):
+        exp = ref.forward(img, t % 4)[0].argmax(0).numpy().astype(np.int8)
+        oh, ow = size[1] // 4, size[0] // 4
+        ys = np.minimum((np.arange(oh) * (H / oh)).astype(np.int64), H - 1)
+        xs = np.minimum((np.arange(ow) * (W / ow)).astype(np.int64), W - 1)
+        exp_rgb = ld.decode_segmap(exp[ys][:, xs]).astype(np.uint8)
+        got = np.asarray(Image.open(out_dir / folder / name).convert("RGB"))
+        assert got.shape == exp_rgb.shape == (oh, ow, 3)
+        mism += int((got != exp_rgb).any(axis=2).sum())
+    assert mism <= 0.002 * T * oh * ow, mism          # only numerical-tie pixels may differ

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/Testing")
 
 import torch  # noqa: E402
-from model.pspnet import td4_psp18 as ref_td4, td2_psp50 as ref_td2  # noqa: E402  (the reference itself)
+from model.pspnet import td4_psp18 as ref_td4, td2_psp50 as ref_td2, pspnet as ref_psp  # noqa: E402  (the reference itself)
 
 from tdnet_amd import arch, weights  # noqa: E402
 
@@ -81,6 +81,38 @@ def run_traced(spec, m, frames):
     return per_frame
 
 
+def psp_goldens(meta, digests):
+    """Single-frame PSPNet-101 (pspnet.py): traced small case + full-size digest.  No LayerNorm, so nothing is patched."""
+    spec = arch.model_spec("psp", 19, "resnet101")
+    for H, W, full in [(33, 65, True), (769, 1537, False)]:
+        sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
+        m = ref_psp.pspnet(nclass=19, model_path=None).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        cur = {}
+        hs = [m.pretrained.layer4.register_forward_hook(lambda mod, i, o: cur.__setitem__("c4", o)),
+              m.head.conv5[0].register_forward_hook(lambda mod, i, o: cur.__setitem__("z", o)),
+              m.head.register_forward_hook(lambda mod, i, o: cur.__setitem__("lowres", o))]
+        x = weights.synth_video(H, W, 1, seed=1)[0]
+        with torch.no_grad():
+            out = m(torch.from_numpy(x), pos_id=0)
+        for h in hs:
+            h.remove()
+        if full:
+            arrs = {"f0_%s" % k: v.numpy().astype(np.float32) for k, v in cur.items()}
+            arrs["f0_logits"] = out.numpy().astype(np.float32)
+            fn = os.path.join(OUT, "psp_resnet101_%dx%d.npz" % (H, W))
+            np.savez_compressed(fn, __meta__=np.array(meta), **arrs)
+            print("wrote", fn, "%.1f MB" % (os.path.getsize(fn) / 1e6))
+        else:
+            o = out.numpy()
+            tag = "psp_resnet101_%dx%d" % (H, W)
+            digests[tag + "_last_frame"] = np.array(0)
+            digests[tag + "_stats"] = np.array([o.min(), o.max(), o.mean(), np.sqrt((o.astype(np.float64) ** 2).sum())], dtype=np.float64)
+            digests[tag + "_sample"] = o[0, :, ::61, ::67].astype(np.float32)
+            digests[tag + "_labels_sample"] = o[0].argmax(0)[::61, ::67].astype(np.int16)
+            print(tag, digests[tag + "_stats"])
+
+
 def main():
     torch.set_num_threads(THREADS)
     os.makedirs(OUT, exist_ok=True)
@@ -125,6 +157,7 @@ def main():
         digests[tag + "_gap_hist"] = np.array([(gap < 1e-4).sum(), (gap < 1e-3).sum(), gap.size], dtype=np.int64)
         digests[tag + "_label_sha256"] = np.array(hashlib.sha256(lab.astype(np.uint8).tobytes()).hexdigest())
         print(tag, digests[tag + "_stats"], digests[tag + "_gap_hist"])
+    psp_goldens(meta, digests)
     fn = os.path.join(OUT, "fullsize_digests.npz")
     np.savez_compressed(fn, __meta__=np.array(meta), **digests)
     print("wrote", fn)
