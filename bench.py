@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch (default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="steady-state frames timed on the CPU oracle")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+                    help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16-input MFMA convs, fp32 accumulate "
+                         "(BASELINE config 5); parity vs the fp32 CPU path is reported, not gated")
     args = ap.parse_args()
     H, W = (int(v) for v in args.size.lower().split("x"))
 
@@ -69,6 +72,9 @@ def main():
     if args.conv_pipeline is not None:
         from tdnet_amd import _capi
         _capi.lib().tdnet_set_conv_pipeline(args.conv_pipeline)
+    if args.precision == "fp16":
+        from tdnet_amd import _capi
+        _capi.lib().tdnet_set_conv_precision(1)
     if args.backbone is None:
         args.backbone = "resnet101" if args.model == "psp" else "resnet18"
     spec = arch.model_spec(args.model, 19, args.backbone)
@@ -112,7 +118,8 @@ def main():
     res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, P + 2),
            "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": "f32" if args.precision == "fp32" else "f16 conv operands (fp32 accumulate, fp32 storage; attention/LN/PPM fp32)",
+           "data": "synthetic",
            "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, 1 clip per GPU"
                                   % (mname, H, W, spec.fifo),
                       "parallelism": "clip-parallel x%d, RCCL weight broadcast only" % world, "target_fps_per_gpu": 30}}

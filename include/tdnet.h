@@ -77,6 +77,9 @@ double tdnet_last_launches(const tdnet_t* h, int which);
 /* Tuning hook (process-wide): conv software pipeline used by handles finalized after the call.
  * 0 = one-stage prefetch (tile s+1 in flight), 1 = two-stage (tile s+2 in flight, LDS writes between the MFMAs).     */
 int tdnet_set_conv_pipeline(int deep);
+/* Precision mode (process-wide, handles finalized after the call): 0 = fp32 MFMA, the default and the only mode that
+ * meets the 1e-3 logits gate; 1 = fp16-input MFMA with fp32 accumulation for every conv but the stem (BASELINE config 5). */
+int tdnet_set_conv_precision(int fp16);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */

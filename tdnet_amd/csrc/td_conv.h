@@ -288,7 +288,9 @@ static inline ConvTileDims conv_tile_dims(ConvTile t) {
 }
 
 // Set by tdnet_set_conv_pipeline (tuning hook): 0 = single-stage prefetch, 1 = two-stage ("deep") pipeline.
-static int g_conv_deep = 1;      // measured on MI355X: +4..6 % on every layer shape (profiles/r1_kernel_probe.txt)
+static int g_conv_deep = 1;      // measured on MI355X: +4..6 % on every layer shape (profiles/r01b_kernel_probe.txt)
+// Set by tdnet_set_conv_precision: 0 = fp32 MFMA (default), 1 = fp16-input MFMA with fp32 accumulate (td_conv_h.h).
+static int g_conv_fp16 = 0;
 
 // Choose the tile: 128-wide N when Cout allows, and the smaller M tile when 128x128 would leave CUs idle.
 // Cost model: the launch ends when the busiest CU has finished its share of the workgroups, so what matters is the

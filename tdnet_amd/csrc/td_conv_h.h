@@ -1,0 +1,216 @@
+// td_conv_h.h -- the same NHWC implicit-GEMM convolution on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate):
+// the "fp16 MFMA" mode of BASELINE.json config 5.  Activations stay fp32 in HBM (every other kernel is unchanged); the
+// gather converts them to fp16 (round-to-nearest-even) on the way into LDS, weights are packed as fp16 on the host.
+//
+// Per K step (BK = 64 channels of one tap) a 128x128 block issues 64 MFMAs of 32 cycles each instead of 256 of 64 cycles:
+// 16x the matrix rate, so the kernel lives or dies by how little else it does per step -- one ds_read_b128 per operand per
+// MFMA (LDS image [kq = 8 groups of 8 k][row][8 halfs], conflict free), 12 buffer loads + 16 packed converts + 8 LDS
+// writes per thread, all spread between the MFMAs of the two-stage pipeline of td_conv.h.
+//
+// Numerics: inputs are rounded to fp16 (2^-11 relative), products are exact in fp32, accumulation is fp32.  This mode does
+// NOT meet the 1e-3 logits gate of the fp32 path; bench.py reports its parity next to the number.
+#pragma once
+#include "td_conv.h"
+
+template <int BM, int BN>
+struct ConvLdsH {                                   // sizes in halfs
+    static constexpr int A_STRIDE = BM * 8 + 8;     // per k-group: BM rows x 8 halfs (+16 B pad, conflict-free ds_write_b128)
+    static constexpr int B_STRIDE = BN * 8;
+    static constexpr int A_HALFS = 8 * A_STRIDE;
+    static constexpr int B_HALFS = 8 * B_STRIDE;
+    static constexpr int BUF_HALFS = A_HALFS + B_HALFS;
+    static constexpr int BYTES = 2 * BUF_HALFS * 2;
+};
+
+TD_DEV f16x8 td_ld8h(const _Float16* p) { return *reinterpret_cast<const f16x8*>(p); }
+TD_DEV void td_st8h(_Float16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+TD_DEV f16x8 td_cvt8(f32x4 lo, f32x4 hi) {
+    f16x8 r;
+    r[0] = (_Float16)lo[0]; r[1] = (_Float16)lo[1]; r[2] = (_Float16)lo[2]; r[3] = (_Float16)lo[3];
+    r[4] = (_Float16)hi[0]; r[5] = (_Float16)hi[1]; r[6] = (_Float16)hi[2]; r[7] = (_Float16)hi[3];
+    return r;
+}
+
+// ConvArgs as td_conv.h, except: wp = packed fp16 weights [nsteps][8][CoutPad][8 halfs], nsteps = (Cin/64)*KS*KS.
+template <int BM, int BN, int WGM, int WGN, int KS>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
+    constexpr int AL = BM / 32, BL = BN / 32;          // 16-byte LDS slots per thread per step (A: 8 channels of one pixel)
+    static_assert((AL == 2 || AL == 4) && (BL == 2 || BL == 4), "staging slots are spread over the 4 k-groups");
+    using L = ConvLdsH<BM, BN>;
+    constexpr int NTAPS = KS * KS;
+    TD_DYN_LDS(smem);
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int a_row = tid >> 3, a_kq = tid & 7;         // slot i -> row a_row + 32 i, channels a_kq*8 .. +7 of the 64-channel chunk
+    int a_by[AL], a_bx[AL];
+    unsigned a_off[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int m = m0 + a_row + 32 * i;
+        const int oy = m / p.Wo, ox = m - oy * p.Wo;
+        a_by[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 28);
+        a_bx[i] = ox * p.stride - p.pad;
+        a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (unsigned)a_kq * 8u) * 4u;
+    }
+    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 4u);
+    const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
+    unsigned b_off[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
+        b_off[i] = (unsigned)(kq * p.CoutPad + n0 + n) * 16u;
+    }
+    const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
+
+    int l_step = 0, l_chunk = 0, l_tap = 0;
+    auto load_tile = [&](f32x4 (&ra)[2 * AL], f32x4 (&rb)[BL]) {
+        const int ky = l_tap / KS;
+        const int dy = ky * p.dil, dx = (l_tap - ky * KS) * p.dil;
+        const unsigned delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * 4u;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = ok ? a_off[i] + delta : TD_BUF_OOB;
+            ra[2 * i] = td_buf_ld4(in_buf, off, 0u);
+            ra[2 * i + 1] = td_buf_ld4(in_buf, ok ? off + 16u : TD_BUF_OOB, 0u);
+        }
+        const unsigned wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;
+#pragma unroll
+        for (int i = 0; i < BL; ++i) rb[i] = td_buf_ld4(w_buf, b_off[i], wsoff);
+        ++l_step;
+        if (++l_tap == NTAPS) { l_tap = 0; ++l_chunk; }
+    };
+    auto store_a = [&](int buf, int i, const f32x4 (&ra)[2 * AL]) {
+        td_st8h(lds + buf * L::BUF_HALFS + a_kq * L::A_STRIDE + (a_row + 32 * i) * 8, td_cvt8(ra[2 * i], ra[2 * i + 1]));
+    };
+    auto store_b = [&](int buf, int i, const f32x4 (&rb)[BL]) {
+        const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
+        *reinterpret_cast<f32x4*>(lds + buf * L::BUF_HALFS + L::A_HALFS + kq * L::B_STRIDE + n * 8) = rb[i];   // already fp16 bits
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one K step = 4 MFMA k-steps of 16; k-step g uses LDS groups 2g (lanes 0-31) and 2g+1 (lanes 32-63)
+    auto compute = [&](int buf, const f32x4 (&sa)[2 * AL], const f32x4 (&sb)[BL]) {
+        const _Float16* As = lds + buf * L::BUF_HALFS + (wm * WM + l31) * 8;
+        const _Float16* Bs = lds + buf * L::BUF_HALFS + L::A_HALFS + (wn * WN + l31) * 8;
+        f16x8 af[2][MT], bf[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = td_ld8h(As + half * L::A_STRIDE + i * 256);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[0][j] = td_ld8h(Bs + half * L::B_STRIDE + j * 256);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[(g + 1) & 1][i] = td_ld8h(As + (2 * g + 2 + half) * L::A_STRIDE + i * 256);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[(g + 1) & 1][j] = td_ld8h(Bs + (2 * g + 2 + half) * L::B_STRIDE + j * 256);
+            }
+#pragma unroll
+            for (int i = 0; i < AL; ++i) if (i * (4 / AL) == g) store_a(buf ^ 1, i, sa);
+#pragma unroll
+            for (int i = 0; i < BL; ++i) if (i * (4 / BL) == g) store_b(buf ^ 1, i, sb);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = td_mfma32_f16(af[g & 1][i], bf[g & 1][j], acc[i][j]);
+        }
+    };
+
+    // two-stage pipeline, branch free (see td_conv.h): tile s+2 in flight, tile s+1 written to LDS under the MFMAs of tile s
+    f32x4 ra[2 * AL], rb[BL], ra2[2 * AL], rb2[BL];
+    load_tile(ra, rb);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) store_a(0, i, ra);
+#pragma unroll
+    for (int i = 0; i < BL; ++i) store_b(0, i, rb);
+    load_tile(ra, rb);
+    __syncthreads();
+    for (int step = 0; step < p.nsteps; step += 2) {
+        load_tile(ra2, rb2);
+        compute(0, ra, rb);
+        __syncthreads();
+        if (step + 1 >= p.nsteps) break;
+        load_tile(ra, rb);
+        compute(1, ra2, rb2);
+        __syncthreads();
+    }
+
+    const int nb = n0 + wn * WN + l31 * NT;
+    float bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = (nb + j < p.Cout) ? p.bias[nb + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            const size_t o = (size_t)m * p.Cout + nb;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nb + j >= p.Cout) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (p.resid) v += p.resid[o + j];
+                if (p.act == 1) v = v > 0.f ? v : 0.f;
+                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
+                p.out[o + j] = v;
+            }
+        }
+    }
+}
+
+static inline int conv_nsteps_h(int Cin, int KS) { return (Cin / 64) * KS * KS; }
+
+// fp16 packing: [step][kq][slot][8 halfs]; slot -> output channel exactly as conv_pack_weights, k = chunk*64 + kq*8 + e.
+static inline void conv_pack_weights_h(const float* w, int Cout, int Cin, int KS, ConvTile tile, _Float16* dst) {
+    const ConvTileDims d = conv_tile_dims(tile);
+    const int WN = d.BN / d.WGN, NT = WN / 32;
+    const int CoutPad = conv_cout_pad(Cout, tile);
+    const int nsteps = conv_nsteps_h(Cin, KS), ntaps = KS * KS;
+    for (int step = 0; step < nsteps; ++step)
+        for (int kq = 0; kq < 8; ++kq)
+            for (int slot = 0; slot < CoutPad; ++slot) {
+                const int tn = slot / d.BN, within = slot % d.BN, wn = within / WN, w2 = within % WN;
+                const int nt = w2 / 32, j = w2 % 32;
+                const int n = tn * d.BN + wn * WN + j * NT + nt;
+                _Float16* o = dst + (((size_t)step * 8 + kq) * CoutPad + slot) * 8;
+                const int chunk = step / ntaps, tap = step % ntaps;
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = chunk * 64 + kq * 8 + e;
+                    o[e] = (_Float16)(n < Cout ? w[((size_t)n * Cin + ci) * ntaps + tap] : 0.f);
+                }
+            }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static inline void conv_launch_h_t(const ConvArgs& a, int KS, hipStream_t s) {
+    const int grid = ((a.M + BM - 1) / BM) * a.tiles_n;
+    const int lds = ConvLdsH<BM, BN>::BYTES;
+    if (KS == 3) TD_LAUNCH((k_conv_igemm_h<BM, BN, WGM, WGN, 3>), dim3(grid), dim3(256), lds, s, a);
+    else TD_LAUNCH((k_conv_igemm_h<BM, BN, WGM, WGN, 1>), dim3(grid), dim3(256), lds, s, a);
+}
+static inline void conv_launch_h(ConvArgs a, ConvTile tile, int KS, hipStream_t s) {
+    const ConvTileDims d = conv_tile_dims(tile);
+    a.tiles_n = a.CoutPad / d.BN;
+    if (d.BM == 128 && d.BN == 128) conv_launch_h_t<128, 128, 2, 2>(a, KS, s);
+    else if (d.BM == 64) conv_launch_h_t<64, 128, 2, 2>(a, KS, s);
+    else conv_launch_h_t<128, 64, 4, 1>(a, KS, s);
+}

@@ -11,6 +11,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define TD_KERNEL __global__
 #define TD_DEV __device__ __forceinline__
@@ -39,6 +40,9 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
 
 // compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
 #define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+// fp16 inputs, fp32 accumulate: D(32x32) += A(32x16) * B(16x32); lane l supplies 8 consecutive k of row/column l&31 (k-group l>>5)
+TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 TD_DEV float td_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 TD_DEV float td_exp2(float x) { return exp2f(x); }

@@ -9,6 +9,7 @@
 #include "../../include/tdnet.h"
 #include "td_device.h"
 #include "td_conv.h"
+#include "td_conv_h.h"
 #include "td_attn.h"
 #include "td_misc.h"
 
@@ -90,6 +91,7 @@ static int key_size(int n) { return (n - 1) / 4 + 1; }
 struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
+    bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
     ConvTile tile = CT_128x128;
     int CoutPad = 0, nsteps = 0;
     float* d_wp = nullptr;
@@ -101,17 +103,26 @@ static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2
 
 // Upload a BN-folded OIHW weight + bias as a ConvLayer for an output of M pixels.
 static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& b, int Cout, int Cin, int KS,
-                           int stride, int dil, int act, bool stem, long M) {
+                           int stride, int dil, int act, bool stem, long M, int forced_tile = -1) {
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
-    L.tile = conv_pick_tile((int)M, Cout);
+    L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)M, Cout);
     L.CoutPad = conv_cout_pad(Cout, L.tile);
-    L.nsteps = conv_nsteps(Cin, KS, stem);
-    std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
-    conv_pack_weights(w.data(), Cout, Cin, KS, stem, L.tile, packed.data());
-    TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(float)));
-    TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    L.h16 = g_conv_fp16 && !stem && Cin % 64 == 0;
+    if (L.h16) {
+        L.nsteps = conv_nsteps_h(Cin, KS);
+        std::vector<_Float16> packed((size_t)L.nsteps * 8 * L.CoutPad * 8);
+        conv_pack_weights_h(w.data(), Cout, Cin, KS, L.tile, packed.data());
+        TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(_Float16)));
+        TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    } else {
+        L.nsteps = conv_nsteps(Cin, KS, stem);
+        std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
+        conv_pack_weights(w.data(), Cout, Cin, KS, stem, L.tile, packed.data());
+        TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(float)));
+        TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     std::vector<float> bb(Cout, 0.f);
     if (!b.empty()) bb = b;
     TD_HIP(hipMalloc((void**)&L.d_bias, Cout * sizeof(float)));
@@ -553,7 +564,8 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
-    conv_launch(a, L.tile, L.KS, L.stem, s);
+    if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
+    else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;
     if (Wo_out) *Wo_out = Wo;
@@ -830,6 +842,9 @@ static double frame_flops(const tdnet* n) {
 }
 extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->finalized ? n->flops_frame : -1.0; }
 
+// Precision mode for handles finalized AFTER the call: 0 = fp32 MFMA (default, meets the 1e-3 logits gate),
+// 1 = fp16-input MFMA with fp32 accumulation for every conv except the stem (BASELINE config 5 "fp16 MFMA").
+extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; return 0; }
 // Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
 extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }
 
@@ -888,15 +903,7 @@ extern "C" int tdnet_op_conv2d_tile(const float* in, int H, int W, int Cin, cons
     ConvLayer L;
     std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
     if (bias_host) b.assign(bias_host, bias_host + Cout);
-    if (Cin % 32) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
-    L.Cin = Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = false; L.pad = dil * (KS / 2);
-    L.tile = (ConvTile)tile; L.CoutPad = conv_cout_pad(Cout, L.tile); L.nsteps = conv_nsteps(Cin, KS, false);
-    std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
-    conv_pack_weights(w.data(), Cout, Cin, KS, false, L.tile, packed.data());
-    if (upload(&L.d_wp, packed)) return -1;
-    std::vector<float> bb(Cout, 0.f);
-    if (!b.empty()) bb = b;
-    if (upload(&L.d_bias, bb)) return -1;
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, 0, tile)) return -1;
     run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
@@ -1010,17 +1017,14 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     if ((KS != 1 && KS != 3) || Cin % 32 || tile < 0 || tile >= CT_COUNT) { td_fail("tdnet_bench_conv: bad arguments"); return -1.0; }
     hipStream_t s = (hipStream_t)stream;
     ConvLayer L;
-    L.Cin = Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = 1; L.stem = false; L.pad = dil * (KS / 2);
-    L.tile = (ConvTile)tile; L.CoutPad = conv_cout_pad(Cout, L.tile); L.nsteps = conv_nsteps(Cin, KS, false);
     std::vector<float> w((size_t)Cout * Cin * KS * KS), x((size_t)H * W * Cin), b(Cout, 0.1f);
     unsigned st = 12345u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
     for (auto& v : w) v = rnd() * 0.05f;
     for (auto& v : x) v = rnd();
-    std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
-    conv_pack_weights(w.data(), Cout, Cin, KS, false, L.tile, packed.data());
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, 0, tile)) return -1.0;
     float *din = nullptr, *dout = nullptr;
-    if (upload(&L.d_wp, packed) || upload(&L.d_bias, b) || upload(&din, x)) return -1.0;
+    if (upload(&din, x)) return -1.0;
     const int Ho = out_size(H, KS, stride, dil, L.pad), Wo = out_size(W, KS, stride, dil, L.pad);
     if (dev_alloc(&dout, (size_t)Ho * Wo * Cout)) return -1.0;
     hipEvent_t e0, e1;

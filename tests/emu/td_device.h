@@ -21,6 +21,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct dim3 {
     unsigned x, y, z;
@@ -68,6 +69,7 @@ extern thread_local Idx g_blockIdx, g_gridDim, g_blockDim;
 extern thread_local char* g_lds;
 void syncthreads();
 f32x16 mfma32(float a, float b, f32x16 c);
+f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c);
 float shfl_xor(float v, int mask);
 void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
 }  // namespace tdemu
@@ -101,6 +103,7 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
 }
 
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }
+TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return tdemu::mfma32_f16(a, b, c); }
 TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
 TD_DEV float td_exp2(float x) { return exp2f(x); }
 TD_DEV int td_lane() { return threadIdx.x & 63; }

@@ -64,6 +64,7 @@ static constexpr int MAX_THREADS = 512;
 
 struct WaveCtx {
     float a[2][64], b[2][64];
+    float a8[2][64][8], b8[2][64][8];           // fp16 MFMA operands (widened)
     unsigned count = 0, gen = 0;
 };
 struct Worker {
@@ -132,6 +133,24 @@ f32x16 mfma32(float a, float b, f32x16 c) {
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         c[r] = fmaf(w.a[slot][row + 32], w.b[slot][col + 32], fmaf(w.a[slot][row], w.b[slot][col], c[r]));
+    }
+    return c;
+}
+// v_mfma_f32_32x32x16_f16: lane l holds 8 consecutive k (k-group l>>5) of row/column l&31; products are exact in fp32
+f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c) {
+    Fiber* f = cur;
+    WaveCtx& w = W->waves[f->tidx.x >> 6];
+    const int lane = f->tidx.x & 63, slot = f->seq & 1;
+    f->seq++;
+    for (int e = 0; e < 8; ++e) { w.a8[slot][lane][e] = (float)a[e]; w.b8[slot][lane][e] = (float)b[e]; }
+    wave_barrier(w);
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float s = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) s += w.a8[slot][row + 32 * h][e] * w.b8[slot][col + 32 * h][e];
+        c[r] = s;
     }
     return c;
 }

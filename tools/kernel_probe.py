@@ -21,13 +21,22 @@ SHAPES = [("layer4 512->512 d4", 128, 256, 512, 512, 3, 1, 4), ("layer4 256->512
           ("layer1 64->64", 256, 512, 64, 64, 3, 1, 1), ("head 512->128", 128, 256, 512, 128, 3, 1, 1),
           ("enc_v 1x1 512->512", 128, 256, 512, 512, 1, 1, 1), ("ds 1x1 256->512", 128, 256, 256, 512, 1, 1, 1)]
 names = ["128x128", "64x128", "128x64", "128x128D", "64x128D", "128x64D"]
-for (nm, H, W, Cin, Cout, KS, st, dil) in SHAPES:
+# quantisation probe: the same layer4 conv at 1, 2, 4, 8 workgroup rounds (M = 16k .. 131k pixels)
+for Hq in (64, 128, 256, 512):
+    gf = 2.0 * Hq * 256 * 512 * 512 * 9 / 1e9
+    ms = lib.tdnet_bench_conv(Hq, 256, 512, 512, 3, 1, 4, 3, 10, None)
+    print("layer4 512->512 d4 at %dx256 (%d blocks): %.3f ms %.1f TF" % (Hq, Hq * 256 // 128 * 4, ms, gf / ms), flush=True)
+for prec in (0, 1):
+  lib.tdnet_set_conv_precision(prec)
+  print("---- conv precision:", "fp16-input MFMA" if prec else "fp32 MFMA", flush=True)
+  for (nm, H, W, Cin, Cout, KS, st, dil) in SHAPES:
     Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
     gf = 2.0 * Ho * Wo * Cout * Cin * KS * KS / 1e9
     row = {}
-    for t in range(6):
+    for t in (range(6) if prec == 0 else (3, 4, 5)):
         if Cout <= 64 and t not in (2, 5):
             continue
         ms = lib.tdnet_bench_conv(H, W, Cin, Cout, KS, st, dil, t, 20, None)
         row[names[t]] = "%.3f ms %.1f TF" % (ms, gf / ms)
     print("%-22s %6.1f GFLOP  " % (nm, gf) + "  ".join("%s: %s" % kv for kv in row.items()), flush=True)
+lib.tdnet_set_conv_precision(0)
