@@ -80,6 +80,9 @@ int tdnet_set_conv_pipeline(int deep);
 /* Precision mode (process-wide, handles finalized after the call): 0 = fp32 MFMA, the default and the only mode that
  * meets the 1e-3 logits gate; 1 = fp16-input MFMA with fp32 accumulation for every conv but the stem (BASELINE config 5). */
 int tdnet_set_conv_precision(int fp16);
+/* Tuning hook: start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups, to de-phase the two
+ * workgroups that share a CU.                                                                                       */
+int tdnet_set_conv_stagger(int units);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */

@@ -42,6 +42,7 @@ struct ConvArgs {
     int nsteps;           // (Cin/32)*KS*KS, STEM: ceil(KS*KS/8)
     int act;              // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
     int tiles_n;          // CoutPad / BN
+    int stagger;          // start delay of every odd group of 256 workgroups, in units of 512 cycles (see k_conv_igemm)
 };
 
 // bijective "block b runs on XCD b%8" -> contiguous range of tiles per XCD (cdna_hip_programming.md T1)
@@ -81,6 +82,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // De-phase the workgroups that share a CU.  All workgroups of a launch start together and run identical K loops, so
+    // two co-resident groups reach their barriers and load bursts at the same time and the MFMA pipe idles in both at once;
+    // the probe shows the first "round" of a launch running 15 % slower than later, naturally staggered rounds.  Groups
+    // b and b+256 land on the same CU in the first round (XCD = b%8, round-robin over its 32 CUs), so every odd group of
+    // 256 sleeps about half a K step (p.stagger x 512 cycles) once; the offset then persists (identical periods).
+    if ((blockIdx.x >> 8) & 1)
+        for (int i = 0; i < p.stagger; ++i) TD_SLEEP(8);               // 8 x 64 = 512 cycles per unit
 
     // ---- per-thread gather geometry: slot i -> row (tid>>3) + 32 i, k-group tid&7 ------------------------------
     const int a_row = tid >> 3, a_kq = tid & 7;
@@ -291,6 +300,8 @@ static inline ConvTileDims conv_tile_dims(ConvTile t) {
 static int g_conv_deep = 1;      // measured on MI355X: +4..6 % on every layer shape (profiles/r01b_kernel_probe.txt)
 // Set by tdnet_set_conv_precision: 0 = fp32 MFMA (default), 1 = fp16-input MFMA with fp32 accumulate (td_conv_h.h).
 static int g_conv_fp16 = 0;
+// Set by tdnet_set_conv_stagger: start delay (x512 cycles) of the second workgroup on each CU; 0 = off.
+static int g_conv_stagger = 0;
 
 // Choose the tile: 128-wide N when Cout allows, and the smaller M tile when 128x128 would leave CUs idle.
 // Cost model: the launch ends when the busiest CU has finished its share of the workgroups, so what matters is the

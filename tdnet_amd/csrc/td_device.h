@@ -38,6 +38,9 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff_bytes, soff_bytes, 0));
 }
 
+// s_sleep: park the wave for ~64*n cycles (n <= 127); used to de-phase co-resident workgroups
+#define TD_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+
 // compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
 #define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 

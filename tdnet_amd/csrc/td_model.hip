@@ -562,7 +562,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0;
+    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = g_conv_stagger;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
@@ -845,6 +845,7 @@ extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->final
 // Precision mode for handles finalized AFTER the call: 0 = fp32 MFMA (default, meets the 1e-3 logits gate),
 // 1 = fp16-input MFMA with fp32 accumulation for every conv except the stem (BASELINE config 5 "fp16 MFMA").
 extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; return 0; }
+extern "C" int tdnet_set_conv_stagger(int units) { g_conv_stagger = units < 0 ? 0 : units > 64 ? 64 : units; return 0; }
 // Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
 extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }
 

@@ -89,6 +89,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
     tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds))
 
 #define TD_SCHED_GROUP(mask, n) ((void)0)
+#define TD_SLEEP(n) ((void)0)
 
 struct TdBuf { const char* p; unsigned bytes; };
 #define TD_BUF_OOB 0x80000000u
