@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch (default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="steady-state frames timed on the CPU oracle")
+    ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4, 2 everywhere (default: library default)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16-input MFMA convs, fp32 accumulate "
                          "(BASELINE config 5); parity vs the fp32 CPU path is reported, not gated")
@@ -75,6 +76,9 @@ def main():
     if args.precision == "fp16":
         from tdnet_amd import _capi
         _capi.lib().tdnet_set_conv_precision(1)
+    if args.winograd is not None:
+        from tdnet_amd import _capi
+        _capi.lib().tdnet_set_conv_winograd(args.winograd)
     if args.backbone is None:
         args.backbone = "resnet101" if args.model == "psp" else "resnet18"
     spec = arch.model_spec(args.model, 19, args.backbone)

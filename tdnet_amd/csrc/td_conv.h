@@ -43,6 +43,7 @@ struct ConvArgs {
     int act;              // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
     int tiles_n;          // CoutPad / BN
     int stagger;          // start delay of every odd group of 256 workgroups, in units of 512 cycles (see k_conv_igemm)
+    int nbatch;           // > 1: batched 1x1 GEMMs (Winograd), see k_conv_igemm
 };
 
 // bijective "block b runs on XCD b%8" -> contiguous range of tiles per XCD (cdna_hip_programming.md T1)
@@ -79,7 +80,18 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
+    // Batched launch (Winograd: 16 independent GEMMs, td_wino.h): the grid is nbatch consecutive groups of workgroups,
+    // batch b reads in + b*M*Cin, the weights of batch b and writes out + b*M*Cout.  nbatch <= 1: plain conv.
+    int bid_in_batch = blockIdx.x, nblk = gridDim.x;
+    if (p.nbatch > 1) {
+        nblk = gridDim.x / p.nbatch;
+        const int b = blockIdx.x / nblk;
+        bid_in_batch = blockIdx.x - b * nblk;
+        p.in += (size_t)b * p.M * p.Cin;
+        p.out += (size_t)b * p.M * p.Cout;
+        p.wp += (size_t)b * p.nsteps * 8 * p.CoutPad * 4;
+    }
+    const int lin = td_xcd_remap(bid_in_batch, nblk);
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -363,7 +375,7 @@ static inline void conv_pack_weights(const float* w, int Cout, int Cin, int KS, 
 
 template <int BM, int BN, int WGM, int WGN, bool DEEP>
 static inline void conv_launch_t(const ConvArgs& a, int KS, bool stem, hipStream_t s) {
-    const int grid = ((a.M + BM - 1) / BM) * a.tiles_n;
+    const int grid = ((a.M + BM - 1) / BM) * a.tiles_n * (a.nbatch > 1 ? a.nbatch : 1);
     const int lds = ConvLds<BM, BN>::BYTES;
     if (stem && KS == 7) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 7, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
     else if (stem) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, true, DEEP>), dim3(grid), dim3(256), lds, s, a);

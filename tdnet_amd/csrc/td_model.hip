@@ -10,6 +10,7 @@
 #include "td_device.h"
 #include "td_conv.h"
 #include "td_conv_h.h"
+#include "td_wino.h"
 #include "td_attn.h"
 #include "td_misc.h"
 
@@ -92,12 +93,17 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
+    bool wino = false;                                                 // Winograd F(2x2,3x3): d_wp = 16 packed 1x1 weight sets (td_wino.h)
+    float* d_zero = nullptr;                                           // zero bias for the batched GEMM pass
     ConvTile tile = CT_128x128;
     int CoutPad = 0, nsteps = 0;
     float* d_wp = nullptr;
     float* d_bias = nullptr;
     double flops_per_pixel() const { return 2.0 * Cout * (stem ? 3.0 * KS * KS : (double)Cin * KS * KS); }
 };
+
+// 0 = direct convs only, 1 = Winograd for stride-1 3x3 convs with Cin, Cout >= 256 (layers 3-4), 2 = every stride-1 3x3 conv
+static int g_conv_wino = 0;
 
 static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2 * pad - dil * (KS - 1) - 1) / stride + 1; }
 
@@ -107,6 +113,28 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
+    L.wino = g_conv_wino && !g_conv_fp16 && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
+             (g_conv_wino >= 2 || (Cin >= 256 && Cout >= 256));
+    if (L.wino) {
+        // 16 batched [T x Cin] x [Cin x Cout] GEMMs: 16 * T = 4 * M rows in total -> pick the tile for that many workgroups
+        L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)std::min<long>(4 * M, 1 << 30), Cout);
+        L.CoutPad = conv_cout_pad(Cout, L.tile);
+        L.nsteps = conv_nsteps(Cin, 1, false);
+        std::vector<std::vector<float>> U;
+        wino_transform_weights(w.data(), Cout, Cin, U);
+        const size_t per = (size_t)L.nsteps * 8 * L.CoutPad * 4;
+        std::vector<float> packed(16 * per);
+        for (int b16 = 0; b16 < 16; ++b16) conv_pack_weights(U[b16].data(), Cout, Cin, 1, false, L.tile, packed.data() + b16 * per);
+        TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(float)));
+        TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> bb(Cout, 0.f), zz(Cout, 0.f);
+        if (!b.empty()) bb = b;
+        TD_HIP(hipMalloc((void**)&L.d_bias, Cout * sizeof(float)));
+        TD_HIP(hipMemcpy(L.d_bias, bb.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
+        TD_HIP(hipMalloc((void**)&L.d_zero, Cout * sizeof(float)));
+        TD_HIP(hipMemcpy(L.d_zero, zz.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
     L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)M, Cout);
     L.CoutPad = conv_cout_pad(Cout, L.tile);
     L.h16 = g_conv_fp16 && !stem && Cin % 64 == 0;
@@ -132,7 +160,8 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
 static void free_conv_layer(ConvLayer& L) {
     if (L.d_wp) hipFree(L.d_wp);
     if (L.d_bias) hipFree(L.d_bias);
-    L.d_wp = L.d_bias = nullptr;
+    if (L.d_zero) hipFree(L.d_zero);
+    L.d_wp = L.d_bias = L.d_zero = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -171,6 +200,8 @@ struct tdnet {
     float *vp = nullptr, *chain_a = nullptr, *chain_b = nullptr, *feat = nullptr;
     float *ln_part = nullptr, *ln_mean = nullptr, *ln_rstd = nullptr, *ln = nullptr;
     float *headmid = nullptr, *lowres = nullptr, *stage_tmp = nullptr, *logits_tmp = nullptr;
+    float *wino_v = nullptr, *wino_m = nullptr;                        // Winograd workspaces [16][T][Cin] / [16][T][Cout]
+    size_t wino_v_floats = 0, wino_m_floats = 0;
     size_t stage_tmp_floats = 0;
     std::vector<CacheSlot> slots;
     std::vector<int> fifo;                                             // slot ids, oldest first
@@ -318,7 +349,7 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     for (auto& p : n->paths) free_path(p);
     for (float* q : {n->img4, n->s1, n->s1b, n->bx, n->bt, n->br, n->bu, n->rowpart, n->pooled, n->ppmfeat, n->z, n->v_cur, n->q1, n->q_cur,
                      n->k1, n->vp, n->chain_a, n->chain_b, n->feat, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, n->headmid,
-                     n->lowres, n->stage_tmp, n->logits_tmp})
+                     n->lowres, n->stage_tmp, n->logits_tmp, n->wino_v, n->wino_m})
         if (q) hipFree(q);
     for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
     for (auto& r : n->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
@@ -401,6 +432,27 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
+    {   // Winograd workspaces: the largest [16][T][C] over the layers that use it (all paths share them; one stream)
+        size_t vmax = 0, mmax = 0;
+        auto upd = [&](const ConvLayer& L, int H, int W) {
+            if (!L.wino) return;
+            const size_t T = (size_t)wino_tiles(H, W, L.dil);
+            vmax = std::max(vmax, 16 * T * L.Cin); mmax = std::max(mmax, 16 * T * L.Cout);
+        };
+        const PathLayers& L0 = n->paths[0];
+        if (n->deep) { upd(L0.stem2, n->H1, n->W1); upd(L0.stem3, n->H1, n->W1); }
+        int ch = n->H2, cw = n->W2;
+        for (size_t i = 0; i < L0.blocks.size(); ++i) {
+            const BlockSpec& bs = n->bspec[i];
+            const int oh = out_size(ch, 3, bs.stride, bs.dil1, bs.dil1), ow = out_size(cw, 3, bs.stride, bs.dil1, bs.dil1);
+            if (bs.bott) upd(L0.blocks[i].c2, ch, cw);
+            else { upd(L0.blocks[i].c1, ch, cw); upd(L0.blocks[i].c2, oh, ow); }
+            ch = oh; cw = ow;
+        }
+        upd(L0.head3, n->h, n->w);
+        n->wino_v_floats = vmax; n->wino_m_floats = mmax;
+        if (vmax && (dev_alloc(&n->wino_v, vmax) || dev_alloc(&n->wino_m, mmax))) return -1;
+    }
     n->slots.resize(n->FIFO + 1);
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -559,10 +611,40 @@ static void prof_end(tdnet* n, hipStream_t s) {
 static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
                     int* Ho_out = nullptr, int* Wo_out = nullptr) {
     const int Ho = out_size(H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(W, L.KS, L.stride, L.dil, L.pad);
+    if (L.wino) {
+        const int TY = wino_tiles_1d(H, L.dil), TX = wino_tiles_1d(W, L.dil);
+        const long T = (long)L.dil * L.dil * TY * TX;
+        float *V = nullptr, *Mb = nullptr;
+        const bool own = n == nullptr || n->wino_v_floats < (size_t)16 * T * L.Cin || n->wino_m_floats < (size_t)16 * T * L.Cout;
+        if (own) {
+            if (n) return td_fail("internal: Winograd workspace too small");
+            if (dev_alloc(&V, (size_t)16 * T * L.Cin) || dev_alloc(&Mb, (size_t)16 * T * L.Cout)) return -1;
+        } else { V = n->wino_v; Mb = n->wino_m; }
+        WinoArgs wa;
+        wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
+        wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act;
+        prof_begin(n, 2, false, 0, s);
+        TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        prof_end(n, s);
+        ConvArgs g;
+        g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
+        g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
+        g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = 16;
+        prof_begin(n, 0, L.tile == CT_128x128 || L.tile == CT_128x128_DEEP, 2.0 * 16 * T * (double)L.Cin * L.Cout, s);
+        conv_launch(g, L.tile, 1, false, s);
+        prof_end(n, s);
+        prof_begin(n, 2, false, 0, s);
+        TD_LAUNCH(k_wino_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        prof_end(n, s);
+        if (own) { TD_HIP(hipStreamSynchronize(s)); hipFree(V); hipFree(Mb); }
+        if (Ho_out) *Ho_out = H;
+        if (Wo_out) *Wo_out = W;
+        return 0;
+    }
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = g_conv_stagger;
+    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = g_conv_stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
@@ -845,6 +927,8 @@ extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->final
 // Precision mode for handles finalized AFTER the call: 0 = fp32 MFMA (default, meets the 1e-3 logits gate),
 // 1 = fp16-input MFMA with fp32 accumulation for every conv except the stem (BASELINE config 5 "fp16 MFMA").
 extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; return 0; }
+// 0 = direct convolutions (default), 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (layers 3-4), 2 = for every stride-1 3x3
+extern "C" int tdnet_set_conv_winograd(int mode) { g_conv_wino = mode < 0 ? 0 : mode > 2 ? 2 : mode; return 0; }
 extern "C" int tdnet_set_conv_stagger(int units) { g_conv_stagger = units < 0 ? 0 : units > 64 ? 64 : units; return 0; }
 // Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
 extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }
@@ -1030,15 +1114,24 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     if (dev_alloc(&dout, (size_t)Ho * Wo * Cout)) return -1.0;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) run_conv(nullptr, L, din, H, W, nullptr, dout, s);
+    tdnet tmp;                                                        // only carries the Winograd workspace for run_conv
+    if (L.wino) {
+        const size_t T = (size_t)wino_tiles(H, W, dil);
+        tmp.wino_v_floats = 16 * T * Cin; tmp.wino_m_floats = 16 * T * Cout;
+        if (dev_alloc(&tmp.wino_v, tmp.wino_v_floats) || dev_alloc(&tmp.wino_m, tmp.wino_m_floats)) return -1.0;
+    }
+    tdnet* ws = L.wino ? &tmp : nullptr;
+    for (int i = 0; i < 2; ++i) run_conv(ws, L, din, H, W, nullptr, dout, s);
     hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i) run_conv(nullptr, L, din, H, W, nullptr, dout, s);
+    for (int i = 0; i < iters; ++i) run_conv(ws, L, din, H, W, nullptr, dout, s);
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(din); hipFree(dout);
+    if (tmp.wino_v) hipFree(tmp.wino_v);
+    if (tmp.wino_m) hipFree(tmp.wino_m);
     free_conv_layer(L);
     return ms / iters;
 }

@@ -103,3 +103,29 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
     e.forward_labels(x, 0, lab)
     assert (lab == out[0].argmax(0)).all()
     e.close()
+
+
+def test_winograd_conv_and_pipeline(lib, golden_dir):
+    """Winograd F(2x2,3x3) mode (td_wino.h): every dilation, ragged sizes, then the td4 pipeline with layers 3-4 on it."""
+    lib.tdnet_set_conv_winograd(2)
+    try:
+        for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
+                  (5, 9, 256, 512, 3, 1, 16, 2, False), (40, 40, 32, 128, 3, 1, 1, 1, False), (1, 1, 32, 32, 3, 1, 1, 0, False),
+                  (7, 7, 32, 64, 3, 1, 3, 1, True)]:
+            opcheck.conv(lib, MEM, *a)
+        opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False)          # stride 2 is not eligible: direct path
+        lib.tdnet_set_conv_winograd(1)
+        name, bb, H, W = "td4", "resnet18", 33, 65
+        spec = arch.model_spec(name, 19, bb)
+        h, w = arch.feat_size(H), arch.feat_size(W)
+        g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+        e = Engine(4, 18, 19, H, W, 0, lib=lib)
+        e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+        for t, x in enumerate(weights.synth_video(H, W, 5, seed=1)):
+            out = np.full((1, 19, H, W), 7e7, np.float32)
+            e.forward(x, t % 4, out)
+            assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 1e-4 * np.abs(g["f%d_c4" % t]).max()
+            assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
+        e.close()
+    finally:
+        lib.tdnet_set_conv_winograd(0)

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""GPU-box probe: direct vs Winograd F(2x2,3x3) time per layer shape (same launch path as the model)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tdnet_amd import _capi
+lib = _capi.lib(); torch.zeros(1, device="cuda")
+SHAPES = [("layer4 512->512 d4", 128, 256, 512, 512, 4), ("layer4 512->512 d8", 128, 256, 512, 512, 8), ("layer4 256->512 d4", 128, 256, 256, 512, 4),
+          ("layer3 256->256 d2", 128, 256, 256, 256, 2), ("layer3.0 128->256 d1", 128, 256, 128, 256, 1), ("head 512->128", 128, 256, 512, 128, 1),
+          ("layer2 128->128", 128, 256, 128, 128, 1), ("layer1 64->64", 256, 512, 64, 64, 1), ("native l4 512->512 d4", 97, 193, 512, 512, 4)]
+for (nm, H, W, Cin, Cout, d) in SHAPES:
+    gf = 2.0 * H * W * Cout * Cin * 9 / 1e9
+    out = []
+    for mode in (0, 2):
+        lib.tdnet_set_conv_winograd(mode)
+        t = 5 if Cout <= 64 else 3
+        ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 3, 1, d, t, 20, None) for _ in range(2))
+        out.append("%s %.3f ms (%.0f TF eff.)" % ("wino" if mode else "direct", ms, gf / ms))
+    print("%-24s %6.1f GFLOP  %s" % (nm, gf, "   ".join(out)), flush=True)
+lib.tdnet_set_conv_winograd(0)
