@@ -148,9 +148,18 @@ def main():
         dom_ms, dom_fl, dom_n = acc[3]
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2,3> (3x3 dilated conv, fp32 MFMA)",
-                               "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic_from_profiles(),
+            from tdnet_amd import _capi
+            cfgbits = _capi.lib().tdnet_get_conv_config()
+            if cfgbits & 2:
+                kname, peak = "k_conv_igemm_h<128,128,2,2,3> (3x3 dilated conv, fp16-input MFMA, fp32 accumulate)", 2500.0
+            elif (cfgbits >> 2) & 3:
+                kname, peak = ("k_conv_igemm<128,128,2,2,1> x16 (batched GEMM of the Winograd F(2x2,3x3) convs of layers 3-4 + head, "
+                               "fp32 MFMA; FLOP = executed GEMM FLOP, 2.25x fewer than the direct conv's)"), PEAK_FP32_MFMA_TFLOPS
+            else:
+                kname, peak = "k_conv_igemm<128,128,2,2,3> (3x3 dilated conv, fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS
+            res["roofline"] = {"bound": "mfma", "kernel": kname,
+                               "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(achieved / peak, 4), "traffic": traffic_from_profiles(),
                                "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nprof,
                                "gflop_per_launch": round(dom_fl / dom_n / 1e9, 2)}
         res["breakdown_ms_per_frame"] = {"conv_gemm": round(acc[0][0] / nprof, 3), "attention": round(acc[1][0] / nprof, 3),

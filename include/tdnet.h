@@ -83,9 +83,12 @@ int tdnet_set_conv_precision(int fp16);
 /* Tuning hook: start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups, to de-phase the two
  * workgroups that share a CU.                                                                                       */
 int tdnet_set_conv_stagger(int units);
-/* Conv algorithm (process-wide, handles finalized after the call): 0 = direct implicit GEMM everywhere (default),
- * 1 = Winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 256 channels (ResNet layers 3-4), 2 = for every stride-1 3x3. */
+/* Conv algorithm (process-wide, handles finalized after the call): 0 = direct implicit GEMM everywhere,
+ * 1 (default) = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4 and the
+ * FCN head), 2 = for every stride-1 3x3.  All modes are fp32 and meet the 1e-3 logits gate.                              */
 int tdnet_set_conv_winograd(int mode);
+/* Current process-wide conv configuration: bit 0 two-stage pipeline, bit 1 fp16-input MFMA, bits 2-3 Winograd mode.   */
+int tdnet_get_conv_config(void);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */

@@ -102,8 +102,10 @@ struct ConvLayer {
     double flops_per_pixel() const { return 2.0 * Cout * (stem ? 3.0 * KS * KS : (double)Cin * KS * KS); }
 };
 
-// 0 = direct convs only, 1 = Winograd for stride-1 3x3 convs with Cin, Cout >= 256 (layers 3-4), 2 = every stride-1 3x3 conv
-static int g_conv_wino = 0;
+// 0 = direct convs only, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4
+// and the FCN head), 2 = every stride-1 3x3 conv.  Default 1: measured +20 % frames/s at 1024x2048, +23 % at 769x1537, with
+// logits as close to the fp32 CPU path as the direct kernels' (profiles/r01f_*).
+static int g_conv_wino = 1;
 
 static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2 * pad - dil * (KS - 1) - 1) / stride + 1; }
 
@@ -114,7 +116,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     L.pad = stem ? KS / 2 : dil * (KS / 2);
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
     L.wino = g_conv_wino && !g_conv_fp16 && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
-             (g_conv_wino >= 2 || (Cin >= 256 && Cout >= 256));
+             (g_conv_wino >= 2 || (Cin >= 256 && Cout >= 128));
     if (L.wino) {
         // 16 batched [T x Cin] x [Cin x Cout] GEMMs: 16 * T = 4 * M rows in total -> pick the tile for that many workgroups
         L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)std::min<long>(4 * M, 1 << 30), Cout);
@@ -181,7 +183,7 @@ struct PathLayers {
     int pid = 0;
 };
 struct CacheSlot { float* q = nullptr; float* k = nullptr; float* v = nullptr; };
-struct ProfRec { int family; bool dominant; hipEvent_t e0, e1; double flops; };
+struct ProfRec { int family; int dominant; hipEvent_t e0, e1; double flops; };   // dominant: 0 no, 1 direct 3x3 128x128, 2 Winograd batched GEMM
 
 struct tdnet {
     tdnet_cfg cfg;
@@ -210,6 +212,7 @@ struct tdnet {
     // cache-only work (V' GEMMs + the two cached-frame attention steps) runs on a side stream under the backbone
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool failed = false;                                              // a launch helper reported an error during the current forward
     bool prof = false;
     std::vector<ProfRec> recs;
     size_t nrec = 0;
@@ -427,11 +430,6 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->z, hw * ZC)) return -1;
     n->stage_tmp_floats = hw * ZC;
     if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass) || dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
-    if (psp) return 0;
-    if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
-    if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
-    if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
-    if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
     {   // Winograd workspaces: the largest [16][T][C] over the layers that use it (all paths share them; one stream)
         size_t vmax = 0, mmax = 0;
         auto upd = [&](const ConvLayer& L, int H, int W) {
@@ -453,6 +451,11 @@ static int alloc_workspace(tdnet* n) {
         n->wino_v_floats = vmax; n->wino_m_floats = mmax;
         if (vmax && (dev_alloc(&n->wino_v, vmax) || dev_alloc(&n->wino_m, mmax))) return -1;
     }
+    if (psp) return 0;
+    if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
+    if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
+    if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
+    if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
     n->slots.resize(n->FIFO + 1);
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -590,7 +593,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
 // ---------------------------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------------------------
-static void prof_begin(tdnet* n, int family, bool dominant, double flops, hipStream_t s) {
+static void prof_begin(tdnet* n, int family, int dominant, double flops, hipStream_t s) {
     if (!n || !n->prof) return;
     if (n->nrec == n->recs.size()) {
         ProfRec r;
@@ -617,7 +620,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         float *V = nullptr, *Mb = nullptr;
         const bool own = n == nullptr || n->wino_v_floats < (size_t)16 * T * L.Cin || n->wino_m_floats < (size_t)16 * T * L.Cout;
         if (own) {
-            if (n) return td_fail("internal: Winograd workspace too small");
+            if (n) { n->failed = true; return td_fail("internal: Winograd workspace too small"); }
             if (dev_alloc(&V, (size_t)16 * T * L.Cin) || dev_alloc(&Mb, (size_t)16 * T * L.Cout)) return -1;
         } else { V = n->wino_v; Mb = n->wino_m; }
         WinoArgs wa;
@@ -630,7 +633,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
         g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
         g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = 16;
-        prof_begin(n, 0, L.tile == CT_128x128 || L.tile == CT_128x128_DEEP, 2.0 * 16 * T * (double)L.Cin * L.Cout, s);
+        prof_begin(n, 0, 2, 2.0 * 16 * T * (double)L.Cin * L.Cout, s);
         conv_launch(g, L.tile, 1, false, s);
         prof_end(n, s);
         prof_begin(n, 2, false, 0, s);
@@ -724,6 +727,7 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     if (pos_id < 0 || pos_id >= n->P) return td_fail("tdnet_forward: pos_id %d out of range 0..%d", pos_id, n->P - 1);
     PathLayers& L = n->paths[pos_id];
     n->nrec = 0;
+    n->failed = false;
     const int DV = n->DV;
     // ---- fork: everything that depends only on CACHED frames (td4_psp18.py:145-146 and the fc of :147) runs on the side
     // stream while the backbone of the current frame runs on `s`; joined right before the final attention.
@@ -777,7 +781,7 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
         run_ppm(n, c4, n->h, n->w, n->C, n->C, n->C / 4, L.d_ppm_w, L.d_ppm_b, 0, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
         run_conv(n, L.head3, n->z, n->h, n->w, nullptr, n->headmid, s);
         run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s);
-        return 0;
+        return n->failed ? -1 : 0;
     }
     run_ppm(n, c4, n->h, n->w, n->C, n->C / 2, n->C / 8, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
     // Encoding, pre=False (transformer.py:52-56)
@@ -817,7 +821,7 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     n->fifo.push_back(slot);
     if ((int)n->fifo.size() > n->FIFO) n->fifo.erase(n->fifo.begin());
     n->last_slot = slot;
-    return 0;
+    return n->failed ? -1 : 0;
 }
 
 extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* logits, void* stream) {
@@ -929,6 +933,8 @@ extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->final
 extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; return 0; }
 // 0 = direct convolutions (default), 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (layers 3-4), 2 = for every stride-1 3x3
 extern "C" int tdnet_set_conv_winograd(int mode) { g_conv_wino = mode < 0 ? 0 : mode > 2 ? 2 : mode; return 0; }
+// bit 0: two-stage pipeline, bit 1: fp16-input MFMA, bits 2-3: Winograd mode, bits 8..: stagger
+extern "C" int tdnet_get_conv_config(void) { return (g_conv_deep & 1) | ((g_conv_fp16 & 1) << 1) | ((g_conv_wino & 3) << 2) | (g_conv_stagger << 8); }
 extern "C" int tdnet_set_conv_stagger(int units) { g_conv_stagger = units < 0 ? 0 : units > 64 ? 64 : units; return 0; }
 // Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
 extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }
@@ -944,9 +950,11 @@ extern "C" int tdnet_set_profiling(tdnet_t* n, int on) {
 static double prof_query(const tdnet* n, int which, int mode) {
     if (!n || !n->prof || n->nrec == 0) return -1.0;
     double ms = 0.0, fl = 0.0, cnt = 0.0;
+    int domkind = 1;                                                   // the Winograd GEMM is the dominant kernel whenever it runs
+    for (size_t i = 0; i < n->nrec; ++i) if (n->recs[i].dominant == 2) domkind = 2;
     for (size_t i = 0; i < n->nrec; ++i) {
         const ProfRec& r = n->recs[i];
-        const bool take = which == 3 ? (r.family == 0 && r.dominant) : r.family == which;
+        const bool take = which == 3 ? (r.family == 0 && r.dominant == domkind) : r.family == which;
         if (!take) continue;
         if (mode == 0) {
             hipEventSynchronize(r.e1);

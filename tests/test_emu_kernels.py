@@ -19,8 +19,16 @@ def lib():
     return emu_util.emu_lib()
 
 
+@pytest.fixture()
+def direct_convs(lib):
+    """Force the direct implicit-GEMM kernels (the library default routes wide stride-1 3x3 convs to Winograd)."""
+    lib.tdnet_set_conv_winograd(0)
+    yield
+    lib.tdnet_set_conv_winograd(1)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
-def test_conv_variants(lib, tile):
+def test_conv_variants(lib, direct_convs, tile):
     opcheck.conv(lib, MEM, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)       # dilated 3x3 + residual + ReLU
     opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)       # stride 2, Cout not a tile multiple
     opcheck.conv(lib, MEM, 11, 19, 64, 19, 1, 1, 1, 2, False, tile)       # 1x1, 19 channels, LeakyReLU
@@ -31,7 +39,7 @@ def test_conv_variants(lib, tile):
     opcheck.conv(lib, MEM, 7, 9, 96, 64, 1, 1, 1, 1, False, tile)         # three K steps (odd tail of the 2-stage loop)
 
 
-def test_conv_auto_tile_and_edges(lib):
+def test_conv_auto_tile_and_edges(lib, direct_convs):
     opcheck.conv(lib, MEM, 20, 23, 64, 64, 1, 4, 1, 2, False)             # the stride-4 key sub-sampling conv
     opcheck.conv(lib, MEM, 9, 17, 128, 256, 3, 1, 8, 1, True)             # dilation 8 larger than the image half
     opcheck.conv(lib, MEM, 5, 9, 256, 512, 3, 1, 16, 1, False)            # dilation 16 (resnet34 multi-grid): all taps but centre padded
@@ -128,4 +136,4 @@ def test_winograd_conv_and_pipeline(lib, golden_dir):
             assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
         e.close()
     finally:
-        lib.tdnet_set_conv_winograd(0)
+        lib.tdnet_set_conv_winograd(1)             # library default

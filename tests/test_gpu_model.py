@@ -114,6 +114,17 @@ def test_full_size_digest_from_reference(golden_dir):
         assert (out[0].argmax(0)[::61, ::67] != g[tag + "_labels_sample"]).mean() <= 0.002
 
 
+def test_direct_conv_mode_meets_the_same_gate():
+    """The library default uses Winograd for layers 3-4; the all-direct configuration must stay parity-green too."""
+    from tdnet_amd import _capi
+    _capi.lib().tdnet_set_conv_winograd(0)
+    try:
+        _vs_oracle("td4", "resnet18", 257, 513, 6)
+        _vs_oracle("td4", "resnet18", 1024, 2048, 5)
+    finally:
+        _capi.lib().tdnet_set_conv_winograd(1)
+
+
 def test_properties_determinism_labels_reset():
     H, W = 129, 257
     frames = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, 6, seed=3)]

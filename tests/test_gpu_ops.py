@@ -20,8 +20,16 @@ def mem():
     return opcheck.TorchMem()
 
 
+@pytest.fixture()
+def direct_convs(lib):
+    """Force the direct implicit-GEMM kernels (the library default routes wide stride-1 3x3 convs to Winograd)."""
+    lib.tdnet_set_conv_winograd(0)
+    yield
+    lib.tdnet_set_conv_winograd(1)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
-def test_conv_variants(lib, mem, tile):
+def test_conv_variants(lib, mem, direct_convs, tile):
     opcheck.conv(lib, mem, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)
     opcheck.conv(lib, mem, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)
     opcheck.conv(lib, mem, 11, 19, 64, 19, 1, 1, 1, 2, False, tile)
@@ -34,7 +42,9 @@ def test_conv_variants(lib, mem, tile):
     opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tile, tol=2e-4)   # the dominant layer4 shape on every variant
 
 
-def test_conv_real_shapes(lib, mem):
+@pytest.mark.parametrize("wino", [0, 1])
+def test_conv_real_shapes(lib, mem, wino):
+    lib.tdnet_set_conv_winograd(wino)
     opcheck.conv(lib, mem, 64, 128, 64, 64, 3, 1, 1, 1, True)             # layer1-like
     opcheck.conv(lib, mem, 64, 128, 64, 128, 3, 2, 1, 1, False)           # layer2.0.conv1
     opcheck.conv(lib, mem, 64, 128, 64, 128, 1, 2, 1, 0, False)           # layer2.0.downsample
@@ -46,6 +56,7 @@ def test_conv_real_shapes(lib, mem):
     opcheck.conv(lib, mem, 128, 256, 512, 64, 1, 4, 1, 2, False)          # w_ks.0 on the stride-4 key grid
     opcheck.conv(lib, mem, 1, 2048, 512, 512, 1, 1, 1, 0, False)          # attention fc on the cached value matrix
     opcheck.conv(lib, mem, 40, 40, 512, 128, 3, 1, 1, 1, False)           # FCNHead conv
+    lib.tdnet_set_conv_winograd(1)
 
 
 def test_stem(lib, mem):

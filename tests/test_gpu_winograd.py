@@ -25,4 +25,4 @@ def test_winograd_ops_and_model():
         tm._vs_oracle("td4", "resnet18", 1024, 2048, 5)
         tm._vs_oracle("td2", "resnet34", 180, 240, 3)
     finally:
-        lib.tdnet_set_conv_winograd(0)
+        lib.tdnet_set_conv_winograd(1)             # library default

@@ -4,7 +4,7 @@ import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.lib(); torch.zeros(1, device="cuda"); lib.tdnet_set_conv_winograd(0)
 SHAPES = [("layer4 512->512 d4", 128, 256, 512, 512, 3, 1, 4, 3), ("layer3 256->256 d2", 128, 256, 256, 256, 3, 1, 2, 3),
           ("layer2 128->128 (64x128)", 128, 256, 128, 128, 3, 1, 1, 4), ("layer1 64->64 (128x64)", 256, 512, 64, 64, 3, 1, 1, 5),
           ("enc_v 1x1 512->512", 128, 256, 512, 512, 1, 1, 1, 3)]

@@ -17,4 +17,4 @@ for (nm, H, W, Cin, Cout, d) in SHAPES:
         ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 3, 1, d, t, 20, None) for _ in range(2))
         out.append("%s %.3f ms (%.0f TF eff.)" % ("wino" if mode else "direct", ms, gf / ms))
     print("%-24s %6.1f GFLOP  %s" % (nm, gf, "   ".join(out)), flush=True)
-lib.tdnet_set_conv_winograd(0)
+lib.tdnet_set_conv_winograd(1)
