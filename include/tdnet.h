@@ -87,8 +87,11 @@ int tdnet_set_conv_stagger(int units);
  * 1 (default) = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4 and the
  * FCN head), 2 = for every stride-1 3x3.  All modes are fp32 and meet the 1e-3 logits gate.                              */
 int tdnet_set_conv_winograd(int mode);
-/* Current process-wide conv configuration: bit 0 two-stage pipeline, bit 1 fp16-input MFMA, bits 2-3 Winograd mode.   */
+/* Current process-wide conv configuration: bit 0 two-stage pipeline, bit 1 fp16-input MFMA, bits 2-3 Winograd mode, bit 4 persistent GEMM. */
 int tdnet_get_conv_config(void);
+/* Tuning hook: 1 (default) = stride-1 1x1 convs and the Winograd GEMMs run on the persistent multi-tile GEMM kernel,
+ * 0 = on the one-tile-per-workgroup conv kernel.                                                                     */
+int tdnet_set_gemm_persistent(int on);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */

@@ -44,6 +44,7 @@ SYMBOLS = {
     "tdnet_set_conv_stagger": (ctypes.c_int, [ctypes.c_int]),
     "tdnet_set_conv_winograd": (ctypes.c_int, [ctypes.c_int]),
     "tdnet_get_conv_config": (ctypes.c_int, []),
+    "tdnet_set_gemm_persistent": (ctypes.c_int, [ctypes.c_int]),
     "tdnet_bench_mfma_peak": (ctypes.c_double, [ctypes.c_int, ctypes.c_int, c_void_p]),
     "tdnet_bench_conv": (ctypes.c_double, [ctypes.c_int] * 9 + [c_void_p]),
     "tdnet_last_error": (ctypes.c_char_p, []),

@@ -5,8 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtdnet_hip.so")
-SRCS = [os.path.join(CSRC, f) for f in ("td_model.hip", "td_device.h", "td_conv.h", "td_attn.h", "td_misc.h")] + \
-       [os.path.join(os.path.dirname(HERE), "include", "tdnet.h")]
+import glob  # noqa: E402
+SRCS = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(os.path.dirname(HERE), "include", "tdnet.h"), os.path.abspath(__file__)]
 
 
 def build(force=False, verbose=False):

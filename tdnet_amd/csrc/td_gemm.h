@@ -1,0 +1,220 @@
+// td_gemm.h -- persistent fp32-MFMA GEMM for the short-K contractions of the path:
+//   out[b][m][n] = act( sum_k A[b][m][k] * W[b][k][n] + bias[n] (+ resid[m][n]) ),   b < nbatch, k < K = Cin
+// i.e. every stride-1 1x1 convolution (Encoding projections transformer.py:18-24, Bottleneck 1x1s resnet.py:70-78, attention fc
+// on the cached value matrix) and the 16 batched GEMMs of a Winograd conv (td_wino.h).  K is only 64..2048 here, 2..64 steps of
+// 32: a workgroup that does ONE tile spends a large part of its life in the prologue (first loads exposed) and the epilogue
+// (accumulator stores), which is why the conv kernel reaches 84 % of the MFMA roof on K = 4608 but 65 % on K = 512.
+//
+// So this kernel is persistent: the grid is one wave of resident workgroups, each walks a list of output tiles, and the
+// two-stage load pipeline of td_conv.h runs ACROSS tile boundaries -- while tile i's accumulators are stored, tile i+1's
+// first two K slices are already in flight / in LDS.  Same LDS images, fragment maps, weight packing (conv_pack_weights,
+// KS = 1) and output-column permutation as k_conv_igemm; the A operand is a plain row-major matrix (no taps, no padding).
+//
+// Tile order: linear index = (batch, tile_m, tile_n) with tile_n fastest, cut into 8 contiguous ranges, one per XCD
+// (workgroup w runs on XCD w % 8), so the N-tiles that share an A panel run on the same L2 at about the same time.
+#pragma once
+#include "td_conv.h"
+
+struct GemmArgs {
+    const float* a;       // [nbatch][M][K]
+    const float* wp;      // [nbatch][K/32][8][NPad][4]  (conv_pack_weights, KS = 1)
+    const float* bias;    // [N]
+    const float* resid;   // [M][N] or nullptr (nbatch == 1 only)
+    float* out;           // [nbatch][M][N]
+    int M, N, NPad, K;
+    int nbatch, act;
+    int tiles_m, tiles_n; // per batch
+};
+
+template <int BM, int BN, int WGM, int WGN>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
+    constexpr int AL = BM / 32, BL = BN / 32;
+    static_assert((AL == 2 || AL == 4) && (BL == 2 || BL == 4), "staging slots are spread over the 4 k-groups");
+    using L = ConvLds<BM, BN>;
+    TD_DYN_LDS(smem);
+    float* lds = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int a_row = tid >> 3, a_kq = tid & 7;
+
+    // ---- this workgroup's tile list: range of XCD (bid % 8), positions q, q + G8, q + 2 G8, ... ----------------
+    const int per_batch = p.tiles_m * p.tiles_n, total = per_batch * p.nbatch;
+    const int NX = gridDim.x < 8 ? (int)gridDim.x : 8;               // 8 XCDs (fewer ranges only for grids smaller than that)
+    const int xcd = blockIdx.x % NX, q = blockIdx.x / NX;
+    const int G8 = ((int)gridDim.x + NX - 1 - xcd) / NX;             // workgroups on this XCD
+    const int nq = total / NX, rem = total % NX;
+    const int xbase = xcd < rem ? xcd * (nq + 1) : rem * (nq + 1) + (xcd - rem) * nq;
+    const int xcount = nq + (xcd < rem ? 1 : 0);
+    const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
+    const int nsteps = p.K >> 5;
+    const int gtotal = my_tiles * nsteps;                            // "global steps" of this workgroup
+    if (gtotal == 0) return;
+    const unsigned w_step_bytes = 8u * (unsigned)p.NPad * 16u;
+    const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 4u, w_bytes = (unsigned)nsteps * w_step_bytes;
+
+    // ---- loader state (runs two global steps ahead of the MFMAs) -------------------------------------------------
+    int l_tile = 0, l_step = 0;                                      // index into my tile list / K step inside it
+    TdBuf a_buf, w_buf;
+    unsigned a_off[AL], b_off[BL];
+    auto loader_enter_tile = [&]() {
+        const int lin = xbase + q + (l_tile < my_tiles ? l_tile : my_tiles - 1) * G8;   // past the end: stay on the last tile
+        const int b = lin / per_batch, r = lin - b * per_batch;
+        const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
+        a_buf = td_make_buf(p.a + (size_t)b * p.M * p.K, a_bytes);
+        w_buf = td_make_buf(p.wp + (size_t)b * nsteps * 8 * p.NPad * 4, w_bytes);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int m = tm * BM + a_row + 32 * i;
+            a_off[i] = m < p.M ? ((unsigned)m * (unsigned)p.K + (unsigned)a_kq * 4u) * 4u : TD_BUF_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) {
+            const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
+            b_off[i] = (unsigned)(kq * p.NPad + tn * BN + n) * 16u;
+        }
+    };
+    auto load_tile = [&](f32x4 (&ra)[AL], f32x4 (&rb)[BL]) {
+        const unsigned kb = (unsigned)l_step * 128u;                 // 32 floats per step
+#pragma unroll
+        for (int i = 0; i < AL; ++i) ra[i] = td_buf_ld4(a_buf, a_off[i] == TD_BUF_OOB ? TD_BUF_OOB : a_off[i] + kb, 0u);
+        const unsigned wsoff = (unsigned)l_step * w_step_bytes;
+#pragma unroll
+        for (int i = 0; i < BL; ++i) rb[i] = td_buf_ld4(w_buf, b_off[i], wsoff);
+        if (++l_step == nsteps) { l_step = 0; ++l_tile; loader_enter_tile(); }
+    };
+    auto store_a = [&](int buf, int i, const f32x4 (&ra)[AL]) {
+        td_st4(lds + buf * L::BUF_FLOATS + a_kq * L::A_STRIDE + (a_row + 32 * i) * 4, ra[i]);
+    };
+    auto store_b = [&](int buf, int i, const f32x4 (&rb)[BL]) {
+        const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
+        td_st4(lds + buf * L::BUF_FLOATS + L::A_FLOATS + kq * L::B_STRIDE + n * 4, rb[i]);
+    };
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    auto compute = [&](int buf, const f32x4 (&sa)[AL], const f32x4 (&sb)[BL]) {
+        const float* As = lds + buf * L::BUF_FLOATS + (wm * WM + l31) * 4;
+        const float* Bs = lds + buf * L::BUF_FLOATS + L::A_FLOATS + (wn * WN + l31) * 4;
+        f32x4 af[2][MT], bf[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[0][i] = td_ld4(As + half * L::A_STRIDE + i * 128);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[0][j] = td_ld4(Bs + half * L::B_STRIDE + j * 128);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[(g + 1) & 1][i] = td_ld4(As + (2 * g + 2 + half) * L::A_STRIDE + i * 128);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[(g + 1) & 1][j] = td_ld4(Bs + (2 * g + 2 + half) * L::B_STRIDE + j * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < AL; ++i) if (i * (4 / AL) == g) store_a(buf ^ 1, i, sa);
+#pragma unroll
+            for (int i = 0; i < BL; ++i) if (i * (4 / BL) == g) store_b(buf ^ 1, i, sb);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = td_mfma32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j]);
+            if (MT == 2 && NT == 2 && AL == 4 && BL == 4) {
+                TD_SCHED_GROUP(0x008, 2); TD_SCHED_GROUP(0x200, 1); TD_SCHED_GROUP(0x008, 2); TD_SCHED_GROUP(0x200, 1);
+                if (g < 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { TD_SCHED_GROUP(0x100, 1); TD_SCHED_GROUP(0x008, 3); }
+                } else {
+                    TD_SCHED_GROUP(0x008, 12);
+                }
+            }
+        }
+    };
+    // ---- compute-side tile state + epilogue -------------------------------------------------------------------
+    int c_tile = 0, c_step = 0;
+    auto finish_step = [&]() {                                       // called after the MFMAs of one global step
+        if (++c_step < nsteps) return;
+        c_step = 0;
+        const int lin = xbase + q + c_tile * G8;
+        ++c_tile;
+        const int b = lin / per_batch, r0 = lin - b * per_batch;
+        const int tm = r0 / p.tiles_n, tn = r0 - tm * p.tiles_n;
+        float* outb = p.out + (size_t)b * p.M * p.N;
+        const int nb = tn * BN + wn * WN + l31 * NT;
+        float bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = (nb + j < p.N) ? p.bias[nb + j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = tm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= p.M) continue;
+                const size_t o = (size_t)m * p.N + nb;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (nb + j >= p.N) continue;
+                    float v = acc[i][j][r] + bv[j];
+                    if (p.resid) v += p.resid[o + j];
+                    if (p.act == 1) v = v > 0.f ? v : 0.f;
+                    else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
+                    outb[o + j] = v;
+                }
+            }
+        }
+        zero_acc();
+    };
+
+    zero_acc();
+    loader_enter_tile();
+    f32x4 ra[AL], rb[BL], ra2[AL], rb2[BL];
+    load_tile(ra, rb);                                               // global step 0
+#pragma unroll
+    for (int i = 0; i < AL; ++i) store_a(0, i, ra);
+#pragma unroll
+    for (int i = 0; i < BL; ++i) store_b(0, i, rb);
+    load_tile(ra, rb);                                               // global step 1 (clamped if there is none)
+    __syncthreads();
+    for (int g = 0; g < gtotal; g += 2) {
+        load_tile(ra2, rb2);                                         // step g+2 in flight; step g+1 goes to LDS under the MFMAs of step g
+        compute(0, ra, rb);
+        __syncthreads();
+        finish_step();
+        if (g + 1 >= gtotal) break;
+        load_tile(ra, rb);
+        compute(1, ra2, rb2);
+        __syncthreads();
+        finish_step();
+    }
+}
+
+// resident workgroups per CU by LDS (65.8 KB for 128x128, 49.4 KB for the smaller tiles) and registers (<= 208 VGPRs)
+static inline int gemm_blocks_per_cu(ConvTile t) { const ConvTileDims d = conv_tile_dims(t); return d.BM == 128 && d.BN == 128 ? 2 : 3; }
+
+template <int BM, int BN, int WGM, int WGN>
+static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t s) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = a.NPad / BN;
+    const long total = (long)a.tiles_m * a.tiles_n * a.nbatch;
+    long grid = grid_cap > 0 ? grid_cap : 256L * bpc;
+    if (grid > total) grid = total;
+    TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
+}
+// grid_cap > 0 forces the number of workgroups (tests: several tiles per workgroup on small problems)
+static inline void gemm_launch(const GemmArgs& a, ConvTile tile, int grid_cap, hipStream_t s) {
+    const ConvTileDims d = conv_tile_dims(tile);
+    const int bpc = gemm_blocks_per_cu(tile);
+    if (d.BM == 128 && d.BN == 128) gemm_launch_t<128, 128, 2, 2>(a, bpc, grid_cap, s);
+    else if (d.BM == 64) gemm_launch_t<64, 128, 2, 2>(a, bpc, grid_cap, s);
+    else gemm_launch_t<128, 64, 4, 1>(a, bpc, grid_cap, s);
+}

@@ -11,6 +11,7 @@
 #include "td_conv.h"
 #include "td_conv_h.h"
 #include "td_wino.h"
+#include "td_gemm.h"
 #include "td_attn.h"
 #include "td_misc.h"
 
@@ -102,6 +103,8 @@ struct ConvLayer {
     double flops_per_pixel() const { return 2.0 * Cout * (stem ? 3.0 * KS * KS : (double)Cin * KS * KS); }
 };
 
+// 1 = stride-1 1x1 convs and the Winograd GEMMs run on the persistent multi-tile GEMM kernel (td_gemm.h), 0 = on k_conv_igemm
+static int g_gemm_persistent = 1;
 // 0 = direct convs only, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4
 // and the FCN head), 2 = every stride-1 3x3 conv.  Default 1: measured +20 % frames/s at 1024x2048, +23 % at 769x1537, with
 // logits as close to the fp32 CPU path as the direct kernels' (profiles/r01f_*).
@@ -634,7 +637,14 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
         g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = 16;
         prof_begin(n, 0, 2, 2.0 * 16 * T * (double)L.Cin * L.Cout, s);
-        conv_launch(g, L.tile, 1, false, s);
+        if (g_gemm_persistent) {
+            GemmArgs ga;
+            ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
+            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 16; ga.act = 0; ga.tiles_m = ga.tiles_n = 0;
+            gemm_launch(ga, L.tile, g_gemm_persistent > 1 ? g_gemm_persistent : 0, s);
+        } else {
+            conv_launch(g, L.tile, 1, false, s);
+        }
         prof_end(n, s);
         prof_begin(n, 2, false, 0, s);
         TD_LAUNCH(k_wino_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
@@ -650,7 +660,12 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = g_conv_stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
-    else conv_launch(a, L.tile, L.KS, L.stem, s);
+    else if (g_gemm_persistent && L.KS == 1 && L.stride == 1 && !L.stem) {
+        GemmArgs ga;
+        ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
+        ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0;
+        gemm_launch(ga, L.tile, g_gemm_persistent > 1 ? g_gemm_persistent : 0, s);
+    } else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;
     if (Wo_out) *Wo_out = Wo;
@@ -934,7 +949,9 @@ extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; 
 // 0 = direct convolutions (default), 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (layers 3-4), 2 = for every stride-1 3x3
 extern "C" int tdnet_set_conv_winograd(int mode) { g_conv_wino = mode < 0 ? 0 : mode > 2 ? 2 : mode; return 0; }
 // bit 0: two-stage pipeline, bit 1: fp16-input MFMA, bits 2-3: Winograd mode, bits 8..: stagger
-extern "C" int tdnet_get_conv_config(void) { return (g_conv_deep & 1) | ((g_conv_fp16 & 1) << 1) | ((g_conv_wino & 3) << 2) | (g_conv_stagger << 8); }
+extern "C" int tdnet_get_conv_config(void) { return (g_conv_deep & 1) | ((g_conv_fp16 & 1) << 1) | ((g_conv_wino & 3) << 2) | ((g_gemm_persistent ? 1 : 0) << 4) | (g_conv_stagger << 8); }
+// 0 = off, 1 = on, n > 1 = on with the grid forced to n workgroups (test hook: many tiles per workgroup)
+extern "C" int tdnet_set_gemm_persistent(int on) { g_gemm_persistent = on < 0 ? 0 : on; return 0; }
 extern "C" int tdnet_set_conv_stagger(int units) { g_conv_stagger = units < 0 ? 0 : units > 64 ? 64 : units; return 0; }
 // Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
 extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }

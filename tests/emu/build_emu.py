@@ -8,8 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_build", "libtdnet_emu.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
-SRCS = [os.path.join(ROOT, "tdnet_amd", "csrc", f) for f in ("td_model.hip", "td_device.h", "td_conv.h", "td_attn.h", "td_misc.h")] + \
-       [os.path.join(HERE, f) for f in ("td_device.h", "tdemu.cpp")] + [os.path.join(ROOT, "include", "tdnet.h")]
+import glob  # noqa: E402
+SRCS = glob.glob(os.path.join(ROOT, "tdnet_amd", "csrc", "*")) + \
+       [os.path.join(HERE, f) for f in ("td_device.h", "tdemu.cpp", "build_emu.py")] + [os.path.join(ROOT, "include", "tdnet.h")]
 
 
 def build(force=False):

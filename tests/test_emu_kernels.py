@@ -137,3 +137,22 @@ def test_winograd_conv_and_pipeline(lib, golden_dir):
         e.close()
     finally:
         lib.tdnet_set_conv_winograd(1)             # library default
+
+
+def test_persistent_gemm_multi_tile(lib):
+    """td_gemm.h: stride-1 1x1 convs and Winograd GEMMs on the persistent kernel, with the grid forced small so every
+    workgroup walks several tiles (pipeline running across tile boundaries, odd/even tile counts, idle workgroups)."""
+    try:
+        for cap in (1, 3, 5, 8, 11):
+            lib.tdnet_set_gemm_persistent(cap if cap > 1 else 2)
+            for tile in (3, 4, 5):
+                opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True, tile)      # 3 K steps, ragged M and N
+                opcheck.conv(lib, MEM, 40, 40, 32, 64, 1, 1, 1, 0, False, tile)      # 1 K step per tile
+            lib.tdnet_set_conv_winograd(2)
+            opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True)                # 16 batches x tiles over few workgroups
+            lib.tdnet_set_conv_winograd(1)
+        lib.tdnet_set_gemm_persistent(0)                                              # the non-persistent fallback stays correct
+        opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True)
+    finally:
+        lib.tdnet_set_gemm_persistent(1)
+        lib.tdnet_set_conv_winograd(1)
