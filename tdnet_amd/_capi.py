@@ -73,6 +73,11 @@ class Lib:
             raise TdnetError("HIP library not found: %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
+        if path == DEFAULT_LIB:
+            # PyTorch-ROCm bundles its own HIP runtime under the same SONAME; it must be the one already loaded when this
+            # library's libamdhip64 dependency is resolved, or the process ends up with two runtimes and hipSetDevice reports
+            # "no ROCm-capable device" (seen on the GPU box when the library was loaded before `import torch`).
+            import torch  # noqa: F401
         self.dll = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.dll, name)              # AttributeError if a declared symbol is not exported

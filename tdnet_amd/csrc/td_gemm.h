@@ -6,7 +6,7 @@
 // (accumulator stores), which is why the conv kernel reaches 84 % of the MFMA roof on K = 4608 but 65 % on K = 512.
 //
 // So this kernel is persistent: the grid is one wave of resident workgroups, each walks a list of output tiles, and the
-// two-stage load pipeline of td_conv.h runs ACROSS tile boundaries -- while tile i's accumulators are stored, tile i+1's
+// load pipeline of td_conv.h (here three stages deep) runs ACROSS tile boundaries -- while tile i's accumulators are stored, tile i+1's
 // first two K slices are already in flight / in LDS.  Same LDS images, fragment maps, weight packing (conv_pack_weights,
 // KS = 1) and output-column permutation as k_conv_igemm; the A operand is a plain row-major matrix (no taps, no padding).
 //
@@ -177,29 +177,36 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
 
     zero_acc();
     loader_enter_tile();
-    f32x4 ra[AL], rb[BL], ra2[AL], rb2[BL];
-    load_tile(ra, rb);                                               // global step 0
+    // THREE register sets: global step g+3 is in flight while step g is multiplied and step g+1 is written to LDS.  The A
+    // panels of the Winograd GEMMs stream from HBM (they were just written by the transform), and two steps of lookahead
+    // (3.5 us) did not cover that latency: 28 % of the wave-cycles sat in s_waitcnt with the two-set pipeline.
+    f32x4 s0a[AL], s0b[BL], s1a[AL], s1b[BL], s2a[AL], s2b[BL];
+    load_tile(s0a, s0b);                                             // global step 0
 #pragma unroll
-    for (int i = 0; i < AL; ++i) store_a(0, i, ra);
+    for (int i = 0; i < AL; ++i) store_a(0, i, s0a);
 #pragma unroll
-    for (int i = 0; i < BL; ++i) store_b(0, i, rb);
-    load_tile(ra, rb);                                               // global step 1 (clamped if there is none)
+    for (int i = 0; i < BL; ++i) store_b(0, i, s0b);
+    load_tile(s0a, s0b);                                             // global step 1 (past the end: clamped, harmless)
+    load_tile(s1a, s1b);                                             // global step 2
     __syncthreads();
-    for (int g = 0; g < gtotal; g += 2) {
-        load_tile(ra2, rb2);                                         // step g+2 in flight; step g+1 goes to LDS under the MFMAs of step g
-        compute(0, ra, rb);
-        __syncthreads();
-        finish_step();
+    // LDS buffers alternate every step, register sets rotate every three: one period = 6 steps
+    for (int g = 0; g < gtotal; g += 6) {
+        load_tile(s2a, s2b); compute(0, s0a, s0b); __syncthreads(); finish_step();
         if (g + 1 >= gtotal) break;
-        load_tile(ra, rb);
-        compute(1, ra2, rb2);
-        __syncthreads();
-        finish_step();
+        load_tile(s0a, s0b); compute(1, s1a, s1b); __syncthreads(); finish_step();
+        if (g + 2 >= gtotal) break;
+        load_tile(s1a, s1b); compute(0, s2a, s2b); __syncthreads(); finish_step();
+        if (g + 3 >= gtotal) break;
+        load_tile(s2a, s2b); compute(1, s0a, s0b); __syncthreads(); finish_step();
+        if (g + 4 >= gtotal) break;
+        load_tile(s0a, s0b); compute(0, s1a, s1b); __syncthreads(); finish_step();
+        if (g + 5 >= gtotal) break;
+        load_tile(s1a, s1b); compute(1, s2a, s2b); __syncthreads(); finish_step();
     }
 }
 
-// resident workgroups per CU by LDS (65.8 KB for 128x128, 49.4 KB for the smaller tiles) and registers (<= 208 VGPRs)
-static inline int gemm_blocks_per_cu(ConvTile t) { const ConvTileDims d = conv_tile_dims(t); return d.BM == 128 && d.BN == 128 ? 2 : 3; }
+// resident workgroups per CU (register-limited)
+static inline int gemm_blocks_per_cu(ConvTile) { return 2; }   // 176-254 VGPRs with three staging sets: 2 waves per SIMD for every tile
 
 template <int BM, int BN, int WGM, int WGN>
 static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t s) {
