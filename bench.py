@@ -153,7 +153,8 @@ def main():
             if cfgbits & 2:
                 kname, peak = "k_conv_igemm_h<128,128,2,2,3> (3x3 dilated conv, fp16-input MFMA, fp32 accumulate)", 2500.0
             elif (cfgbits >> 2) & 3:
-                kname, peak = ("k_conv_igemm<128,128,2,2,1> x16 (batched GEMM of the Winograd F(2x2,3x3) convs of layers 3-4 + head, "
+                gk = "k_gemm_persistent<128,128,2,2>" if (cfgbits >> 4) & 1 else "k_conv_igemm<128,128,2,2,1>"
+                kname, peak = (gk + " x16 (batched GEMM of the Winograd F(2x2,3x3) convs of layers 3-4 + head, "
                                "fp32 MFMA; FLOP = executed GEMM FLOP, 2.25x fewer than the direct conv's)"), PEAK_FP32_MFMA_TFLOPS
             else:
                 kname, peak = "k_conv_igemm<128,128,2,2,3> (3x3 dilated conv, fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS

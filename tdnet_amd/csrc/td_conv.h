@@ -65,6 +65,68 @@ struct ConvLds {
     static constexpr int BYTES = 2 * BUF_FLOATS * 4;
 };
 
+// ---- accumulator epilogue shared by the conv / GEMM kernels:  out[m][n] = act(acc + bias[n] (+ resid[m][n])) -----------
+// acc[i][j][r] of a lane is row  m_base + 32 i + (r & 3) + 8 (r >> 2) + 4 half,  channel  n_base + NT l31 + j  (weight packer
+// permutation).  Storing that directly is NT*4 bytes per lane and 16*MT*NT store instructions per wave, and the vector-memory
+// path issues a store instruction only every few hundred cycles: on a K = 512 tile the stores cost as much as a quarter of the
+// MFMA time.  With NT == 2 adjacent lanes swap half of a row pair (one DPP move per value): the even lane then holds 4
+// consecutive channels of row r, the odd lane the same 4 channels of row r + 1, and a wave stores 16 bytes per lane, 256
+// contiguous bytes per row, with a quarter of the store instructions.
+template <int MT, int NT>
+TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* bias, const float* resid, int M, int N, int act,
+                         int m_base, int n_base, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    auto activate = [&](float v) { return act == 1 ? (v > 0.f ? v : 0.f) : act == 2 ? (v > 0.f ? v : 0.01f * v) : v; };
+    if (NT == 2 && (N & 3) == 0 && ((((size_t)out) | ((size_t)resid)) & 15) == 0) {       // wave-uniform
+        const int odd = l31 & 1;
+        const int chan = n_base + 4 * (l31 >> 1);
+        const bool cok = chan < N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (cok) { bv[0] = bias[chan]; bv[1] = bias[chan + 1]; bv[2] = bias[chan + 2]; bv[3] = bias[chan + 3]; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int r = 2 * rp;
+                const float a0 = acc[i][0][r], a1 = acc[i][NT - 1][r], c0 = acc[i][0][r + 1], c1 = acc[i][NT - 1][r + 1];
+                const float x = td_swap1(odd ? a0 : c0), y = td_swap1(odd ? a1 : c1);   // even sends row r+1, odd sends row r
+                f32x4 v;
+                if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
+                else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
+                const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
+                if (m >= M || !cok) continue;
+                const size_t o = (size_t)m * N + chan;
+                v = v + bv;
+                if (resid) v = v + td_ld4(resid + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = activate(v[e]);
+                td_st4(out + o, v);
+            }
+        }
+        return;
+    }
+    const int nb = n_base + l31 * NT;
+    float bs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bs[j] = (nb + j < N) ? bias[nb + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= M) continue;
+            const size_t o = (size_t)m * N + nb;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nb + j >= N) continue;
+                float v = acc[i][j][r] + bs[j];
+                if (resid) v += resid[o + j];
+                out[o + j] = activate(v);
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int KS, bool STEM, bool DEEP>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
@@ -265,29 +327,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         }
     }
 
-    // ---- epilogue: lane owns channels nb .. nb+NT-1 of row m (see weight packer) ----
-    const int nb = n0 + wn * WN + l31 * NT;
-    float bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = (nb + j < p.Cout) ? p.bias[nb + j] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m >= p.M) continue;
-            const size_t o = (size_t)m * p.Cout + nb;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nb + j >= p.Cout) continue;
-                float v = acc[i][j][r] + bv[j];
-                if (p.resid) v += p.resid[o + j];
-                if (p.act == 1) v = v > 0.f ? v : 0.f;
-                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
-                p.out[o + j] = v;
-            }
-        }
-    }
+    td_store_acc<MT, NT>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

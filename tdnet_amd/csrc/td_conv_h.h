@@ -155,28 +155,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         __syncthreads();
     }
 
-    const int nb = n0 + wn * WN + l31 * NT;
-    float bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j] = (nb + j < p.Cout) ? p.bias[nb + j] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m >= p.M) continue;
-            const size_t o = (size_t)m * p.Cout + nb;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (nb + j >= p.Cout) continue;
-                float v = acc[i][j][r] + bv[j];
-                if (p.resid) v += p.resid[o + j];
-                if (p.act == 1) v = v > 0.f ? v : 0.f;
-                else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
-                p.out[o + j] = v;
-            }
-        }
-    }
+    td_store_acc<MT, NT>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 static inline int conv_nsteps_h(int Cin, int KS) { return (Cin / 64) * KS * KS; }

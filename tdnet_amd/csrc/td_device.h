@@ -48,6 +48,8 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
 TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 TD_DEV float td_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// value of lane ^ 1 (DPP quad_perm [1,0,3,2]: VALU rate, no LDS crossbar)
+TD_DEV float td_swap1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
 TD_DEV float td_exp2(float x) { return exp2f(x); }
 TD_DEV int td_lane() { return threadIdx.x & 63; }
 TD_DEV int td_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }

@@ -6,7 +6,7 @@
 // (accumulator stores), which is why the conv kernel reaches 84 % of the MFMA roof on K = 4608 but 65 % on K = 512.
 //
 // So this kernel is persistent: the grid is one wave of resident workgroups, each walks a list of output tiles, and the
-// load pipeline of td_conv.h (here three stages deep) runs ACROSS tile boundaries -- while tile i's accumulators are stored, tile i+1's
+// load pipeline of td_conv.h runs ACROSS tile boundaries -- while tile i's accumulators are stored, tile i+1's
 // first two K slices are already in flight / in LDS.  Same LDS images, fragment maps, weight packing (conv_pack_weights,
 // KS = 1) and output-column permutation as k_conv_igemm; the A operand is a plain row-major matrix (no taps, no padding).
 //
@@ -51,8 +51,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     const int xcount = nq + (xcd < rem ? 1 : 0);
     const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
     const int nsteps = p.K >> 5;
-    const int gtotal = my_tiles * nsteps;                            // "global steps" of this workgroup
-    if (gtotal == 0) return;
+    if (my_tiles == 0) return;
     const unsigned w_step_bytes = 8u * (unsigned)p.NPad * 16u;
     const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 4u, w_bytes = (unsigned)nsteps * w_step_bytes;
 
@@ -140,73 +139,48 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
             }
         }
     };
-    // ---- compute-side tile state + epilogue -------------------------------------------------------------------
-    int c_tile = 0, c_step = 0;
-    auto finish_step = [&]() {                                       // called after the MFMAs of one global step
-        if (++c_step < nsteps) return;
-        c_step = 0;
+    // ---- epilogue of the c_tile-th tile of this workgroup (ONE copy in the code: the K loop below is a whole number of periods) ----
+    int c_tile = 0;
+    auto store_tile = [&]() {
         const int lin = xbase + q + c_tile * G8;
         ++c_tile;
         const int b = lin / per_batch, r0 = lin - b * per_batch;
         const int tm = r0 / p.tiles_n, tn = r0 - tm * p.tiles_n;
         float* outb = p.out + (size_t)b * p.M * p.N;
-        const int nb = tn * BN + wn * WN + l31 * NT;
-        float bv[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = (nb + j < p.N) ? p.bias[nb + j] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = tm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.M) continue;
-                const size_t o = (size_t)m * p.N + nb;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (nb + j >= p.N) continue;
-                    float v = acc[i][j][r] + bv[j];
-                    if (p.resid) v += p.resid[o + j];
-                    if (p.act == 1) v = v > 0.f ? v : 0.f;
-                    else if (p.act == 2) v = v > 0.f ? v : 0.01f * v;
-                    outb[o + j] = v;
-                }
-            }
-        }
+        td_store_acc<MT, NT>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane);
         zero_acc();
     };
 
     zero_acc();
     loader_enter_tile();
-    // THREE register sets: global step g+3 is in flight while step g is multiplied and step g+1 is written to LDS.  The A
-    // panels of the Winograd GEMMs stream from HBM (they were just written by the transform), and two steps of lookahead
-    // (3.5 us) did not cover that latency: 28 % of the wave-cycles sat in s_waitcnt with the two-set pipeline.
-    f32x4 s0a[AL], s0b[BL], s1a[AL], s1b[BL], s2a[AL], s2b[BL];
-    load_tile(s0a, s0b);                                             // global step 0
+    // Two register sets: while global step g is multiplied, step g+1 moves registers -> LDS and step g+2 is in flight.  (A
+    // third set -- three steps of lookahead -- was measured: no gain, 256 VGPRs and spills.)  K/32 is even (host check), so a
+    // tile is a whole number of two-step periods and the epilogue appears once.
+    f32x4 ra[AL], rb[BL], ra2[AL], rb2[BL];
+    load_tile(ra, rb);                                               // global step 0
 #pragma unroll
-    for (int i = 0; i < AL; ++i) store_a(0, i, s0a);
+    for (int i = 0; i < AL; ++i) store_a(0, i, ra);
 #pragma unroll
-    for (int i = 0; i < BL; ++i) store_b(0, i, s0b);
-    load_tile(s0a, s0b);                                             // global step 1 (past the end: clamped, harmless)
-    load_tile(s1a, s1b);                                             // global step 2
+    for (int i = 0; i < BL; ++i) store_b(0, i, rb);
+    load_tile(ra, rb);                                               // global step 1
     __syncthreads();
-    // LDS buffers alternate every step, register sets rotate every three: one period = 6 steps
-    for (int g = 0; g < gtotal; g += 6) {
-        load_tile(s2a, s2b); compute(0, s0a, s0b); __syncthreads(); finish_step();
-        if (g + 1 >= gtotal) break;
-        load_tile(s0a, s0b); compute(1, s1a, s1b); __syncthreads(); finish_step();
-        if (g + 2 >= gtotal) break;
-        load_tile(s1a, s1b); compute(0, s2a, s2b); __syncthreads(); finish_step();
-        if (g + 3 >= gtotal) break;
-        load_tile(s2a, s2b); compute(1, s0a, s0b); __syncthreads(); finish_step();
-        if (g + 4 >= gtotal) break;
-        load_tile(s0a, s0b); compute(0, s1a, s1b); __syncthreads(); finish_step();
-        if (g + 5 >= gtotal) break;
-        load_tile(s1a, s1b); compute(1, s2a, s2b); __syncthreads(); finish_step();
+    for (int t = 0; t < my_tiles; ++t) {
+        for (int st = 0; st < nsteps; st += 2) {
+            load_tile(ra2, rb2);
+            compute(0, ra, rb);
+            __syncthreads();
+            load_tile(ra, rb);                                       // past the last tile: clamped to it, never consumed
+            compute(1, ra2, rb2);
+            __syncthreads();
+        }
+        store_tile();
     }
 }
 
-// resident workgroups per CU (register-limited)
-static inline int gemm_blocks_per_cu(ConvTile) { return 2; }   // 176-254 VGPRs with three staging sets: 2 waves per SIMD for every tile
+// resident workgroups per CU by LDS (65.8 KB for 128x128, 49.4 KB for the smaller tiles) and registers
+static inline int gemm_blocks_per_cu(ConvTile t) { const ConvTileDims d = conv_tile_dims(t); return d.BM == 128 && d.BN == 128 ? 2 : 3; }
+// the two-step period needs an even number of K steps
+static inline bool gemm_supports(int K) { return K % 64 == 0; }
 
 template <int BM, int BN, int WGM, int WGN>
 static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t s) {

@@ -637,7 +637,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
         g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = 16;
         prof_begin(n, 0, 2, 2.0 * 16 * T * (double)L.Cin * L.Cout, s);
-        if (g_gemm_persistent) {
+        if (g_gemm_persistent && gemm_supports(L.Cin)) {
             GemmArgs ga;
             ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
             ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 16; ga.act = 0; ga.tiles_m = ga.tiles_n = 0;
@@ -660,7 +660,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = g_conv_stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
-    else if (g_gemm_persistent && L.KS == 1 && L.stride == 1 && !L.stem) {
+    else if (g_gemm_persistent && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
         ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0;
