@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16-input MFMA convs, fp32 accumulate "
                          "(BASELINE config 5); parity vs the fp32 CPU path is reported, not gated")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="independent clips served concurrently by one GPU, each with its own handle/FIFO on its own HIP stream "
+                         "(throughput mode; a step is then one frame of EVERY clip).  Default 1 = BASELINE's one clip per GPU")
     args = ap.parse_args()
     H, W = (int(v) for v in args.size.lower().split("x"))
 
@@ -92,15 +95,27 @@ def main():
         cls = td4_psp18.td4_psp18 if args.model == "td4" else td2_psp50.td2_psp50
         model = cls(nclass=19, path_num=P, model_path=None, backbone=args.backbone).eval().to(dev)
     model.load_state_dict(sd)
+    C = max(1, args.clips_per_gpu)
+    models, streams = [model], [torch.cuda.current_stream(dev)]
+    for _ in range(C - 1):                                                        # extra clips: own handle (weights + FIFO), own stream
+        m2 = type(model)(nclass=19, model_path=None, backbone=args.backbone).eval().to(dev) if args.model == "psp" else \
+            type(model)(nclass=19, path_num=P, model_path=None, backbone=args.backbone).eval().to(dev)
+        m2.load_state_dict(sd)
+        models.append(m2); streams.append(torch.cuda.Stream(dev))
 
-    # one clip per rank (different seeds), pre-staged on the device; frames cycle, pos_id keeps counting
+    # one clip per handle (different seeds), pre-staged on the device; frames cycle, pos_id keeps counting
     NF = 8
-    clip = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=100 + rank)]
+    clips = [[torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=100 + rank + 1000 * c)] for c in range(C)]
+    clip = clips[0]
     t_frame = 0
 
     def step():
         nonlocal t_frame
-        out = model(clip[t_frame % NF], pos_id=t_frame % P)
+        out = None
+        for c in range(C):
+            with torch.cuda.stream(streams[c]):
+                o = models[c](clips[c][t_frame % NF], pos_id=t_frame % P)
+            out = o if out is None else out
         t_frame += 1
         return out
 
@@ -116,7 +131,7 @@ def main():
         parallel.barrier()
         dt = time.perf_counter() - t0
     tmax = parallel.allreduce_max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()
-    fps = world * args.steps / tmax
+    fps = world * C * args.steps / tmax
 
     mname = ("psp%s" if args.model == "psp" else args.model + "-psp%s") % args.backbone[6:]
     res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
@@ -124,15 +139,15 @@ def main():
            "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32" if args.precision == "fp32" else "f16 conv operands (fp32 accumulate, fp32 storage; attention/LN/PPM fp32)",
            "data": "synthetic",
-           "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, 1 clip per GPU"
-                                  % (mname, H, W, spec.fifo),
+           "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, %d clip%s per GPU"
+                                  % (mname, H, W, spec.fifo, C, "" if C == 1 else "s (concurrent HIP streams)"),
                       "parallelism": "clip-parallel x%d, RCCL weight broadcast only" % world, "target_fps_per_gpu": 30}}
 
     if rank == 0:
         eng = model.engine
         gflop = eng.flops_per_frame() / 1e9
         res["config"]["algorithmic_gflop_per_frame"] = round(gflop, 1)
-        res["config"]["frame_tflops"] = round(gflop * (args.steps / tmax) / 1e3, 2)
+        res["config"]["frame_tflops"] = round(gflop * (C * args.steps / tmax) / 1e3, 2)
         # ---- roofline of the dominant kernel: profiled replay (HIP events around every launch, same stream) ----------
         eng.set_profiling(True)
         acc = {k: [0.0, 0.0, 0.0] for k in (0, 1, 2, 3)}

@@ -135,8 +135,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     load_k(cw * 32, kf);
     for (int st = 0; st < nsuper; ++st) {
         const int kbase = st * SK, kb = kbase + cw * 32;
-        f32x4 bb[2][4];
+        f32x4 bb[3][4];                                           // V' groups G+1, G+2 in flight while G is multiplied
         load_v(kbase, 0, bb[0]);                                  // in flight under the 32 score MFMAs
+        load_v(kbase, 1, bb[1]);
         const f32x16 s = score_tile(kf);
         f32x16 pr;
 #pragma unroll
@@ -156,13 +157,13 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         if (st + 1 < nsuper) load_k(kb + SK, kf);                 // next key tile, hidden under the P V' MFMAs
 #pragma unroll
         for (int G = 0; G < 4 * CW; ++G) {
-            if (G + 1 < 4 * CW) load_v(kbase, G + 1, bb[(G + 1) & 1]);
+            if (G + 2 < 4 * CW) load_v(kbase, G + 2, bb[(G + 2) % 3]);
             const f32x4 a4 = td_ld4(Pw + ((2 * G + half) * 32 + l31) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = td_mfma32(a4[e], bb[G & 1][e][j], acc[j]);
-            if (G + 1 < 4 * CW) { TD_SCHED_GROUP(0x020, 4); TD_SCHED_GROUP(0x100, 1); }
+                for (int j = 0; j < NT; ++j) acc[j] = td_mfma32(a4[e], bb[G % 3][e][j], acc[j]);
+            if (G + 2 < 4 * CW) { TD_SCHED_GROUP(0x020, 4); TD_SCHED_GROUP(0x100, 1); }
             TD_SCHED_GROUP(0x008, 4 * NT);
         }
     }
