@@ -58,6 +58,25 @@ int  tdnet_forward_labels(tdnet_t* h, const float* img_nchw_dev, int pos_id, int
 int  tdnet_reset(tdnet_t* h);
 int  tdnet_fifo_len(const tdnet_t* h);
 
+/* ---- split frame + cache transport: path-parallel single stream (SURVEY 8e "alternative" / 8f-N4) ----------------
+ * tdnet_forward == tdnet_encode followed by tdnet_propagate.  The split exists so that W GPUs can serve ONE video
+ * stream, GPU g taking the frames t = g (mod W): the cache entry (q,k,v) a frame contributes to its successors
+ * (Encoding pre=True, transformer.py:34-50; pushed by buffer_contral td4_psp18.py:123-134) exists after tdnet_encode,
+ * is read out with tdnet_cache_export, travels to the peers (one all-gather per round over xGMI), and is inserted into
+ * their FIFOs with tdnet_cache_push in frame order; tdnet_propagate then runs attention propagation + head against
+ * the FIFO as it stands and commits the frame's own entry.  All calls are stream-ordered on `stream`.                */
+/* backbone + pyramid slice + Encoding of one frame; leaves its cache entry pending (td4_psp18.py:138-140,153).     */
+int  tdnet_encode(tdnet_t* h, const float* img_nchw_dev, int pos_id, void* stream);
+/* attention propagation + LayerNorm + head + x8 upsample of the pending frame (td4_psp18.py:142-152), then FIFO push */
+int  tdnet_propagate(tdnet_t* h, float* logits_nchw_dev, void* stream);
+int  tdnet_propagate_labels(tdnet_t* h, int32_t* labels_dev, void* stream);
+/* cache entry geometry: q,k are [Lk,dk], v is [Lk,dv] fp32                                                         */
+int  tdnet_cache_dims(const tdnet_t* h, int* Lk, int* dk, int* dv);
+/* copy the pending frame's entry into caller-owned device buffers                                                  */
+int  tdnet_cache_export(tdnet_t* h, float* q_dev, float* k_dev, float* v_dev, void* stream);
+/* append an entry computed by a peer to the FIFO (oldest entry drops out when the FIFO is full)                    */
+int  tdnet_cache_push(tdnet_t* h, const float* q_dev, const float* k_dev, const float* v_dev, void* stream);
+
 /* ---- introspection for the parity tests ------------------------------------------------------------------------ */
 /* Copies an internal stage buffer of the LAST frame to host, converted to the reference's layout
  * (NCHW for maps, [L,C] for q/k/v).  names: c4 z q_cur v_cur feat ln lowres cache_q cache_k cache_v.

@@ -33,6 +33,12 @@ SYMBOLS = {
     "tdnet_forward_labels": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
     "tdnet_reset": (ctypes.c_int, [c_void_p]),
     "tdnet_fifo_len": (ctypes.c_int, [c_void_p]),
+    "tdnet_encode": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p]),
+    "tdnet_propagate": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    "tdnet_propagate_labels": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    "tdnet_cache_dims": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "tdnet_cache_export": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tdnet_cache_push": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_get_stage": (ctypes.c_long, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "tdnet_flops_per_frame": (ctypes.c_double, [c_void_p]),
     "tdnet_set_profiling": (ctypes.c_int, [c_void_p, ctypes.c_int]),

@@ -211,6 +211,8 @@ struct tdnet {
     std::vector<CacheSlot> slots;
     std::vector<int> fifo;                                             // slot ids, oldest first
     int last_slot = -1;
+    int pending_slot = -1;                                             // cache entry of an encoded, not yet propagated frame
+    int pending_pos = -1;
     // profiling
     // cache-only work (V' GEMMs + the two cached-frame attention steps) runs on a side stream under the backbone
     hipStream_t side = nullptr;
@@ -459,7 +461,7 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
-    n->slots.resize(n->FIFO + 1);
+    n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
     return 0;
@@ -737,32 +739,50 @@ static void launch_upsample(const float* in, int C, int h, int w, int H, int W, 
 }
 
 // low-resolution logits of one frame (planar [nclass][h*w]) + FIFO update
-static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
-    if (!n->finalized) return td_fail("tdnet_forward: weights not finalized (the HIP path never runs on random init)");
-    if (pos_id < 0 || pos_id >= n->P) return td_fail("tdnet_forward: pos_id %d out of range 0..%d", pos_id, n->P - 1);
-    PathLayers& L = n->paths[pos_id];
-    n->nrec = 0;
-    n->failed = false;
-    const int DV = n->DV;
-    // ---- fork: everything that depends only on CACHED frames (td4_psp18.py:145-146 and the fc of :147) runs on the side
-    // stream while the backbone of the current frame runs on `s`; joined right before the final attention.
-    const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
-    if (steady) {
-        hipStream_t c = n->side;
-        TD_HIP(hipEventRecord(n->ev_fork, s));
-        TD_HIP(hipStreamWaitEvent(c, n->ev_fork, 0));
-        if (n->P == 4) {
-            const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
-            run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c);
-            if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c)) return -1;   // v2 + V[1]
-            run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c);
-            if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c)) return -1;   // v3 + V[2]
-            run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c);                                              // (v3 + V[2]) W^T
-        } else {
-            run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c);
-        }
-        TD_HIP(hipEventRecord(n->ev_join, c));
+// A frame is three pieces (td4_psp18.py:137-154):
+//   chain    everything that depends only on CACHED frames (:145-146 and the fc of :147) -- side stream, joined before the
+//            final attention;
+//   encode   backbone, pyramid slice, Encoding(pre=False) and Encoding(pre=True): ends with q_cur / v_cur and this frame's own
+//            cache entry in a PENDING slot (not yet in the FIFO);
+//   finish   final attention against the newest cached frame, plane LayerNorm, head, classifier; then the pending entry is
+//            committed to the FIFO (:153-154, :123-134).
+// tdnet_forward runs chain || encode, then finish.  tdnet_encode / tdnet_propagate expose the two halves so that a
+// path-parallel deployment can exchange cache entries between them.
+static int free_slot(tdnet* n) {
+    for (int i = 0; i < (int)n->slots.size(); ++i) {
+        bool used = i == n->pending_slot;
+        for (int f : n->fifo) used |= f == i;
+        if (!used) return i;
     }
+    return -1;
+}
+static void fifo_commit(tdnet* n, int slot) {
+    n->fifo.push_back(slot);
+    if ((int)n->fifo.size() > n->FIFO) n->fifo.erase(n->fifo.begin());
+    n->last_slot = slot;
+}
+
+static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
+    const int DV = n->DV;
+    hipStream_t c = n->side;
+    TD_HIP(hipEventRecord(n->ev_fork, s));
+    TD_HIP(hipStreamWaitEvent(c, n->ev_fork, 0));
+    if (n->P == 4) {
+        const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
+        run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c);
+        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c)) return -1;   // v2 + V[1]
+        run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c);
+        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c)) return -1;   // v3 + V[2]
+        run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c);                                              // (v3 + V[2]) W^T
+    } else {
+        run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c);
+    }
+    TD_HIP(hipEventRecord(n->ev_join, c));
+    return 0;
+}
+
+static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s) {
+    const int DV = n->DV;
     // backbone (resnet.py:204-215)
     run_stem_pre(n, img, n->H, n->W, n->img4, s);
     if (n->deep) {                                                     // resnet.py:122-131
@@ -803,6 +823,23 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s);
     run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s);
     run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, s);
+    // Encoding, pre=True (transformer.py:34-50) -> pending cache entry; q_ and v_ are the stride-4 subsample of q_cur / v_cur
+    const int slot = free_slot(n);
+    if (slot < 0) return td_fail("internal: no free cache slot");
+    CacheSlot& cs = n->slots[slot];
+    run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, s);
+    run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, s);
+    prof_begin(n, 2, false, 0, s);
+    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
+    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, s, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
+    prof_end(n, s);
+    n->pending_slot = slot;
+    return n->failed ? -1 : 0;
+}
+
+// chain_launched: launch_chain() already ran for this frame (it read the FIFO as it is now)
+static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
+    const int DV = n->DV;
     const float* feat = n->v_cur;
     if (steady) {
         TD_HIP(hipStreamWaitEvent(s, n->ev_join, 0));                   // join: v' of the newest cached frame is ready
@@ -818,25 +855,30 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
     run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, s);
     run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s);
     run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s);
-    // Encoding, pre=True (transformer.py:34-50) -> FIFO push (td4_psp18.py:153-154, :123-134)
-    int slot = -1;
-    for (int i = 0; i < (int)n->slots.size(); ++i) {
-        bool used = false;
-        for (int f : n->fifo) used |= f == i;
-        if (!used) { slot = i; break; }
-    }
-    if (slot < 0) return td_fail("internal: no free cache slot");
-    CacheSlot& cs = n->slots[slot];
-    run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, s);
-    run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, s);
-    prof_begin(n, 2, false, 0, s);
-    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
-    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, s, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
-    prof_end(n, s);
-    n->fifo.push_back(slot);
-    if ((int)n->fifo.size() > n->FIFO) n->fifo.erase(n->fifo.begin());
-    n->last_slot = slot;
+    // FIFO push (td4_psp18.py:153-154, :123-134)
+    const int slot = n->pending_slot;
+    n->pending_slot = -1;
+    fifo_commit(n, slot);
     return n->failed ? -1 : 0;
+}
+
+static int frame_checks(tdnet* n, int pos_id, const char* who) {
+    if (!n->finalized) return td_fail("%s: weights not finalized (the HIP path never runs on random init)", who);
+    if (pos_id < 0 || pos_id >= n->P) return td_fail("%s: pos_id %d out of range 0..%d", who, pos_id, n->P - 1);
+    return 0;
+}
+
+static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
+    if (frame_checks(n, pos_id, "tdnet_forward")) return -1;
+    if (n->pending_slot >= 0) return td_fail("tdnet_forward: a frame encoded with tdnet_encode is waiting for tdnet_propagate");
+    PathLayers& L = n->paths[pos_id];
+    n->nrec = 0;
+    n->failed = false;
+    const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
+    if (steady && launch_chain(n, L, s)) return -1;                    // overlaps the backbone below
+    if (encode_frame(n, L, img, s)) return -1;
+    if (n->cfg.model == 1) return 0;
+    return finish_frame(n, L, steady, s);
 }
 
 extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* logits, void* stream) {
@@ -866,10 +908,82 @@ extern "C" int tdnet_forward_labels(tdnet_t* n, const float* img, int pos_id, in
     TD_HIP(hipGetLastError());
     return 0;
 }
+// ---- split frame + cache transport (path-parallel single stream) ------------------------------------
+// Rank g of a path-parallel group serves the frames t = g (mod W): it encodes its frame as soon as the image is there, publishes
+// the resulting cache entry, receives the entries of the frames in between from its peers (in frame order) and only then
+// propagates.  The FIFO of every rank therefore holds exactly what the sequential td4_psp18.py:123-154 would hold.
+extern "C" int tdnet_encode(tdnet_t* n, const float* img, int pos_id, void* stream) {
+    if (!n || !img) return td_fail("tdnet_encode: null argument");
+    if (frame_checks(n, pos_id, "tdnet_encode")) return -1;
+    if (n->cfg.model == 1) return td_fail("tdnet_encode: pspnet has no temporal state; use tdnet_forward");
+    if (n->pending_slot >= 0) return td_fail("tdnet_encode: the previous encoded frame has not been propagated");
+    n->nrec = 0;
+    n->failed = false;
+    if (encode_frame(n, n->paths[pos_id], img, (hipStream_t)stream)) return -1;
+    n->pending_pos = pos_id;
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+static int propagate_lowres(tdnet* n, hipStream_t s) {
+    if (n->pending_slot < 0) return td_fail("tdnet_propagate: no encoded frame (call tdnet_encode first)");
+    PathLayers& L = n->paths[n->pending_pos];
+    const bool steady = (int)n->fifo.size() >= n->FIFO;
+    if (steady && launch_chain(n, L, s)) return -1;
+    return finish_frame(n, L, steady, s);
+}
+extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
+    if (!n || !logits) return td_fail("tdnet_propagate: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (propagate_lowres(n, s)) return -1;
+    launch_upsample(n->lowres, n->cfg.nclass, n->h, n->w, n->H, n->W, logits, s);
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int tdnet_propagate_labels(tdnet_t* n, int32_t* labels, void* stream) {
+    if (!n || !labels) return td_fail("tdnet_propagate_labels: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (propagate_lowres(n, s)) return -1;
+    TD_LAUNCH(k_upsample_argmax, dim3(td_grid_for((long)n->H * n->W)), dim3(256), 0, s, (const float*)n->lowres, labels, n->cfg.nclass,
+              n->h, n->w, n->H, n->W);
+    TD_HIP(hipGetLastError());
+    return 0;
+}
+extern "C" int tdnet_cache_dims(const tdnet_t* n, int* Lk, int* dk, int* dv) {
+    if (!n) return td_fail("tdnet_cache_dims: null handle");
+    if (n->cfg.model == 1) return td_fail("tdnet_cache_dims: pspnet has no cache");
+    if (Lk) *Lk = n->Lk;
+    if (dk) *dk = 64;
+    if (dv) *dv = n->DV;
+    return 0;
+}
+extern "C" int tdnet_cache_export(tdnet_t* n, float* q, float* k, float* v, void* stream) {
+    if (!n || !q || !k || !v) return td_fail("tdnet_cache_export: null argument");
+    if (n->pending_slot < 0) return td_fail("tdnet_cache_export: no encoded frame (call tdnet_encode first)");
+    const CacheSlot& c = n->slots[n->pending_slot];
+    hipStream_t s = (hipStream_t)stream;
+    TD_HIP(hipMemcpyAsync(q, c.q, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TD_HIP(hipMemcpyAsync(k, c.k, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TD_HIP(hipMemcpyAsync(v, c.v, (size_t)n->Lk * n->DV * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+extern "C" int tdnet_cache_push(tdnet_t* n, const float* q, const float* k, const float* v, void* stream) {
+    if (!n || !q || !k || !v) return td_fail("tdnet_cache_push: null argument");
+    if (n->cfg.model == 1) return td_fail("tdnet_cache_push: pspnet has no cache");
+    const int slot = free_slot(n);
+    if (slot < 0) return td_fail("internal: no free cache slot");
+    const CacheSlot& c = n->slots[slot];
+    hipStream_t s = (hipStream_t)stream;
+    TD_HIP(hipMemcpyAsync(c.q, q, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TD_HIP(hipMemcpyAsync(c.k, k, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    TD_HIP(hipMemcpyAsync(c.v, v, (size_t)n->Lk * n->DV * sizeof(float), hipMemcpyDeviceToDevice, s));
+    fifo_commit(n, slot);
+    return 0;
+}
 extern "C" int tdnet_reset(tdnet_t* n) {
     if (!n) return td_fail("tdnet_reset: null handle");
     n->fifo.clear();
     n->last_slot = -1;
+    n->pending_slot = n->pending_pos = -1;
     return 0;
 }
 extern "C" int tdnet_fifo_len(const tdnet_t* n) { return n ? (int)n->fifo.size() : -1; }

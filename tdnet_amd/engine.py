@@ -55,6 +55,28 @@ class Engine:
     def forward_labels(self, img_ptr, pos_id, labels_ptr, stream=None):
         self.lib.check(self.lib.tdnet_forward_labels(self.h, _ptr(img_ptr), int(pos_id), _ptr(labels_ptr), stream))
 
+    # ---- split frame + cache transport (path-parallel single stream; include/tdnet.h) ----
+    def encode(self, img_ptr, pos_id, stream=None):
+        self.lib.check(self.lib.tdnet_encode(self.h, _ptr(img_ptr), int(pos_id), stream))
+
+    def propagate(self, logits_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_propagate(self.h, _ptr(logits_ptr), stream))
+
+    def propagate_labels(self, labels_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_propagate_labels(self.h, _ptr(labels_ptr), stream))
+
+    def cache_dims(self):
+        import ctypes
+        lk, dk, dv = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.lib.check(self.lib.tdnet_cache_dims(self.h, ctypes.byref(lk), ctypes.byref(dk), ctypes.byref(dv)))
+        return lk.value, dk.value, dv.value
+
+    def cache_export(self, q_ptr, k_ptr, v_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_cache_export(self.h, _ptr(q_ptr), _ptr(k_ptr), _ptr(v_ptr), stream))
+
+    def cache_push(self, q_ptr, k_ptr, v_ptr, stream=None):
+        self.lib.check(self.lib.tdnet_cache_push(self.h, _ptr(q_ptr), _ptr(k_ptr), _ptr(v_ptr), stream))
+
     def argmax(self, logits_ptr, labels_ptr, stream=None):
         self.lib.check(self.lib.tdnet_argmax(self.h, _ptr(logits_ptr), _ptr(labels_ptr), stream))
 

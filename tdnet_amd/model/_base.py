@@ -124,6 +124,48 @@ class _TDNetBase(nn.Module):
         eng.forward_labels(img.data_ptr(), pos_id, out.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
         return out
 
+    # ---- split frame + cache transport (path-parallel single stream: parallel.PathParallelStream) ------------------
+    def _check_cuda(self, img):
+        if not torch.is_tensor(img) or img.dim() != 4 or img.shape[1] != 3 or img.shape[0] != 1:
+            raise RuntimeError("expected an image tensor [1,3,H,W]")
+        if img.device.type != "cuda":
+            raise TdnetError("tdnet_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % img.device.type)
+
+    def encode(self, img, pos_id=0):
+        """First half of forward(): backbone + pyramid slice + Encoding; the frame's cache entry is left pending."""
+        self._check_cuda(img)
+        if pos_id not in range(self.path_num):
+            raise RuntimeError("pos_id must be t mod %d" % self.path_num)
+        img = img.contiguous().float()
+        eng = self._get_engine(img)
+        self._pending_shape = (img.shape[2], img.shape[3], img.device)
+        eng.encode(img.data_ptr(), pos_id, torch.cuda.current_stream(img.device).cuda_stream)
+
+    def propagate(self, labels=False):
+        """Second half of forward() for the pending frame, against the FIFO as it stands; returns logits (or int32 labels)."""
+        H, W, dev = self._pending_shape
+        s = torch.cuda.current_stream(dev).cuda_stream
+        if labels:
+            out = torch.empty((1, H, W), device=dev, dtype=torch.int32)
+            self._engine.propagate_labels(out.data_ptr(), s)
+        else:
+            out = torch.empty((1, self.nclass, H, W), device=dev, dtype=torch.float32)
+            self._engine.propagate(out.data_ptr(), s)
+        return out
+
+    def cache_entry_numel(self):
+        """(q, k, v) element counts of one cache entry: [Lk,64], [Lk,64], [Lk,d_v]."""
+        lk, dk, dv = self._engine.cache_dims()
+        return lk * dk, lk * dk, lk * dv
+
+    def cache_export(self, q, k, v):
+        """Copy the pending frame's cache entry into the given contiguous fp32 CUDA tensors."""
+        self._engine.cache_export(q.data_ptr(), k.data_ptr(), v.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
+
+    def cache_push(self, q, k, v):
+        """Append a peer's cache entry to the FIFO (contiguous fp32 CUDA tensors)."""
+        self._engine.cache_push(q.data_ptr(), k.data_ptr(), v.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
+
     def reset(self):
         if self._engine is not None:
             self._engine.reset()

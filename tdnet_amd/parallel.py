@@ -4,6 +4,10 @@ A clip's only state is its own K/Q/V FIFO (td4_psp18.py:118-134), so ranks never
 collectives are: ONE broadcast of the flat fp32 weight blob from rank 0 (RCCL over xGMI; 219 MB for td4) at start, and
 small all-reduces of the 19x19 confusion matrix / timing at the end.  Backend "nccl" is RCCL on ROCm; the CPU tests run
 the same code over gloo with world_size 2.
+
+PathParallelStream is the other mode of SURVEY.md §8e (row N4): ONE video stream served by W ranks, rank g taking the frames
+t = g (mod W).  That path has a real exchange step -- every frame's (q,k,v) cache entry, 5.2 MB at 1024x2048 -- and it is the
+only per-frame collective in the package: one all-gather of W entries per round of W frames.
 """
 import os
 
@@ -76,3 +80,75 @@ def allreduce_max(t):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+class PathParallelStream:
+    """One video stream on W ranks (SURVEY.md §8e "alternative", §8f N4).
+
+    Frame t is served by rank t mod W with sub-network t mod P.  What frame t needs from its predecessors is only their cache
+    entries (td4_psp18.py:145-147 read K/V/Q_queue; :153-154 push), and an entry exists as soon as its frame is ENCODED
+    (backbone + Encoding), before any attention.  So a round of W consecutive frames is:
+        1. every rank encodes its own frame (all W backbones run concurrently) and exports the entry;
+        2. ONE exchange: all-gather of the W entries (RCCL over xGMI; W broadcasts on backends without GPU all-gather);
+        3. every rank walks the round in frame order: pushes the entries of the frames before its own, propagates its own
+           frame (attention chain + head; this commits its own entry), pushes the entries after its own.
+    Every rank's FIFO therefore goes through exactly the states of the sequential loop (test.py:45-53), outputs are
+    bit-identical to one GPU serving the stream, and W frames finish in about one frame's latency.
+
+    `stage` is duck-typed (the model classes of tdnet_amd.model implement it): encode(img, pos_id), propagate(labels=) -> out,
+    cache_entry_numel() -> (nq, nk, nv), cache_export(q, k, v), cache_push(q, k, v).
+    """
+
+    def __init__(self, stage, path_num, rank=None, world=None, device=None):
+        self.stage, self.P = stage, path_num
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.device = device
+        self._buf = None
+
+    def owner(self, t):
+        return t % self.world
+
+    def _buffers(self):
+        if self._buf is None:
+            nq, nk, nv = self.stage.cache_entry_numel()
+            self._sizes = (nq, nk, nv)
+            self._buf = torch.zeros(self.world, nq + nk + nv, dtype=torch.float32, device=self.device)
+        return self._buf
+
+    def _split(self, row):
+        nq, nk, nv = self._sizes
+        return row[:nq], row[nq:nq + nk], row[nq + nk:]
+
+    def _exchange(self, buf, n_valid):
+        """Row j of `buf` is rank j's entry; after the call every rank holds rows 0..n_valid-1."""
+        if self.world == 1:
+            return
+        if dist.get_backend() == "nccl" and n_valid == self.world:
+            dist.all_gather_into_tensor(buf.view(-1), buf[self.rank].clone())
+        else:
+            for j in range(n_valid):
+                dist.broadcast(buf[j], src=j)
+
+    def process(self, frames, labels=False):
+        """frames: the whole clip (sequence of [1,3,H,W] device tensors, or None for frames this rank does not own).
+        Returns {t: output} for the frames this rank served."""
+        T, W = len(frames), self.world
+        outs = {}
+        for r0 in range(0, T, W):
+            n_valid = min(W, T - r0)
+            mine = r0 + self.rank if self.rank < n_valid else None
+            if mine is not None:
+                self.stage.encode(frames[mine], pos_id=mine % self.P)
+            buf = self._buffers() if (mine is not None or self._buf is not None) else None
+            if buf is None:                                           # a rank that never owned a frame still needs the geometry
+                raise RuntimeError("rank %d owns no frame of the first round: feed at least world_size frames" % self.rank)
+            if mine is not None:
+                self.stage.cache_export(*self._split(buf[self.rank]))
+            self._exchange(buf, n_valid)
+            for j in range(n_valid):
+                if j == self.rank:
+                    outs[mine] = self.stage.propagate(labels=labels)
+                else:
+                    self.stage.cache_push(*self._split(buf[j]))
+        return outs

@@ -53,3 +53,80 @@ def test_two_rank_gloo():
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]          # every clip exactly once
     assert res[0][3] == res[1][3] == 21                            # summed confusion matrix
     assert res[0][4] == res[1][4] == 2.0                           # max over ranks
+
+
+# ---- path-parallel single stream (parallel.PathParallelStream): the exchange schedule, on a CPU stand-in for the engine ----
+class _ToyStage:
+    """Same FIFO semantics as the handle (td4_psp18.py:123-154): entries are pushed in frame order, the output of a frame is a
+    function of the FIFO contents at propagate time and of the frame itself, and propagate commits the frame's own entry."""
+
+    def __init__(self, fifo_depth, n=7):
+        self.depth, self.n, self.fifo, self.pending = fifo_depth, n, [], None
+
+    def encode(self, img, pos_id=0):
+        assert self.pending is None
+        f = float(img.sum())
+        self.pending = (torch.full((self.n,), f), torch.full((self.n,), f + 0.25 * pos_id), torch.full((2 * self.n,), -f))
+        self.cur = (f, pos_id)
+
+    def cache_entry_numel(self):
+        return self.n, self.n, 2 * self.n
+
+    def cache_export(self, q, k, v):
+        for dst, src in zip((q, k, v), self.pending):
+            dst.copy_(src)
+
+    def _commit(self, e):
+        self.fifo.append(e)
+        if len(self.fifo) > self.depth:
+            self.fifo.pop(0)
+
+    def cache_push(self, q, k, v):
+        self._commit((q.clone(), k.clone(), v.clone()))
+
+    def propagate(self, labels=False):
+        acc = self.cur[0] * 1000.0 + self.cur[1]
+        if len(self.fifo) >= self.depth:                               # warm-up frames ignore the cache
+            for i, (q, k, v) in enumerate(self.fifo):
+                acc += (i + 1) * float(q[0]) + 10.0 * (i + 1) * float(k[0]) + 100.0 * (i + 1) * float(v[0])
+        self._commit(self.pending)
+        self.pending = None
+        return torch.tensor([acc], dtype=torch.float64)
+
+
+def _toy_frames(T):
+    return [torch.full((1, 3, 2, 2), float(t + 1)) for t in range(T)]
+
+
+def _pp_worker(rank, world, port, q, T, P, depth):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    pp = parallel.PathParallelStream(_ToyStage(depth), P, device=torch.device("cpu"))
+    outs = pp.process(_toy_frames(T))
+    q.put((rank, {t: float(o) for t, o in outs.items()}))
+    dist.destroy_process_group()
+
+
+def _pp_sequential(T, P, depth):
+    st, out = _ToyStage(depth), {}
+    for t, f in enumerate(_toy_frames(T)):
+        st.encode(f, t % P)
+        out[t] = float(st.propagate())
+    return out
+
+
+def test_path_parallel_schedule_matches_sequential():
+    ctx = mp.get_context("spawn")
+    for (T, P, depth) in ((9, 4, 3), (6, 2, 1)):                       # td4 (FIFO 3) with a ragged last round; td2 (FIFO 1)
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_pp_worker, args=(r, 2, port, q, T, P, depth)) for r in range(2)]
+        for p in ps:
+            p.start()
+        res = dict(q.get(timeout=300) for _ in ps)
+        for p in ps:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(res[0]) == list(range(0, T, 2)) and sorted(res[1]) == list(range(1, T, 2))   # rank g serves t = g mod 2
+        merged = {**res[0], **res[1]}
+        assert merged == _pp_sequential(T, P, depth)                   # every rank's FIFO went through the sequential states

@@ -156,3 +156,58 @@ def test_persistent_gemm_multi_tile(lib):
     finally:
         lib.tdnet_set_gemm_persistent(1)
         lib.tdnet_set_conv_winograd(1)
+
+
+@pytest.mark.parametrize("name,T", [("td4", 7), ("td2", 4)])
+def test_split_frame_and_cache_transport_equal_the_single_handle_stream(lib, name, T):
+    """include/tdnet.h split API: two handles play two path-parallel ranks (frames t = g mod 2), exchanging cache entries
+    with tdnet_cache_export / tdnet_cache_push in the order of parallel.PathParallelStream.  Outputs and FIFO states must be
+    BIT-identical to one handle running tdnet_forward over the stream."""
+    H, W, bb = 33, 65, "resnet18"
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    sd = weights.synth_state_dict(spec, h, w, 0)
+    frames = weights.synth_video(H, W, T, seed=3)
+    one = Engine(spec.path_num, 18, 19, H, W, 0, lib=lib)
+    one.load_state_dict(sd)
+    ref = []
+    for t, x in enumerate(frames):
+        out = np.zeros((1, 19, H, W), np.float32)
+        one.forward(x, t % spec.path_num, out)
+        ref.append(out)
+    ranks = [Engine(spec.path_num, 18, 19, H, W, 0, lib=lib) for _ in range(2)]
+    for e in ranks:
+        e.load_state_dict(sd)
+    lk, dk, dv = ranks[0].cache_dims()
+    assert (lk, dk, dv) == (arch.key_size(h) * arch.key_size(w), 64, spec.d_v)
+    got = {}
+    for r0 in range(0, T, 2):
+        n_valid = min(2, T - r0)
+        entries = []
+        for g in range(n_valid):                                                  # 1. every rank encodes its own frame
+            ranks[g].encode(frames[r0 + g], (r0 + g) % spec.path_num)
+            q, k, v = np.zeros((lk, dk), np.float32), np.zeros((lk, dk), np.float32), np.zeros((lk, dv), np.float32)
+            ranks[g].cache_export(q, k, v)                                        # 2. the exchange
+            entries.append((q, k, v))
+        for g in range(n_valid):                                                  # 3. walk the round in frame order
+            for j in range(n_valid):
+                if j == g:
+                    out = np.zeros((1, 19, H, W), np.float32)
+                    ranks[g].propagate(out)
+                    got[r0 + g] = out
+                else:
+                    ranks[g].cache_push(*entries[j])
+    for t in range(T):
+        assert np.array_equal(got[t], ref[t]), t
+    # the split halves on ONE handle are tdnet_forward; a second encode before propagate is refused, as is a stray propagate
+    one.reset()
+    out = np.zeros((1, 19, H, W), np.float32)
+    one.encode(frames[0], 0)
+    with pytest.raises(Exception):
+        one.encode(frames[1], 1 % spec.path_num)
+    one.propagate(out)
+    with pytest.raises(Exception):
+        one.propagate(out)
+    assert np.array_equal(out, ref[0])
+    for e in ranks + [one]:
+        e.close()
