@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips served concurrently by one GPU, each with its own handle/FIFO on its own HIP stream "
                          "(throughput mode; a step is then one frame of EVERY clip).  Default 1 = BASELINE's one clip per GPU")
+    ap.add_argument("--mode", default="clips", choices=["clips", "path-parallel"],
+                    help="clips (default, BASELINE): independent clips, one per GPU, no per-frame communication | path-parallel: ONE "
+                         "stream served by all N ranks, rank g takes frames t = g (mod N), one all-gather of cache entries per round "
+                         "of N frames (a step is then one round)")
     args = ap.parse_args()
     H, W = (int(v) for v in args.size.lower().split("x"))
 
@@ -109,8 +113,18 @@ def main():
     clip = clips[0]
     t_frame = 0
 
+    pp = parallel.PathParallelStream(model, P, rank=rank, world=world, device=dev) if args.mode == "path-parallel" else None
+    if pp is not None:
+        clip = clips[0] = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=100)]   # the SAME stream on every rank
+        C = 1
+
     def step():
         nonlocal t_frame
+        if pp is not None:                                            # one round: frames t_frame .. t_frame + world - 1
+            # PathParallelStream.process keeps pos_id = t mod P only if rounds start at multiples of lcm(world, P): NF = 8 does
+            out = pp.process([clip[(t_frame + j) % NF] for j in range(world)], first_frame=t_frame)
+            t_frame += world
+            return out
         out = None
         for c in range(C):
             with torch.cuda.stream(streams[c]):
@@ -141,7 +155,11 @@ def main():
            "data": "synthetic",
            "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, %d clip%s per GPU"
                                   % (mname, H, W, spec.fifo, C, "" if C == 1 else "s (concurrent HIP streams)"),
-                      "parallelism": "clip-parallel x%d, RCCL weight broadcast only" % world, "target_fps_per_gpu": 30}}
+                      "parallelism": ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else
+                                     ("path-parallel x%d: one stream, one all-gather of %d cache entries per round" % (world, world)),
+                      "target_fps_per_gpu": 30}}
+    if pp is not None:
+        res["scaling"] = "strong"
 
     if rank == 0:
         eng = model.engine

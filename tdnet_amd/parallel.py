@@ -130,16 +130,19 @@ class PathParallelStream:
             for j in range(n_valid):
                 dist.broadcast(buf[j], src=j)
 
-    def process(self, frames, labels=False):
-        """frames: the whole clip (sequence of [1,3,H,W] device tensors, or None for frames this rank does not own).
-        Returns {t: output} for the frames this rank served."""
+    def process(self, frames, labels=False, first_frame=0):
+        """frames: consecutive frames of the stream (sequence of [1,3,H,W] device tensors, or None for frames this rank does
+        not own); frames[i] is frame number first_frame + i of the stream (first_frame a multiple of world_size).
+        Returns {i: output} for the frames this rank served."""
         T, W = len(frames), self.world
+        if first_frame % W:
+            raise ValueError("first_frame must be a multiple of world_size")
         outs = {}
         for r0 in range(0, T, W):
             n_valid = min(W, T - r0)
             mine = r0 + self.rank if self.rank < n_valid else None
             if mine is not None:
-                self.stage.encode(frames[mine], pos_id=mine % self.P)
+                self.stage.encode(frames[mine], pos_id=(first_frame + mine) % self.P)
             buf = self._buffers() if (mine is not None or self._buf is not None) else None
             if buf is None:                                           # a rank that never owned a frame still needs the geometry
                 raise RuntimeError("rank %d owns no frame of the first round: feed at least world_size frames" % self.rank)
