@@ -146,13 +146,14 @@ def test_persistent_gemm_multi_tile(lib):
         for cap in (1, 3, 5, 8, 11):
             lib.tdnet_set_gemm_persistent(cap if cap > 1 else 2)
             for tile in (3, 4, 5):
-                opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True, tile)      # 3 K steps, ragged M and N
-                opcheck.conv(lib, MEM, 40, 40, 32, 64, 1, 1, 1, 0, False, tile)      # 1 K step per tile
+                opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True, tile)     # 4 K steps of 32, ragged M and N
+                opcheck.conv(lib, MEM, 40, 40, 64, 64, 1, 1, 1, 0, False, tile)      # one period per tile
+                opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True, tile)      # K = 96: odd step count -> single-tile kernel
             lib.tdnet_set_conv_winograd(2)
             opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True)                # 16 batches x tiles over few workgroups
             lib.tdnet_set_conv_winograd(1)
         lib.tdnet_set_gemm_persistent(0)                                              # the non-persistent fallback stays correct
-        opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True)
+        opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True)
     finally:
         lib.tdnet_set_gemm_persistent(1)
         lib.tdnet_set_conv_winograd(1)

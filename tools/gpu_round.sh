@@ -13,6 +13,13 @@ timeout 300 python bench.py --size 769x1537 --steps 40 > $R/bench_native.log 2>&
 timeout 300 python bench.py --model td2 --backbone resnet50 --size 769x1537 --steps 40 > $R/bench_td2psp50.log 2>&1
 timeout 300 python bench.py --model td2 --backbone resnet34 --size 720x960 --steps 40 > $R/bench_td2psp34.log 2>&1
 timeout 300 python bench.py --model psp --size 769x1537 --steps 30 --cpu-frames 1 > $R/bench_psp101.log 2>&1
+timeout 300 python bench.py --clips-per-gpu 3 --steps 30 --no-cpu-baseline > $R/bench_3clips.log 2>&1
+timeout 300 python bench.py --mode path-parallel --steps 40 --no-cpu-baseline > $R/bench_pathparallel_n1.log 2>&1
+timeout 300 python bench.py --model td2 --backbone resnet34 --size 720x960 --steps 40 --precision fp16 > $R/bench_td2psp34_fp16.log 2>&1
+timeout 300 python bench.py --precision fp16 --steps 40 > $R/bench_td4_fp16.log 2>&1
+timeout 120 python tools/attn_probe.py > $R/attn_probe.log 2>&1
+timeout 120 python tools/wino_probe.py > $R/wino_probe.log 2>&1
+timeout 120 python tools/gemm_k_probe.py > $R/gemm_k_probe.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 6 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$R/prof" -o r1 -- $B > "$GRAFT_REPO_ROOT/$R/prof.log" 2>&1
