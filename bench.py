@@ -170,6 +170,8 @@ def main():
         eng.set_profiling(True)
         acc = {k: [0.0, 0.0, 0.0] for k in (0, 1, 2, 3)}
         nprof = 2 * P
+        C_timed, C = C, 1                                             # the replay runs clip 0 alone: per-launch durations, no co-running streams
+        torch.cuda.synchronize(dev)
         with torch.no_grad():
             for _ in range(nprof):
                 step()
