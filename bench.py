@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch (default: library default)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="steady-state frames timed on the CPU oracle")
-    ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4, 2 everywhere (default: library default)")
+    ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4 + head, 3 Winograd F(4x4,3x3) for them (default: library default)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16-input MFMA convs, fp32 accumulate "
                          "(BASELINE config 5); parity vs the fp32 CPU path is reported, not gated")
@@ -187,10 +187,12 @@ def main():
             cfgbits = _capi.lib().tdnet_get_conv_config()
             if cfgbits & 2:
                 kname, peak = "k_conv_igemm_h<128,128,2,2,3> (3x3 dilated conv, fp16-input MFMA, fp32 accumulate)", 2500.0
-            elif (cfgbits >> 2) & 3:
-                gk = "k_gemm_persistent<128,128,2,2>" if (cfgbits >> 4) & 1 else "k_conv_igemm<128,128,2,2,1>"
-                kname, peak = (gk + " x16 (batched GEMM of the Winograd F(2x2,3x3) convs of layers 3-4 + head, "
-                               "fp32 MFMA; FLOP = executed GEMM FLOP, 2.25x fewer than the direct conv's)"), PEAK_FP32_MFMA_TFLOPS
+            elif (cfgbits >> 2) & 7:
+                gk = "k_gemm_persistent" if (cfgbits >> 5) & 1 else "k_conv_igemm<.,.,.,.,1>"
+                f4 = ((cfgbits >> 2) & 7) >= 3
+                kname, peak = (gk + " x%d (batched GEMM of the Winograd F(%s,3x3) convs of layers 3-4 + head, "
+                               "fp32 MFMA; FLOP = executed GEMM FLOP, %sx fewer than the direct conv's)"
+                               % ((36, "4x4", "4") if f4 else (16, "2x2", "2.25"))), PEAK_FP32_MFMA_TFLOPS
             else:
                 kname, peak = "k_conv_igemm<128,128,2,2,3> (3x3 dilated conv, fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS
             res["roofline"] = {"bound": "mfma", "kernel": kname,

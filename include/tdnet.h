@@ -103,10 +103,13 @@ int tdnet_set_conv_precision(int fp16);
  * workgroups that share a CU.                                                                                       */
 int tdnet_set_conv_stagger(int units);
 /* Conv algorithm (process-wide, handles finalized after the call): 0 = direct implicit GEMM everywhere,
- * 1 (default) = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4 and the
- * FCN head), 2 = for every stride-1 3x3.  All modes are fp32 and meet the 1e-3 logits gate.                              */
+ * 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4 and the FCN head),
+ * 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) = Winograd F(4x4,3x3) for the stride-1 3x3 convs with
+ * Cin >= 128 and Cout >= 128 (ResNet layers 2-4 and the FCN head), 4 = F(4x4,3x3) for every stride-1 3x3 (test hook).
+ * All modes are fp32 and meet the 1e-3 logits gate.                                                                  */
+#define TDNET_WINOGRAD_DEFAULT 3
 int tdnet_set_conv_winograd(int mode);
-/* Current process-wide conv configuration: bit 0 two-stage pipeline, bit 1 fp16-input MFMA, bits 2-3 Winograd mode, bit 4 persistent GEMM. */
+/* Current process-wide conv configuration: bit 0 two-stage pipeline, bit 1 fp16-input MFMA, bits 2-4 Winograd mode, bit 5 persistent GEMM. */
 int tdnet_get_conv_config(void);
 /* Tuning hook: 1 (default) = stride-1 1x1 convs and the Winograd GEMMs run on the persistent multi-tile GEMM kernel,
  * 0 = on the one-tile-per-workgroup conv kernel.                                                                     */

@@ -23,6 +23,8 @@ class TdnetError(RuntimeError):
 
 
 # name -> (restype, argtypes); every symbol include/tdnet.h declares
+WINOGRAD_DEFAULT = 3          # include/tdnet.h TDNET_WINOGRAD_DEFAULT: F(4x4,3x3) for the wide stride-1 3x3 convs
+
 SYMBOLS = {
     "tdnet_create": (ctypes.c_int, [ctypes.POINTER(TdnetCfg), ctypes.POINTER(c_void_p)]),
     "tdnet_destroy": (None, [c_void_p]),

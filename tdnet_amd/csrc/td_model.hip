@@ -94,7 +94,7 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
-    bool wino = false;                                                 // Winograd F(2x2,3x3): d_wp = 16 packed 1x1 weight sets (td_wino.h)
+    int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3)): d_wp = (m+2)^2 packed 1x1 weight sets (td_wino.h)
     float* d_zero = nullptr;                                           // zero bias for the batched GEMM pass
     ConvTile tile = CT_128x128;
     int CoutPad = 0, nsteps = 0;
@@ -108,7 +108,7 @@ static int g_gemm_persistent = 1;
 // 0 = direct convs only, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4
 // and the FCN head), 2 = every stride-1 3x3 conv.  Default 1: measured +20 % frames/s at 1024x2048, +23 % at 769x1537, with
 // logits as close to the fp32 CPU path as the direct kernels' (profiles/r01f_*).
-static int g_conv_wino = 1;
+static int g_conv_wino = TDNET_WINOGRAD_DEFAULT;
 
 static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2 * pad - dil * (KS - 1) - 1) / stride + 1; }
 
@@ -118,18 +118,20 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
-    L.wino = g_conv_wino && !g_conv_fp16 && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
-             (g_conv_wino >= 2 || (Cin >= 256 && Cout >= 128));
+    const bool wino_ok = g_conv_wino && !g_conv_fp16 && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
+                         (g_conv_wino == 2 || g_conv_wino == 4 || (Cin >= (g_conv_wino == 3 ? 128 : 256) && Cout >= 128));
+    L.wino = !wino_ok ? 0 : g_conv_wino >= 3 ? 4 : 2;
     if (L.wino) {
-        // 16 batched [T x Cin] x [Cin x Cout] GEMMs: 16 * T = 4 * M rows in total -> pick the tile for that many workgroups
-        L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)std::min<long>(4 * M, 1 << 30), Cout);
+        // nb = (m+2)^2 batched [T x Cin] x [Cin x Cout] GEMMs, T = M / m^2 tiles: nb * T rows in total -> pick the tile for that many workgroups
+        const int nb = (L.wino + 2) * (L.wino + 2);
+        L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout);
         L.CoutPad = conv_cout_pad(Cout, L.tile);
         L.nsteps = conv_nsteps(Cin, 1, false);
         std::vector<std::vector<float>> U;
-        wino_transform_weights(w.data(), Cout, Cin, U);
+        wino_transform_weights(w.data(), Cout, Cin, L.wino, U);
         const size_t per = (size_t)L.nsteps * 8 * L.CoutPad * 4;
-        std::vector<float> packed(16 * per);
-        for (int b16 = 0; b16 < 16; ++b16) conv_pack_weights(U[b16].data(), Cout, Cin, 1, false, L.tile, packed.data() + b16 * per);
+        std::vector<float> packed(nb * per);
+        for (int bi = 0; bi < nb; ++bi) conv_pack_weights(U[bi].data(), Cout, Cin, 1, false, L.tile, packed.data() + bi * per);
         TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(float)));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         std::vector<float> bb(Cout, 0.f), zz(Cout, 0.f);
@@ -435,12 +437,12 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->z, hw * ZC)) return -1;
     n->stage_tmp_floats = hw * ZC;
     if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass) || dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
-    {   // Winograd workspaces: the largest [16][T][C] over the layers that use it (all paths share them; one stream)
+    {   // Winograd workspaces: the largest [(m+2)^2][T][C] over the layers that use it (all paths share them; one stream)
         size_t vmax = 0, mmax = 0;
         auto upd = [&](const ConvLayer& L, int H, int W) {
             if (!L.wino) return;
-            const size_t T = (size_t)wino_tiles(H, W, L.dil);
-            vmax = std::max(vmax, 16 * T * L.Cin); mmax = std::max(mmax, 16 * T * L.Cout);
+            const size_t T = (size_t)wino_tiles(H, W, L.dil, L.wino), nb = (size_t)(L.wino + 2) * (L.wino + 2);
+            vmax = std::max(vmax, nb * T * L.Cin); mmax = std::max(mmax, nb * T * L.Cout);
         };
         const PathLayers& L0 = n->paths[0];
         if (n->deep) { upd(L0.stem2, n->H1, n->W1); upd(L0.stem3, n->H1, n->W1); }
@@ -620,36 +622,39 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
                     int* Ho_out = nullptr, int* Wo_out = nullptr) {
     const int Ho = out_size(H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(W, L.KS, L.stride, L.dil, L.pad);
     if (L.wino) {
-        const int TY = wino_tiles_1d(H, L.dil), TX = wino_tiles_1d(W, L.dil);
+        const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
         const long T = (long)L.dil * L.dil * TY * TX;
+        const int nb = (L.wino + 2) * (L.wino + 2);
         float *V = nullptr, *Mb = nullptr;
-        const bool own = n == nullptr || n->wino_v_floats < (size_t)16 * T * L.Cin || n->wino_m_floats < (size_t)16 * T * L.Cout;
+        const bool own = n == nullptr || n->wino_v_floats < (size_t)nb * T * L.Cin || n->wino_m_floats < (size_t)nb * T * L.Cout;
         if (own) {
             if (n) { n->failed = true; return td_fail("internal: Winograd workspace too small"); }
-            if (dev_alloc(&V, (size_t)16 * T * L.Cin) || dev_alloc(&Mb, (size_t)16 * T * L.Cout)) return -1;
+            if (dev_alloc(&V, (size_t)nb * T * L.Cin) || dev_alloc(&Mb, (size_t)nb * T * L.Cout)) return -1;
         } else { V = n->wino_v; Mb = n->wino_m; }
         WinoArgs wa;
         wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
         wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act;
         prof_begin(n, 2, false, 0, s);
-        TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        if (L.wino == 4) TD_LAUNCH(k_wino4_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        else TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
         prof_end(n, s);
-        ConvArgs g;
-        g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
-        g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
-        g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = 16;
-        prof_begin(n, 0, 2, 2.0 * 16 * T * (double)L.Cin * L.Cout, s);
+        prof_begin(n, 0, 2, 2.0 * nb * T * (double)L.Cin * L.Cout, s);
         if (g_gemm_persistent && gemm_supports(L.Cin)) {
             GemmArgs ga;
             ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
-            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 16; ga.act = 0; ga.tiles_m = ga.tiles_n = 0;
+            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0;
             gemm_launch(ga, L.tile, g_gemm_persistent > 1 ? g_gemm_persistent : 0, s);
         } else {
+            ConvArgs g;
+            g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
+            g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
+            g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = nb;
             conv_launch(g, L.tile, 1, false, s);
         }
         prof_end(n, s);
         prof_begin(n, 2, false, 0, s);
-        TD_LAUNCH(k_wino_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        if (L.wino == 4) TD_LAUNCH(k_wino4_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        else TD_LAUNCH(k_wino_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
         prof_end(n, s);
         if (own) { TD_HIP(hipStreamSynchronize(s)); hipFree(V); hipFree(Mb); }
         if (Ho_out) *Ho_out = H;
@@ -1061,9 +1066,9 @@ extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->final
 // 1 = fp16-input MFMA with fp32 accumulation for every conv except the stem (BASELINE config 5 "fp16 MFMA").
 extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; return 0; }
 // 0 = direct convolutions (default), 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (layers 3-4), 2 = for every stride-1 3x3
-extern "C" int tdnet_set_conv_winograd(int mode) { g_conv_wino = mode < 0 ? 0 : mode > 2 ? 2 : mode; return 0; }
-// bit 0: two-stage pipeline, bit 1: fp16-input MFMA, bits 2-3: Winograd mode, bits 8..: stagger
-extern "C" int tdnet_get_conv_config(void) { return (g_conv_deep & 1) | ((g_conv_fp16 & 1) << 1) | ((g_conv_wino & 3) << 2) | ((g_gemm_persistent ? 1 : 0) << 4) | (g_conv_stagger << 8); }
+extern "C" int tdnet_set_conv_winograd(int mode) { g_conv_wino = mode < 0 ? 0 : mode > 4 ? 4 : mode; return 0; }
+// bit 0: two-stage pipeline, bit 1: fp16-input MFMA, bits 2-4: Winograd mode, bit 5: persistent GEMM, bits 8..: stagger
+extern "C" int tdnet_get_conv_config(void) { return (g_conv_deep & 1) | ((g_conv_fp16 & 1) << 1) | ((g_conv_wino & 7) << 2) | ((g_gemm_persistent ? 1 : 0) << 5) | (g_conv_stagger << 8); }
 // 0 = off, 1 = on, n > 1 = on with the grid forced to n workgroups (test hook: many tiles per workgroup)
 extern "C" int tdnet_set_gemm_persistent(int on) { g_gemm_persistent = on < 0 ? 0 : on; return 0; }
 extern "C" int tdnet_set_conv_stagger(int units) { g_conv_stagger = units < 0 ? 0 : units > 64 ? 64 : units; return 0; }
@@ -1255,8 +1260,8 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     hipEventCreate(&e0); hipEventCreate(&e1);
     tdnet tmp;                                                        // only carries the Winograd workspace for run_conv
     if (L.wino) {
-        const size_t T = (size_t)wino_tiles(H, W, dil);
-        tmp.wino_v_floats = 16 * T * Cin; tmp.wino_m_floats = 16 * T * Cout;
+        const size_t T = (size_t)wino_tiles(H, W, dil, L.wino), nb = (size_t)(L.wino + 2) * (L.wino + 2);
+        tmp.wino_v_floats = nb * T * Cin; tmp.wino_m_floats = nb * T * Cout;
         if (dev_alloc(&tmp.wino_v, tmp.wino_v_floats) || dev_alloc(&tmp.wino_m, tmp.wino_m_floats)) return -1.0;
     }
     tdnet* ws = L.wino ? &tmp : nullptr;

@@ -1,16 +1,20 @@
-// td_wino.h -- Winograd F(2x2, 3x3) for the stride-1 dilated 3x3 convolutions of layers 3-4 (fp32).
+// td_wino.h -- Winograd F(2x2, 3x3) and F(4x4, 3x3) for the stride-1 dilated 3x3 convolutions of layers 3-4 and the head (fp32).
 //
-// Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A  turns every 2x2 output tile into 16 products per (ci, co) instead of 36:
-// the contraction shrinks 2.25x and becomes 16 independent [tiles x Cin] x [Cin x Cout] GEMMs, which run on the same
-// fp32-MFMA kernel as the 1x1 convs (k_conv_igemm with nbatch = 16).  The input/output transforms are HBM-bound passes.
+// Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A  turns every m x m output tile into (m+2)^2 products per (ci, co) instead of
+// 9 m^2: 16 instead of 36 for m = 2 (2.25x fewer MACs), 36 instead of 144 for m = 4 (4x fewer).  The contraction becomes
+// (m+2)^2 independent [tiles x Cin] x [Cin x Cout] GEMMs on the persistent fp32-MFMA GEMM (td_gemm.h, nbatch = 16 / 36); the
+// input/output transforms are HBM-bound passes over V = [(m+2)^2][T][Cin] and M = [(m+2)^2][T][Cout], which are 4x / 2.25x the
+// size of the activation, so F(4x4) also moves 1.8x fewer transform bytes than F(2x2).
 //
 // A conv with dilation d (resnet.py:32-37: 2, 4, 8, 16 here) is d*d independent dilation-1 convs on the sub-grids
 // {(py + d a, px + d b)}: a tile is (phase py, px; tile ty, tx) and its 4x4 input patch is read with stride d.
-//   tile index t = ((py*d + px) * TY + ty) * TX + tx,  TY = ceil(ceil(H/d)/2), TX = ceil(ceil(W/d)/2)
+//   tile index t = ((py*d + px) * TY + ty) * TX + tx,  TY = ceil(ceil(H/d)/m), TX = ceil(ceil(W/d)/m)
 // so all phases have the same tile count (out-of-range taps read zeros, out-of-range outputs are not written).
 //
-// Numerics: fp32 throughout; the transforms add a few roundings per element (error ~4x a direct fp32 conv, still 1e-7
-// relative).  Opt-in per DESIGN.md: it changes the summation structure, not the precision.
+// Numerics: fp32 throughout (weights G g G^T are formed in fp64 on the host and rounded once).  Per conv the rms error vs fp64
+// is 2.5x (F2) / 16x (F4, interpolation points 0, +-1, +-2) that of a direct fp32 conv; END TO END (td4 pipeline, CPU experiment
+// tests/numerics_winograd.py) max|dlogit| vs fp64 is 1.2e-5 direct, 1.2e-5 F2, 2.6e-5 F4 -- BN, ReLU and the plane LayerNorm
+// do not amplify it -- against a parity gate of 1e-3.
 #pragma once
 #include "td_conv.h"
 
@@ -126,21 +130,133 @@ TD_KERNEL void k_wino_out(WinoArgs p) {
     }
 }
 
-static inline int wino_tiles_1d(int n, int dil) { return ((n + dil - 1) / dil + 1) / 2; }
-static inline long wino_tiles(int H, int W, int dil) { return (long)dil * dil * wino_tiles_1d(H, dil) * wino_tiles_1d(W, dil); }
+// ---- F(4x4, 3x3): interpolation points 0, +-1, +-2, inf (Lavin & Gray) -----------------------------------------------------
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+TD_DEV void td_wino4_bt(const f32x4 (&d)[6], f32x4 (&t)[6]) {
+    const f32x4 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+TD_DEV void td_wino4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
+    const f32x4 p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = m[0] + p + r;
+    y[1] = q + 2.f * s;
+    y[2] = p + 4.f * r;
+    y[3] = q + 8.f * s + m[5];
+}
 
-// U = G g G^T (fp64) for every (co, ci): 16 [Cout][Cin] matrices, matrix xi*4+nu first
-static inline void wino_transform_weights(const float* w, int Cout, int Cin, std::vector<std::vector<float>>& U) {
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    U.assign(16, std::vector<float>((size_t)Cout * Cin));
+// thread = (tile, 4 channels): 6x6 patch (stride = dilation) -> 36 planes of V.  Columns first (a column is loaded, transformed
+// and kept), then each row of the intermediate is transformed and stored: 144 VGPRs of live state instead of 288.
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
+    const int CV = p.C >> 2;
+    const long total = (long)p.T * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int t = (int)(i / CV);
+        const int tx = t % p.TX; t /= p.TX;
+        const int ty = t % p.TY; t /= p.TY;
+        const int px = t % p.dil, py = t / p.dil;
+        f32x4 tm[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int x = px + p.dil * (4 * tx - 1 + c);
+            f32x4 d[6], col[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int y = py + p.dil * (4 * ty - 1 + r);
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) z = td_ld4(p.in + ((size_t)y * p.W + x) * p.C + cv * 4);
+                d[r] = z;
+            }
+            td_wino4_bt(d, col);                                      // B^T d, one column
+#pragma unroll
+            for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
+        }
+        const size_t tile = (size_t)(i / CV);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            f32x4 v[6];
+            td_wino4_bt(tm[r], v);                                    // (.) B, one row
+#pragma unroll
+            for (int c = 0; c < 6; ++c) td_st4(p.V + ((size_t)(r * 6 + c) * p.T + tile) * p.C + cv * 4, v[c]);
+        }
+    }
+}
+
+// thread = (tile, 4 output channels): Y = A^T m A (4x4 pixels), + bias (+ residual), activation, scatter
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
+    const int CV = p.Cout >> 2;
+    const long total = (long)p.T * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const size_t tile = (size_t)(i / CV);
+        int t = (int)tile;
+        const int tx = t % p.TX; t /= p.TX;
+        const int ty = t % p.TY; t /= p.TY;
+        const int px = t % p.dil, py = t / p.dil;
+        f32x4 sm[4][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            f32x4 m[6], col[4];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m[r] = td_ld4(p.Mb + ((size_t)(r * 6 + c) * p.T + tile) * p.Cout + cv * 4);
+            td_wino4_at(m, col);                                      // A^T m, one column
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[r][c] = col[r];
+        }
+        const f32x4 b = td_ld4(p.bias + cv * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = py + p.dil * (4 * ty + r);
+            if (y >= p.H) continue;
+            f32x4 o4[4];
+            td_wino4_at(sm[r], o4);                                   // (.) A, one row
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int x = px + p.dil * (4 * tx + c);
+                if (x >= p.W) continue;
+                const size_t off = ((size_t)y * p.W + x) * p.Cout + cv * 4;
+                f32x4 o = o4[c] + b;
+                if (p.resid) o = o + td_ld4(p.resid + off);
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.01f * o[e];
+                }
+                td_st4(p.out + off, o);
+            }
+        }
+    }
+}
+
+
+// m = output tile edge (2 or 4)
+static inline int wino_tiles_1d(int n, int dil, int m) { return ((n + dil - 1) / dil + m - 1) / m; }
+static inline long wino_tiles(int H, int W, int dil, int m) { return (long)dil * dil * wino_tiles_1d(H, dil, m) * wino_tiles_1d(W, dil, m); }
+
+// U = G g G^T (fp64) for every (co, ci): (m+2)^2 [Cout][Cin] matrices, matrix xi*(m+2)+nu first
+static inline void wino_transform_weights(const float* w, int Cout, int Cin, int m, std::vector<std::vector<float>>& U) {
+    static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    static const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int n = m + 2;
+    const double (*G)[3] = m == 2 ? G2 : G4;
+    U.assign((size_t)n * n, std::vector<float>((size_t)Cout * Cin));
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci) {
             const float* g = w + ((size_t)co * Cin + ci) * 9;
-            double t[4][3];
-            for (int i = 0; i < 4; ++i)
+            double t[6][3];
+            for (int i = 0; i < n; ++i)
                 for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j)
-                    U[i * 4 + j][(size_t)co * Cin + ci] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    U[(size_t)i * n + j][(size_t)co * Cin + ci] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
         }
 }

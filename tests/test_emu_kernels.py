@@ -8,7 +8,7 @@ import pytest
 
 import emu_util
 import opcheck
-from tdnet_amd import arch, weights
+from tdnet_amd import _capi, arch, weights
 from tdnet_amd.engine import Engine
 
 MEM = opcheck.NumpyMem()
@@ -24,7 +24,7 @@ def direct_convs(lib):
     """Force the direct implicit-GEMM kernels (the library default routes wide stride-1 3x3 convs to Winograd)."""
     lib.tdnet_set_conv_winograd(0)
     yield
-    lib.tdnet_set_conv_winograd(1)
+    lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
@@ -136,7 +136,37 @@ def test_winograd_conv_and_pipeline(lib, golden_dir):
             assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
         e.close()
     finally:
-        lib.tdnet_set_conv_winograd(1)             # library default
+        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
+
+
+def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
+    """Winograd F(4x4,3x3) (td_wino.h k_wino4_in / k_wino4_out, 36 batched GEMMs): every dilation, ragged sizes (tiles hanging
+    over the image, images smaller than a tile), residual/activation variants, then the td4 pipeline with layers 3-4 and the
+    head on it (mode 3, the wide convs) against the goldens captured from the real reference."""
+    lib.tdnet_set_conv_winograd(4)
+    try:
+        worst = 0.0
+        for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
+                  (5, 9, 256, 512, 3, 1, 16, 2, False), (40, 40, 32, 128, 3, 1, 1, 1, False), (1, 1, 32, 32, 3, 1, 1, 0, False),
+                  (7, 7, 32, 64, 3, 1, 3, 1, True), (16, 32, 64, 64, 3, 1, 1, 2, True)]:
+            worst = max(worst, opcheck.conv(lib, MEM, *a, tol=2e-4))       # F4's per-conv error is ~6x F2's; outputs are O(1)
+        opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False)           # stride 2 is not eligible: direct path
+        lib.tdnet_set_conv_winograd(3)
+        name, bb, H, W = "td4", "resnet18", 33, 65
+        spec = arch.model_spec(name, 19, bb)
+        h, w = arch.feat_size(H), arch.feat_size(W)
+        g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+        e = Engine(4, 18, 19, H, W, 0, lib=lib)
+        e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+        for t, x in enumerate(weights.synth_video(H, W, 5, seed=1)):
+            out = np.full((1, 19, H, W), 7e7, np.float32)
+            e.forward(x, t % 4, out)
+            assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 1e-4 * np.abs(g["f%d_c4" % t]).max()
+            assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
+            assert (out[0].argmax(0) == g["f%d_logits" % t][0].argmax(0)).all()
+        e.close()
+    finally:
+        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
 
 
 def test_persistent_gemm_multi_tile(lib):
@@ -151,12 +181,14 @@ def test_persistent_gemm_multi_tile(lib):
                 opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True, tile)      # K = 96: odd step count -> single-tile kernel
             lib.tdnet_set_conv_winograd(2)
             opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True)                # 16 batches x tiles over few workgroups
-            lib.tdnet_set_conv_winograd(1)
+            lib.tdnet_set_conv_winograd(4)
+            opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4)      # 36 batches
+            lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
         lib.tdnet_set_gemm_persistent(0)                                              # the non-persistent fallback stays correct
         opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True)
     finally:
         lib.tdnet_set_gemm_persistent(1)
-        lib.tdnet_set_conv_winograd(1)
+        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
 
 
 @pytest.mark.parametrize("name,T", [("td4", 7), ("td2", 4)])

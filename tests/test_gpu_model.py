@@ -115,14 +115,15 @@ def test_full_size_digest_from_reference(golden_dir):
 
 
 def test_direct_conv_mode_meets_the_same_gate():
-    """The library default uses Winograd for layers 3-4; the all-direct configuration must stay parity-green too."""
+    """The library default uses Winograd F(4x4,3x3) for layers 2-4 and the head; the all-direct configuration must stay
+    parity-green too."""
     from tdnet_amd import _capi
     _capi.lib().tdnet_set_conv_winograd(0)
     try:
         _vs_oracle("td4", "resnet18", 257, 513, 6)
         _vs_oracle("td4", "resnet18", 1024, 2048, 5)
     finally:
-        _capi.lib().tdnet_set_conv_winograd(1)
+        _capi.lib().tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
 
 
 def test_properties_determinism_labels_reset():

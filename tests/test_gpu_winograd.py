@@ -1,5 +1,5 @@
-"""Winograd F(2x2,3x3) mode on the GPU: operator parity at the real layer shapes and the standard model gate
-(max|dlogit| <= 1e-3, tie-band label flips only) against the fp32 CPU oracle."""
+"""Winograd modes on the GPU -- F(2x2,3x3) (mode 1/2) and the default F(4x4,3x3) (mode 3/4): operator parity at the real layer
+shapes and the standard model gate (max|dlogit| <= 1e-3, tie-band label flips only) against the fp32 CPU oracle."""
 import pytest
 import torch
 
@@ -24,5 +24,14 @@ def test_winograd_ops_and_model():
         tm._vs_oracle("td4", "resnet18", 257, 513, 6)
         tm._vs_oracle("td4", "resnet18", 1024, 2048, 5)
         tm._vs_oracle("td2", "resnet34", 180, 240, 3)
+        lib.tdnet_set_conv_winograd(4)                                  # F(4x4,3x3) on every stride-1 3x3
+        for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
+                  (5, 9, 256, 512, 3, 1, 16, 2, False), (1, 1, 32, 32, 3, 1, 1, 0, False), (97, 193, 256, 256, 3, 1, 2, 1, True)]:
+            opcheck.conv(lib, mem, *a, tol=2e-4)
+        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tol=5e-4)    # K = 512 sums through the +-8 output transform
+        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 8, 1, True, tol=5e-4)
+        opcheck.conv(lib, mem, 128, 256, 256, 256, 3, 1, 2, 1, True, tol=5e-4)
+        tm._vs_oracle("td4", "resnet18", 257, 513, 6)                   # mode 4: stricter than the default (layer1 on F4 as well)
+        tm._vs_oracle("td4", "resnet18", 1024, 2048, 5)
     finally:
-        lib.tdnet_set_conv_winograd(1)             # library default
+        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
