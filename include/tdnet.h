@@ -118,7 +118,7 @@ int tdnet_set_gemm_persistent(int on);
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */
 double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* stream);
-double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile, int iters, void* stream);
+double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile /* -1: heuristic */, int iters, void* stream);
 
 const char* tdnet_last_error(void);
 const char* tdnet_version(void);

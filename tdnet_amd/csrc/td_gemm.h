@@ -182,6 +182,28 @@ static inline int gemm_blocks_per_cu(ConvTile t) { const ConvTileDims d = conv_t
 // the two-step period needs an even number of K steps
 static inline bool gemm_supports(int K) { return K % 64 == 0; }
 
+// Tile choice for the persistent kernel.  What matters is how many ROUNDS of the resident workgroups (256 CUs x bpc) the tile
+// list takes, and how full the last round is: a CU working on j < bpc tiles finishes them faster, but not j/bpc faster (one
+// workgroup alone keeps the MFMA pipes ~62 % busy, two of three ~90 %).  Measured on the F(4x4) GEMMs of the frame
+// (tools/wino_tile_probe.py): equal rounds -> the three shapes tie; 256-channel layers at 769x1537: 64x128 0.093 ms vs 128x128
+// 0.110 ms (792 tiles of 128x128 = 1.55 rounds of 512).
+static inline ConvTile gemm_pick_tile(long rows, int nbatch, int N) {
+    if (N <= 64) return g_conv_deep ? CT_128x64_DEEP : CT_128x64;
+    static const struct { ConvTile t; int bm, bn, bpc; double eff; } cand[3] = {
+        {CT_128x128, 128, 128, 2, 1.00}, {CT_64x128, 64, 128, 3, 0.97}, {CT_128x64, 128, 64, 3, 0.95}};
+    ConvTile best = CT_128x128;
+    double best_cost = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const long tiles = ((rows + cand[i].bm - 1) / cand[i].bm) * ((N + cand[i].bn - 1) / cand[i].bn) * nbatch;
+        const long slots = 256L * cand[i].bpc, full = tiles / slots, rem = tiles % slots;
+        const int j = (int)((rem + 255) / 256);
+        const double u = j == cand[i].bpc ? 1.0 : j == 1 ? 0.62 : 0.9;
+        const double cost = (double)cand[i].bm * cand[i].bn * (full * cand[i].bpc + (j ? j / u : 0.0)) / cand[i].eff;
+        if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].t; }
+    }
+    return g_conv_deep ? (ConvTile)(best + 3) : best;
+}
+
 template <int BM, int BN, int WGM, int WGN>
 static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;

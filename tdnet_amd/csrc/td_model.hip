@@ -124,7 +124,10 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     if (L.wino) {
         // nb = (m+2)^2 batched [T x Cin] x [Cin x Cout] GEMMs, T = M / m^2 tiles: nb * T rows in total -> pick the tile for that many workgroups
         const int nb = (L.wino + 2) * (L.wino + 2);
-        L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout);
+        const bool pers = g_gemm_persistent && gemm_supports(Cin);
+        L.tile = forced_tile >= 0 ? (ConvTile)forced_tile
+               : pers ? gemm_pick_tile(wino_tiles_estimate(M, dil, L.wino), nb, Cout)
+                      : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout);
         L.CoutPad = conv_cout_pad(Cout, L.tile);
         L.nsteps = conv_nsteps(Cin, 1, false);
         std::vector<std::vector<float>> U;
@@ -142,9 +145,10 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         TD_HIP(hipMemcpy(L.d_zero, zz.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     }
-    L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : conv_pick_tile((int)M, Cout);
-    L.CoutPad = conv_cout_pad(Cout, L.tile);
     L.h16 = g_conv_fp16 && !stem && Cin % 64 == 0;
+    const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && g_gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
+    L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout) : conv_pick_tile((int)M, Cout);
+    L.CoutPad = conv_cout_pad(Cout, L.tile);
     if (L.h16) {
         L.nsteps = conv_nsteps_h(Cin, KS);
         std::vector<_Float16> packed((size_t)L.nsteps * 8 * L.CoutPad * 8);
@@ -1243,7 +1247,7 @@ extern "C" double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* str
 }
 // Average device time (ms, HIP events on `stream`) of `iters` launches of one conv configuration on random data.
 extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile, int iters, void* stream) {
-    if ((KS != 1 && KS != 3) || Cin % 32 || tile < 0 || tile >= CT_COUNT) { td_fail("tdnet_bench_conv: bad arguments"); return -1.0; }
+    if ((KS != 1 && KS != 3) || Cin % 32 || tile < -1 || tile >= CT_COUNT) { td_fail("tdnet_bench_conv: bad arguments"); return -1.0; }
     hipStream_t s = (hipStream_t)stream;
     ConvLayer L;
     std::vector<float> w((size_t)Cout * Cin * KS * KS), x((size_t)H * W * Cin), b(Cout, 0.1f);
@@ -1251,7 +1255,9 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
     for (auto& v : w) v = rnd() * 0.05f;
     for (auto& v : x) v = rnd();
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, 0, tile)) return -1.0;
+    const int pad_ = dil * (KS / 2);
+    const long M_ = (long)out_size(H, KS, stride, dil, pad_) * out_size(W, KS, stride, dil, pad_);
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, M_, tile)) return -1.0;   // tile -1: the heuristic's choice for this M
     float *din = nullptr, *dout = nullptr;
     if (upload(&din, x)) return -1.0;
     const int Ho = out_size(H, KS, stride, dil, L.pad), Wo = out_size(W, KS, stride, dil, L.pad);

@@ -241,6 +241,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
 static inline int wino_tiles_1d(int n, int dil, int m) { return ((n + dil - 1) / dil + m - 1) / m; }
 static inline long wino_tiles(int H, int W, int dil, int m) { return (long)dil * dil * wino_tiles_1d(H, dil, m) * wino_tiles_1d(W, dil, m); }
 
+// tile count for an output of M pixels whose shape is not at hand (layer setup): assume the 1:2 frames of the path
+static inline long wino_tiles_estimate(long M, int dil, int m) {
+    int H = 1;
+    while ((long)H * H * 2 < M) ++H;
+    const int W = (int)((M + H - 1) / H);
+    return wino_tiles(H, W, dil, m);
+}
+
 // U = G g G^T (fp64) for every (co, ci): (m+2)^2 [Cout][Cin] matrices, matrix xi*(m+2)+nu first
 static inline void wino_transform_weights(const float* w, int Cout, int Cin, int m, std::vector<std::vector<float>>& U) {
     static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
