@@ -192,33 +192,47 @@ TD_KERNEL void k_ln_apply(const float* __restrict__ x, const float* __restrict__
 }
 
 // ---- classifier: 1x1 conv C -> NC (+bias) (td4_psp18.py:299), NHWC in, PLANAR [NC][HW] out ------------------------
+// One workgroup = 64 pixels x 4 channel quarters (one wave each): a lane streams its quarter of its pixel's channels (C bytes,
+// whole cache lines) against the LDS-resident weights, the four partial sums meet in LDS and are added in a fixed order.
+// (One thread per pixel, the first version, left three quarters of the SIMDs without a wave at 128x256: 40 us for 17 MB.)
 template <int NC_MAX>
 TD_KERNEL void k_classifier(const float* __restrict__ x, const float* __restrict__ wgt, const float* __restrict__ bias,
                             float* __restrict__ out, int HW, int C, int NC) {
     TD_DYN_LDS(smem);
     float* ws = reinterpret_cast<float*>(smem);                // [NC][C]
+    float* red = ws + NC * C;                                  // [4][NC][64]
     for (int i = threadIdx.x; i < NC * C; i += blockDim.x) ws[i] = wgt[i];
     __syncthreads();
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= HW) return;
+    const int lp = threadIdx.x & 63, q = threadIdx.x >> 6, CQ = C >> 2;
+    const int p = blockIdx.x * 64 + lp;
     float acc[NC_MAX];
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k) acc[k] = 0.f;
+    if (p < HW) {
+        const float* xp = x + (size_t)p * C + q * CQ;
 #pragma unroll 4
-    for (int c = 0; c < C; c += 4) {
-        const f32x4 v = td_ld4(x + (size_t)p * C + c);
+        for (int c = 0; c < CQ; c += 4) {
+            const f32x4 v = td_ld4(xp + c);
 #pragma unroll
-        for (int k = 0; k < NC_MAX; ++k) {
-            if (k < NC) {
-                const float* wr = ws + k * C + c;
-                acc[k] = fmaf(v[0], wr[0], acc[k]); acc[k] = fmaf(v[1], wr[1], acc[k]);
-                acc[k] = fmaf(v[2], wr[2], acc[k]); acc[k] = fmaf(v[3], wr[3], acc[k]);
+            for (int k = 0; k < NC_MAX; ++k) {
+                if (k < NC) {
+                    const float* wr = ws + k * C + q * CQ + c;
+                    acc[k] = fmaf(v[0], wr[0], acc[k]); acc[k] = fmaf(v[1], wr[1], acc[k]);
+                    acc[k] = fmaf(v[2], wr[2], acc[k]); acc[k] = fmaf(v[3], wr[3], acc[k]);
+                }
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k)
-        if (k < NC) out[(size_t)k * HW + p] = acc[k] + bias[k];
+        if (k < NC) red[(q * NC + k) * 64 + lp] = acc[k];
+    __syncthreads();
+    for (int v = threadIdx.x; v < NC * 64; v += blockDim.x) {
+        const int k = v >> 6, pl = v & 63, pp = blockIdx.x * 64 + pl;
+        if (pp >= HW) continue;
+        const float sum = ((red[(0 * NC + k) * 64 + pl] + red[(1 * NC + k) * 64 + pl]) + red[(2 * NC + k) * 64 + pl]) + red[(3 * NC + k) * 64 + pl];
+        out[(size_t)k * HW + pp] = sum + bias[k];
+    }
 }
 
 // ---- bilinear, align_corners=True (td4_psp18.py:227): planar [C][h][w] -> [C][H][W] ------------------------------
@@ -248,26 +262,23 @@ TD_KERNEL void k_upsample(const float* __restrict__ in, float* __restrict__ out,
 }
 // same arithmetic, 4 consecutive output columns per lane and one 16-byte store (W % 4 == 0): the 159 MB logits write
 // of a 1024x2048 frame is the largest single HBM stream of the path
+// grid = (ceil(W/4 / 256), H, C): the row and channel come from the block index (no 64-bit div/mod per thread), the row's
+// vertical coefficients are wave-uniform
 TD_KERNEL void k_upsample_x4(const float* __restrict__ in, float* __restrict__ out, int C, int h, int w, int H, int W) {
     const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const int W4 = W >> 2;
-    const long total = (long)C * H * W4;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int X4 = (int)(i % W4);
-        const long t = i / W4;
-        const int Y = (int)(t % H), c = (int)(t / H);
-        const UpCoef cy = td_up_coef(Y, sy, h);
-        const float* r0 = in + ((size_t)c * h + cy.i0) * w;
-        const float* r1 = in + ((size_t)c * h + cy.i1) * w;
-        f32x4 o;
+    const int X4 = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y, c = blockIdx.z;
+    if (X4 >= (W >> 2)) return;
+    const UpCoef cy = td_up_coef(Y, sy, h);
+    const float* r0 = in + ((size_t)c * h + cy.i0) * w;
+    const float* r1 = in + ((size_t)c * h + cy.i1) * w;
+    f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const UpCoef cx = td_up_coef(X4 * 4 + e, sx, w);
-            o[e] = (1.f - cy.l) * ((1.f - cx.l) * r0[cx.i0] + cx.l * r0[cx.i1]) + cy.l * ((1.f - cx.l) * r1[cx.i0] + cx.l * r1[cx.i1]);
-        }
-        td_st4(out + ((size_t)c * H + Y) * W + X4 * 4, o);
+    for (int e = 0; e < 4; ++e) {
+        const UpCoef cx = td_up_coef(X4 * 4 + e, sx, w);
+        o[e] = (1.f - cy.l) * ((1.f - cx.l) * r0[cx.i0] + cx.l * r0[cx.i1]) + cy.l * ((1.f - cx.l) * r1[cx.i0] + cx.l * r1[cx.i1]);
     }
+    td_st4(out + ((size_t)c * H + Y) * W + X4 * 4, o);
 }
 // argmax over classes, first maximum wins (== output.max(1)[1], test.py:61); labels int32 [H][W]
 TD_KERNEL void k_argmax(const float* __restrict__ logits, int32_t* __restrict__ labels, int C, long HW) {

@@ -735,7 +735,8 @@ static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* o
 }
 static int run_classifier(tdnet* n, const float* x, int HW, int C, int NC, const float* wgt, const float* bias, float* out, hipStream_t s) {
     prof_begin(n, 2, false, 0, s);
-    const int grid = (HW + 255) / 256, lds = NC * C * 4;
+    if (C % 16) return td_fail("classifier: C=%d is not a multiple of 16", C);
+    const int grid = (HW + 63) / 64, lds = (NC * C + 4 * NC * 64) * 4;
     if (NC <= 19) TD_LAUNCH((k_classifier<19>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
     else TD_LAUNCH((k_classifier<32>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
     prof_end(n, s);
@@ -743,7 +744,7 @@ static int run_classifier(tdnet* n, const float* x, int HW, int C, int NC, const
 }
 
 static void launch_upsample(const float* in, int C, int h, int w, int H, int W, float* out, hipStream_t s) {
-    if (W % 4 == 0) TD_LAUNCH(k_upsample_x4, dim3(td_grid_for((long)C * H * (W / 4), 256, 256 * 16)), dim3(256), 0, s, in, out, C, h, w, H, W);
+    if (W % 4 == 0 && H <= 65535 && C <= 65535) TD_LAUNCH(k_upsample_x4, dim3((W / 4 + 255) / 256, H, C), dim3(256), 0, s, in, out, C, h, w, H, W);
     else TD_LAUNCH(k_upsample, dim3(td_grid_for((long)C * H * W, 256, 256 * 16)), dim3(256), 0, s, in, out, C, h, w, H, W);
 }
 

@@ -192,7 +192,7 @@ static void run_block(Worker* wk, const std::function<void()>& body, int nthread
 void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes) {
     const int nthreads = (int)(block.x * block.y * block.z);
     const long nblocks = (long)grid.x * grid.y * grid.z;
-    if (nthreads > MAX_THREADS || lds_bytes > LDS_BYTES || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) {
+    if (nthreads > MAX_THREADS || lds_bytes > LDS_BYTES || block.y != 1 || block.z != 1) {
         fprintf(stderr, "tdemu: unsupported launch geometry\n");
         abort();
     }
@@ -208,11 +208,11 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
     for (int wi = 0; wi < nw; ++wi) {
         th.emplace_back([&, wi]() {
             Worker* wk = pool[wi];
-            g_gridDim = {grid.x, 1, 1};
+            g_gridDim = {grid.x, grid.y, grid.z};
             g_blockDim = {block.x, 1, 1};
             g_lds = (char*)(((uintptr_t)wk->lds.get() + 255) & ~(uintptr_t)255);
             for (long b = wi; b < nblocks; b += nw) {
-                g_blockIdx = {(unsigned)b, 0, 0};
+                g_blockIdx = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y))};
                 memset(g_lds, 0xCD, lds_bytes);                  // LDS is not zero-initialised on hardware either
                 run_block(wk, body, nthreads);
             }
