@@ -44,7 +44,7 @@ struct AttnLds {
 template <int QW, int CW, int NT>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     static_assert(QW * CW == 4, "4 waves per block");
-    static_assert(NT == 4, "lane owns one float4 of channels");
+    static_assert(NT == 4 || NT == 2, "lane owns NT consecutive channels: one float4 or one float2 of V' / the output");
     constexpr int DV = CW * NT * 32;
     constexpr int SK = 32 * CW;                                  // keys per super-tile
     using L = AttnLds<QW, CW>;
@@ -128,7 +128,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int key = (key0 + e < p.Lk) ? key0 + e : key_last;     // P is exactly 0 for masked keys
-            b[e] = td_ld4(vbase + (size_t)key * DV);
+            if (NT == 4) b[e] = td_ld4(vbase + (size_t)key * DV);
+            else {
+                const f32x2 v2 = *reinterpret_cast<const f32x2*>(vbase + (size_t)key * DV);
+                b[e][0] = v2[0]; b[e][1] = v2[1]; b[e][2] = 0.f; b[e][3] = 0.f;
+            }
         }
     };
     f32x4 kf[8];
@@ -172,7 +176,10 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     if (half == 0) red2[(qw * CW + cw) * 32 + l31] = lsum;
     __syncthreads();
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = td_ld4(p.bias + cb);
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = p.bias[cb + j];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -182,11 +189,17 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
         const float inv = 1.0f / l;
-        f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[2][r] * inv, acc[3][r] * inv};
-        o = o + bv;
         const size_t off = (size_t)q * DV + cb;
-        if (p.resid) o = o + td_ld4(p.resid + off);
-        td_st4(p.out + off, o);
+        if (NT == 4) {
+            f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[NT - 2][r] * inv, acc[NT - 1][r] * inv};
+            o = o + bv;
+            if (p.resid) o = o + td_ld4(p.resid + off);
+            td_st4(p.out + off, o);
+        } else {
+            f32x2 o = {acc[0][r] * inv + bv[0], acc[1][r] * inv + bv[1]};
+            if (p.resid) o = o + *reinterpret_cast<const f32x2*>(p.resid + off);
+            *reinterpret_cast<f32x2*>(p.out + off) = o;
+        }
     }
 }
 
@@ -195,8 +208,9 @@ static inline int attn_launch(const AttnArgs& a, int DV, hipStream_t s) {
         const int grid = (a.Lq + 31) / 32;
         TD_LAUNCH((k_attention<1, 4, 4>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
     } else if (DV == 128) {
-        const int grid = (a.Lq + 127) / 128;
-        TD_LAUNCH((k_attention<4, 1, 4>), dim3(grid), dim3(256), (AttnLds<4, 1>::BYTES), s, a);
+        // two query tiles x two channel halves: 2 waves per SIMD at Lq = 32768 (<4,1,4> -- four tiles, all channels -- runs one)
+        const int grid = (a.Lq + 63) / 64;
+        TD_LAUNCH((k_attention<2, 2, 2>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
     } else {
         return -1;
     }

@@ -60,6 +60,8 @@ def test_attention(lib):
     opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0)
     opcheck.attention(lib, MEM, 64, 128, 512)
     opcheck.attention(lib, MEM, 1, 1, 128)
+    opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True)     # d_v 128 variant: two query tiles x two channel halves, ragged both ways
+    opcheck.attention(lib, MEM, 64, 64, 128, False, True)
 
 
 def test_layernorm_ppm_upsample(lib):
