@@ -4,8 +4,11 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 package (tdnet_amd/) never does: it fails loudly when the HIP library is missing.
 
 What it is: a functional re-statement, written from scratch, of the reference's Testing/ model graph on
-torch CPU tensors (the reference's arithmetic lives in PyTorch -- SURVEY.md §8c -- so the faithful CPU
-restatement uses the same L0 ops: conv2d / batch-norm formula / bmm / softmax / layer_norm / interpolate).
+torch CPU tensors.  The reference's arithmetic lives in PyTorch, so the graph is written over a
+small set of L0 operators -- conv2d / max-pool / adaptive avg-pool / interpolate / bmm / softmax / layer_norm --
+with two implementations: TorchOps (default: PyTorch's own CPU kernels, what the reference runs on; fast enough
+for 1024x2048) and oracle/c_ops.COps (oracle/ops_c.c: the same operators restated in plain C, so that no
+PyTorch kernel is left on the checking side; set_ops() swaps them).
 State is an explicit FIFO, weights are a flat {name: tensor} dict with the reference's state_dict keys.
 
 Pinning: tools/make_golden.py imports the real reference from /root/reference (this container only),
@@ -27,46 +30,71 @@ from tdnet_amd import arch  # noqa: E402  (pure-python spec, no HIP)
 BN_EPS = 1e-5
 
 
+class TorchOps:
+    """Default L0 ops: PyTorch's own CPU kernels -- the arithmetic the reference itself runs on."""
+    conv2d = staticmethod(F.conv2d)
+    relu = staticmethod(F.relu)
+    leaky_relu = staticmethod(F.leaky_relu)
+    max_pool2d = staticmethod(F.max_pool2d)
+    adaptive_avg_pool2d = staticmethod(F.adaptive_avg_pool2d)
+    interpolate = staticmethod(F.interpolate)
+    layer_norm = staticmethod(F.layer_norm)
+    bmm = staticmethod(torch.bmm)
+    matmul = staticmethod(torch.matmul)
+    softmax = staticmethod(torch.softmax)
+
+
+OPS = TorchOps
+
+
+def set_ops(ops):
+    """Swap the L0 ops under the graph: TorchOps (default) or oracle.c_ops.COps -- the plain-C restatement of the same ops
+    (oracle/ops_c.c), which makes the oracle independent of PyTorch's kernels.  Returns the previous backend."""
+    global OPS
+    prev, OPS = OPS, ops
+    return prev
+
+
 def bn_eval(x, sd, pre, leaky=False):
     """Eval-mode BatchNorm2d followed by identity or LeakyReLU(0.01): td4_psp18.py:11-24."""
     y = (x - sd[pre + ".running_mean"][None, :, None, None]) / torch.sqrt(sd[pre + ".running_var"][None, :, None, None] + BN_EPS)
     y = y * sd[pre + ".weight"][None, :, None, None] + sd[pre + ".bias"][None, :, None, None]
-    return F.leaky_relu(y, 0.01) if leaky else y
+    return OPS.leaky_relu(y, 0.01) if leaky else y
 
 
 def basic_block(x, sd, pre, b):
     """resnet.py:25-59: relu(bn1(conv1 x)) -> bn2(conv2 .) -> + (downsample x | x) -> relu."""
-    out = F.conv2d(x, sd[pre + ".conv1.weight"], None, b.stride, b.dil1, b.dil1)
-    out = F.relu(bn_eval(out, sd, pre + ".bn1"))
-    out = F.conv2d(out, sd[pre + ".conv2.weight"], None, 1, b.dil2, b.dil2)
+    out = OPS.conv2d(x, sd[pre + ".conv1.weight"], None, b.stride, b.dil1, b.dil1)
+    out = OPS.relu(bn_eval(out, sd, pre + ".bn1"))
+    out = OPS.conv2d(out, sd[pre + ".conv2.weight"], None, 1, b.dil2, b.dil2)
     out = bn_eval(out, sd, pre + ".bn2")
     res = x
     if b.downsample:
-        res = bn_eval(F.conv2d(x, sd[pre + ".downsample.0.weight"], None, b.stride), sd, pre + ".downsample.1")
-    return F.relu(out + res)
+        res = bn_eval(OPS.conv2d(x, sd[pre + ".downsample.0.weight"], None, b.stride), sd, pre + ".downsample.1")
+    return OPS.relu(out + res)
 
 
 def bottleneck_block(x, sd, pre, b):
     """resnet.py:62-111: 1x1 -> BN -> ReLU -> 3x3(stride, dilation) -> BN -> ReLU -> 1x1 (x4) -> BN -> + residual -> ReLU."""
-    out = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv1.weight"]), sd, pre + ".bn1"))
-    out = F.relu(bn_eval(F.conv2d(out, sd[pre + ".conv2.weight"], None, b.stride, b.dil1, b.dil1), sd, pre + ".bn2"))
-    out = bn_eval(F.conv2d(out, sd[pre + ".conv3.weight"]), sd, pre + ".bn3")
+    out = OPS.relu(bn_eval(OPS.conv2d(x, sd[pre + ".conv1.weight"]), sd, pre + ".bn1"))
+    out = OPS.relu(bn_eval(OPS.conv2d(out, sd[pre + ".conv2.weight"], None, b.stride, b.dil1, b.dil1), sd, pre + ".bn2"))
+    out = bn_eval(OPS.conv2d(out, sd[pre + ".conv3.weight"]), sd, pre + ".bn3")
     res = x
     if b.downsample:
-        res = bn_eval(F.conv2d(x, sd[pre + ".downsample.0.weight"], None, b.stride), sd, pre + ".downsample.1")
-    return F.relu(out + res)
+        res = bn_eval(OPS.conv2d(x, sd[pre + ".downsample.0.weight"], None, b.stride), sd, pre + ".downsample.1")
+    return OPS.relu(out + res)
 
 
 def backbone(x, sd, pre, blocks):
     """resnet.py:204-215: stem (7x7 s2 p3, or the deep_base 3-conv stem :122-131), BN, ReLU, max-pool 3x3 s2 p1, layer1..4 -> c4."""
     if pre + ".conv1.0.weight" in sd:               # deep_base (ResNet-50)
-        x = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv1.0.weight"], None, 2, 1), sd, pre + ".conv1.1"))
-        x = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv1.3.weight"], None, 1, 1), sd, pre + ".conv1.4"))
-        x = F.conv2d(x, sd[pre + ".conv1.6.weight"], None, 1, 1)
+        x = OPS.relu(bn_eval(OPS.conv2d(x, sd[pre + ".conv1.0.weight"], None, 2, 1), sd, pre + ".conv1.1"))
+        x = OPS.relu(bn_eval(OPS.conv2d(x, sd[pre + ".conv1.3.weight"], None, 1, 1), sd, pre + ".conv1.4"))
+        x = OPS.conv2d(x, sd[pre + ".conv1.6.weight"], None, 1, 1)
     else:
-        x = F.conv2d(x, sd[pre + ".conv1.weight"], None, 2, 3)
-    x = F.relu(bn_eval(x, sd, pre + ".bn1"))
-    x = F.max_pool2d(x, 3, 2, 1)
+        x = OPS.conv2d(x, sd[pre + ".conv1.weight"], None, 2, 3)
+    x = OPS.relu(bn_eval(x, sd, pre + ".bn1"))
+    x = OPS.max_pool2d(x, 3, 2, 1)
     for b in blocks:
         x = (bottleneck_block if b.kind == "bottleneck" else basic_block)(x, sd, "%s.%s" % (pre, b.name), b)
     return x
@@ -77,9 +105,9 @@ def pyramid_pooling(c4, sd, pre, path_num, pid):
     n, c, h, w = c4.shape
     feats = []
     for j, o in enumerate((1, 2, 3, 6), 1):
-        p = F.adaptive_avg_pool2d(c4, o)
-        p = F.relu(bn_eval(F.conv2d(p, sd["%s.conv%d.0.weight" % (pre, j)]), sd, "%s.conv%d.1" % (pre, j)))
-        feats.append(F.interpolate(p, (h, w), mode="bilinear", align_corners=True))
+        p = OPS.adaptive_avg_pool2d(c4, o)
+        p = OPS.relu(bn_eval(OPS.conv2d(p, sd["%s.conv%d.0.weight" % (pre, j)]), sd, "%s.conv%d.1" % (pre, j)))
+        feats.append(OPS.interpolate(p, (h, w), mode="bilinear", align_corners=True))
     cs = c // path_num
     fs = c // (path_num * 4)
     parts = [c4[:, pid * cs:(pid + 1) * cs]] + [f[:, pid * fs:(pid + 1) * fs] for f in feats]
@@ -88,7 +116,7 @@ def pyramid_pooling(c4, sd, pre, path_num, pid):
 
 def _conv_bias(x, sd, pre):
     """ConvBNReLU with norm_layer=None is just a biased 1x1 conv: transformer.py:142-161."""
-    return F.conv2d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"])
+    return OPS.conv2d(x, sd[pre + ".conv.weight"], sd[pre + ".conv.bias"])
 
 
 def _qk_branch(x, sd, pre):
@@ -119,11 +147,11 @@ def encoding(z, sd, pre, pre_flag):
 def attention(k_src, v_src, q_tgr, sd, pre, fea_size=None):
     """transformer.py:71-92 + :126-139: softmax(q k^T / 8) v, then per-position fc (1x1 conv with bias)."""
     dk = q_tgr.shape[-1]
-    attn = torch.bmm(q_tgr, k_src.transpose(1, 2)) / math.pow(dk, 0.5)
-    attn = torch.softmax(attn, dim=2)
-    out = torch.bmm(attn, v_src)                                    # [n, Lq, dv]
+    attn = OPS.bmm(q_tgr, k_src.transpose(1, 2)) / math.pow(dk, 0.5)
+    attn = OPS.softmax(attn, dim=2)
+    out = OPS.bmm(attn, v_src)                                    # [n, Lq, dv]
     w = sd[pre + ".fc.0.conv.weight"][:, :, 0, 0]
-    out = out @ w.t() + sd[pre + ".fc.0.conv.bias"]
+    out = OPS.matmul(out, w.t()) + sd[pre + ".fc.0.conv.bias"]
     if fea_size is not None:
         n, _, h, wd = fea_size
         out = out.permute(0, 2, 1).contiguous().view(n, -1, h, wd)
@@ -132,13 +160,13 @@ def attention(k_src, v_src, q_tgr, sd, pre, fea_size=None):
 
 def layer_norm_hw(x, sd, pre):
     """td4_psp18.py:306-312: nn.LayerNorm([h,w]) -- each channel plane normalised, affine [h,w] shared over channels."""
-    return F.layer_norm(x, x.shape[-2:], sd[pre + ".ln.weight"], sd[pre + ".ln.bias"], 1e-5)
+    return OPS.layer_norm(x, x.shape[-2:], sd[pre + ".ln.weight"], sd[pre + ".ln.bias"], 1e-5)
 
 
 def fcn_head(x, sd, pre):
     """td4_psp18.py:287-302: conv3x3 p1 (no bias) -> BN -> ReLU -> Dropout2d(eval=id) -> conv1x1 (+bias)."""
-    y = F.relu(bn_eval(F.conv2d(x, sd[pre + ".conv5.0.weight"], None, 1, 1), sd, pre + ".conv5.1"))
-    return F.conv2d(y, sd[pre + ".conv5.4.weight"], sd[pre + ".conv5.4.bias"])
+    y = OPS.relu(bn_eval(OPS.conv2d(x, sd[pre + ".conv5.0.weight"], None, 1, 1), sd, pre + ".conv5.1"))
+    return OPS.conv2d(y, sd[pre + ".conv5.4.weight"], sd[pre + ".conv5.4.bias"])
 
 
 class TDNetRef:
@@ -194,7 +222,7 @@ class TDNetRef:
         """td4_psp18.py:216-229: path dispatch, then bilinear align_corners upsample to the input size."""
         h, w = img.shape[-2:]
         out = self.forward_lowres(img, pos_id)
-        return F.interpolate(out, (h, w), mode="bilinear", align_corners=True)
+        return OPS.interpolate(out, (h, w), mode="bilinear", align_corners=True)
 
 
 class PSPNetRef:
@@ -216,11 +244,11 @@ class PSPNetRef:
         h, w = img.shape[-2:]
         c4 = backbone(img[-1:], sd, "pretrained", self.blocks)
         z = pyramid_pooling(c4, sd, "head.conv5.0", 1, 0)             # path_num 1, pid 0 = every channel (pspnet.py:157)
-        y = F.relu(bn_eval(F.conv2d(z, sd["head.conv5.1.weight"], None, 1, 1), sd, "head.conv5.2"))
-        low = F.conv2d(y, sd["head.conv5.5.weight"], sd["head.conv5.5.bias"])
+        y = OPS.relu(bn_eval(OPS.conv2d(z, sd["head.conv5.1.weight"], None, 1, 1), sd, "head.conv5.2"))
+        low = OPS.conv2d(y, sd["head.conv5.5.weight"], sd["head.conv5.5.bias"])
         if self.trace is not None:
             self.trace.update(c4=c4, z=z, lowres=low)
-        return F.interpolate(low, (h, w), mode="bilinear", align_corners=True)
+        return OPS.interpolate(low, (h, w), mode="bilinear", align_corners=True)
 
 
 def tune_threads(candidates=(8, 16, 32, 64, 128)):

@@ -75,6 +75,18 @@ def _vs_oracle(name, bb, H, W, T):
     print("%s-%s %dx%d: worst |dlogit| %.2e, %d label flips over %d frames" % (name, bb, H, W, worst, flips, T))
 
 
+def test_vs_c_operator_oracle():
+    """The same gate with the oracle graph running on the plain-C operators (oracle/ops_c.c): no PyTorch kernel on the checking
+    side.  Sizes the naive C loops finish in seconds; the warm-up, steady-state and every-path frames of td4 and td2."""
+    from oracle import c_ops
+    prev = tdnet_ref.set_ops(c_ops.COps)
+    try:
+        _vs_oracle("td4", "resnet18", 65, 129, 7)
+        _vs_oracle("td2", "resnet18", 97, 129, 4)
+    finally:
+        tdnet_ref.set_ops(prev)
+
+
 def test_vs_oracle_mid_size():
     _vs_oracle("td4", "resnet18", 257, 513, 6)
     _vs_oracle("td2", "resnet34", 180, 240, 3)
