@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU-box visit: full parity suite + benches with the default configuration (two-stage pipeline, Winograd for layers 3-4).
+# GPU-box visit: full parity suite + benches + rocprofv3 kernel trace and PMC passes with the default configuration.
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -29,4 +29,4 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$G
 cd "$GRAFT_REPO_ROOT"
 python tools/summarize_prof.py $R > $R/prof_summary.txt 2>&1
 find $R -name "*.csv" -size +8M -delete
-tail -6 $R/gpu_tests.log $R/bench.log
+tail -n 6 $R/gpu_tests.log; tail -n 2 $R/bench.log
