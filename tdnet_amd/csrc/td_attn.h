@@ -53,7 +53,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     float* red = Ps + 2 * L::P_FLOATS;                           // [QW][CW][32] row-max exchange
     float* red2 = red + L::RED_FLOATS;                           // [QW][CW][32] row-sum exchange
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = TD_UNIFORM(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int qw = wave / CW, cw = wave % CW;
     const int q0 = (blockIdx.x * QW + qw) * 32;                  // first query of this wave's tile
@@ -68,7 +68,18 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         for (int g = 0; g < 8; ++g) qf[g] = td_ld4(p.q + (size_t)q * 64 + 8 * g + 4 * half) * p.scale_log2e;
     }
     const int key_last = p.Lk - 1;
+    // K / V' tiles that lie wholly inside the matrices (all but the last, ragged one) are read with buffer loads whose per-lane
+    // offset is a kernel constant and whose tile offset rides in an SGPR: no 64-bit address arithmetic and no clamps in the VALU
+    // stream that shares the issue port with the MFMAs.  (Measured: this kernel does not wait on memory at all -- pointing every
+    // K / V' load at L1-resident rows changes nothing -- it is bound by what the SIMDs issue.)
+    const TdBuf kbuf = td_make_buf(p.k, (unsigned)p.Lk * 64u * 4u);
+    const unsigned k_voff = ((unsigned)l31 * 64u + 4u * (unsigned)half) * 4u;
     auto load_k = [&](int kb, f32x4 (&kf)[8]) {
+        if (kb + 32 <= p.Lk) {                                        // wave-uniform
+#pragma unroll
+            for (int g = 0; g < 8; ++g) kf[g] = td_buf_ld4(kbuf, k_voff, (unsigned)(kb * 64 + 8 * g) * 4u);
+            return;
+        }
         const int key = (kb + l31 < p.Lk) ? kb + l31 : key_last;
 #pragma unroll
         for (int g = 0; g < 8; ++g) kf[g] = td_ld4(p.k + (size_t)key * 64 + 8 * g + 4 * half);
@@ -97,10 +108,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             const int kb = st * SK + cw * 32;
             if (st + 1 < nsuper) load_k(kb + SK, kn);
             const f32x16 s = score_tile(kf);
+            if (kb + 32 <= p.Lk) {                                    // wave-uniform: no key of this tile is masked
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                mx = (key < p.Lk && s[r] > mx) ? s[r] : mx;
+                for (int r = 0; r < 16; ++r) mx = s[r] > mx ? s[r] : mx;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    mx = (key < p.Lk && s[r] > mx) ? s[r] : mx;
+                }
             }
 #pragma unroll
             for (int g = 0; g < 8; ++g) kf[g] = kn[g];
@@ -123,7 +139,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int cb = cw * (NT * 32) + l31 * NT;                     // this lane's first output channel
     const float* vbase = p.vp + cb;
     // V' rows of k-group G of the super-tile starting at kbase: 4 keys per lane-half, one float4 (4 channels) each
+    const TdBuf vbuf = td_make_buf(p.vp, (unsigned)p.Lk * (unsigned)DV * 4u);
+    const unsigned v_voff = (4u * (unsigned)half * (unsigned)DV + (unsigned)cb) * 4u;
     auto load_v = [&](int kbase, int G, f32x4 (&b)[4]) {
+        if (kbase + SK <= p.Lk) {                                     // wave-uniform: the whole super-tile is inside V'
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned soff = (unsigned)(kbase + 8 * G + e) * (unsigned)DV * 4u;
+                if (NT == 4) b[e] = td_buf_ld4(vbuf, v_voff, soff);
+                else {
+                    const f32x2 v2 = td_buf_ld2(vbuf, v_voff, soff);
+                    b[e][0] = v2[0]; b[e][1] = v2[1]; b[e][2] = 0.f; b[e][3] = 0.f;
+                }
+            }
+            return;
+        }
         const int key0 = kbase + 4 * (2 * G + half);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -144,12 +174,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         load_v(kbase, 1, bb[1]);
         const f32x16 s = score_tile(kf);
         f32x16 pr;
+        if (kb + 32 <= p.Lk) {                                        // wave-uniform: no key of this tile is masked
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float e = (key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
-            pr[r] = e;
-            lsum += e;
+            for (int r = 0; r < 16; ++r) {
+                const float e = td_exp2(s[r] - rowmax);
+                pr[r] = e;
+                lsum += e;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float e = (key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
+                pr[r] = e;
+                lsum += e;
+            }
         }
         float* Pw = Ps + (st & 1) * L::P_FLOATS + qw * (8 * CW * 128);
 #pragma unroll

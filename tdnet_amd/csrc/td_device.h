@@ -38,12 +38,16 @@ TD_DEV TdBuf td_make_buf(const float* p, unsigned bytes) {
 TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b.r, voff_bytes, soff_bytes, 0));
 }
+TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
+}
 
 // s_sleep: park the wave for ~64*n cycles (n <= 127); used to de-phase co-resident workgroups
 #define TD_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 
 // compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
 #define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define TD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler a wave-uniform value is one (SGPR, usable as soffset)
 
 // fp16 inputs, fp32 accumulate: D(32x32) += A(32x16) * B(16x32); lane l supplies 8 consecutive k of row/column l&31 (k-group l>>5)
 TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }

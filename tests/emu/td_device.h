@@ -90,6 +90,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
     tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds))
 
 #define TD_SCHED_GROUP(mask, n) ((void)0)
+#define TD_UNIFORM(x) (x)
 #define TD_SLEEP(n) ((void)0)
 
 struct TdBuf { const char* p; unsigned bytes; };
@@ -100,6 +101,14 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     if ((unsigned long long)voff_bytes + 16 <= b.bytes) {       // the hardware range check ignores soffset ...
         if ((unsigned long long)voff_bytes + soff_bytes + 16 > b.bytes) abort();   // ... so kernels must keep the sum in range themselves
         memcpy(&v, b.p + soff_bytes + voff_bytes, 16);
+    }
+    return v;
+}
+TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    f32x2 v = {0.f, 0.f};
+    if ((unsigned long long)voff_bytes + 8 <= b.bytes) {       // the hardware range check ignores soffset ...
+        if ((unsigned long long)voff_bytes + soff_bytes + 8 > b.bytes) abort();   // ... so kernels must keep the sum in range themselves
+        memcpy(&v, b.p + soff_bytes + voff_bytes, 8);
     }
     return v;
 }
