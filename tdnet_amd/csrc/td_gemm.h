@@ -79,7 +79,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     auto load_tile = [&](f32x4 (&ra)[AL], f32x4 (&rb)[BL]) {
         const unsigned kb = (unsigned)l_step * 128u;                 // 32 floats per step
 #pragma unroll
-        for (int i = 0; i < AL; ++i) ra[i] = td_buf_ld4(a_buf, a_off[i] == TD_BUF_OOB ? TD_BUF_OOB : a_off[i] + kb, 0u);
+        for (int i = 0; i < AL; ++i) ra[i] = td_buf_ld4(a_buf, a_off[i], kb);   // the K offset rides in an SGPR: the range check looks at a_off only, so an out-of-range row stays out of range
         const unsigned wsoff = (unsigned)l_step * w_step_bytes;
 #pragma unroll
         for (int i = 0; i < BL; ++i) rb[i] = td_buf_ld4(w_buf, b_off[i], wsoff);
