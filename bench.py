@@ -190,9 +190,9 @@ def main():
             elif (cfgbits >> 2) & 7:
                 gk = "k_gemm_persistent" if (cfgbits >> 5) & 1 else "k_conv_igemm<.,.,.,.,1>"
                 f4 = ((cfgbits >> 2) & 7) >= 3
-                kname, peak = (gk + " x%d (batched GEMM of the Winograd F(%s,3x3) convs of layers 3-4 + head, "
+                kname, peak = (gk + " x%d (batched GEMM of the Winograd F(%s,3x3) convs of layers %s + head, "
                                "fp32 MFMA; FLOP = executed GEMM FLOP, %sx fewer than the direct conv's)"
-                               % ((36, "4x4", "4") if f4 else (16, "2x2", "2.25"))), PEAK_FP32_MFMA_TFLOPS
+                               % ((36, "4x4", "2-4", "4") if f4 else (16, "2x2", "3-4", "2.25"))), PEAK_FP32_MFMA_TFLOPS
             else:
                 kname, peak = "k_conv_igemm<128,128,2,2,3> (3x3 dilated conv, fp32 MFMA)", PEAK_FP32_MFMA_TFLOPS
             res["roofline"] = {"bound": "mfma", "kernel": kname,
