@@ -133,48 +133,82 @@ TD_KERNEL void k_ppm_assemble(const float* __restrict__ c4, const float* __restr
 }
 
 // ---- LayerNorm over the (h,w) plane of each channel (td4_psp18.py:306-312), NHWC ----------------------------------
-// pass A: part[strip][C] = sum_p (x[p][c] - shift[c])^2 or plain sum (shift == nullptr); strips of pixels, fixed order.
-TD_KERNEL void k_ln_partial(const float* __restrict__ x, const float* __restrict__ shift, float* __restrict__ part,
-                            int HW, int C, int sq) {
+// Two-pass (centred) variance without reading the plane twice from HBM: a strip of pixels is swept twice by ONE workgroup
+// (the second sweep hits L2), which yields the strip's mean m_s and M2_s = sum (x - m_s)^2; the strips are then combined
+// exactly:  mean = sum n_s m_s / N,   var = sum (M2_s + n_s (m_s - mean)^2) / N.   Fixed summation order everywhere.
+// pass A: part[s][C] = m_s, part[nstr + s][C] = M2_s  (empty strips write zeros)
+TD_KERNEL void k_ln_stats(const float* __restrict__ x, float* __restrict__ part, int HW, int C) {
     TD_DYN_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);               // [rows][C]
+    float* red = reinterpret_cast<float*>(smem);               // [rows][C], then [C] strip means behind it
     const int CV = C >> 2, rows = blockDim.x / CV;
+    float* smean = red + (size_t)rows * C;
     const int cv = threadIdx.x % CV, r = threadIdx.x / CV;
     const int per = (HW + gridDim.x - 1) / gridDim.x;
     const int p0 = blockIdx.x * per, p1 = (p0 + per < HW) ? p0 + per : HW;
-    f32x4 sh = {0.f, 0.f, 0.f, 0.f};
-    if (shift) sh = td_ld4(shift + cv * 4);
+    const int cnt = p1 > p0 ? p1 - p0 : 0;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + r; p < p1; p += rows) {
-        const f32x4 v = td_ld4(x + (size_t)p * C + cv * 4) - sh;
-        s = s + (sq ? v * v : v);
-    }
+    for (int p = p0 + r; p < p1; p += rows) s = s + td_ld4(x + (size_t)p * C + cv * 4);
     td_st4(red + (size_t)r * C + cv * 4, s);
     __syncthreads();
     if (r == 0) {
         for (int k = 1; k < rows; ++k) s = s + td_ld4(red + (size_t)k * C + cv * 4);
-        td_st4(part + (size_t)blockIdx.x * C + cv * 4, s);
+        const f32x4 m = cnt ? s * (1.0f / (float)cnt) : s;
+        td_st4(smean + cv * 4, m);
+        td_st4(part + (size_t)blockIdx.x * C + cv * 4, m);
+    }
+    __syncthreads();
+    const f32x4 m = td_ld4(smean + cv * 4);
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + r; p < p1; p += rows) {
+        const f32x4 v = td_ld4(x + (size_t)p * C + cv * 4) - m;
+        q = q + v * v;
+    }
+    td_st4(red + (size_t)r * C + cv * 4, q);
+    __syncthreads();
+    if (r == 0) {
+        for (int k = 1; k < rows; ++k) q = q + td_ld4(red + (size_t)k * C + cv * 4);
+        td_st4(part + ((size_t)gridDim.x + blockIdx.x) * C + cv * 4, q);
     }
 }
-// pass B: out[c] = mode 0: sum/HW (mean) ; mode 1: 1/sqrt(sum/HW + eps) (rstd).
+// pass B: mean[c] and rstd[c] = 1/sqrt(var + eps) from the strip statistics.
 // grid = C/16, block = 256 = 16 channels x 16 strip slices; fixed summation order (deterministic).
-TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int HW, int C, int mode, float eps,
-                             float* __restrict__ out) {
+TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int HW, int C, float eps, float* __restrict__ mean,
+                             float* __restrict__ rstd) {
     TD_DYN_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);               // [16 slices][16 channels]
+    float* red = reinterpret_cast<float*>(smem);               // [16 slices][16 channels] + [16] means
+    float* mu = red + 256;
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    const int per = (HW + nstrips - 1) / nstrips;
+    auto count = [&](int k) { const int p0 = k * per, p1 = (p0 + per < HW) ? p0 + per : HW; return p1 > p0 ? (float)(p1 - p0) : 0.f; };
     float s = 0.f;
     if (c < C)
-        for (int k = sl; k < nstrips; k += 16) s += part[(size_t)k * C + c];
+        for (int k = sl; k < nstrips; k += 16) s += count(k) * part[(size_t)k * C + c];
+    red[sl * 16 + cl] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
+        mu[cl] = t / (float)HW;
+    }
+    __syncthreads();
+    const float m = mu[cl];
+    s = 0.f;
+    if (c < C)
+        for (int k = sl; k < nstrips; k += 16) {
+            const float d = part[(size_t)k * C + c] - m;
+            s += part[((size_t)nstrips + k) * C + c] + count(k) * d * d;
+        }
+    __syncthreads();
     red[sl * 16 + cl] = s;
     __syncthreads();
     if (sl == 0 && c < C) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
-        t /= (float)HW;
-        out[c] = mode ? 1.0f / sqrtf(t + eps) : t;
+        mean[c] = m;
+        rstd[c] = 1.0f / sqrtf(t / (float)HW + eps);
     }
 }
 // pass C: y = (x - mean[c]) * rstd[c] * g[p] + b[p]

@@ -466,7 +466,7 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
-    if (dev_alloc(&n->ln_part, (size_t)512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
+    if (dev_alloc(&n->ln_part, (size_t)2 * 512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
     n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -700,12 +700,10 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
     const int CV = C / 4, rows = 256 / CV;
     int nstr = (HW + rows - 1) / rows;
     if (nstr > 512) nstr = 512;
-    const int lds = rows * C * 4;
+    const int lds = (rows + 1) * C * 4;
     prof_begin(n, 2, false, 0, s);
-    TD_LAUNCH(k_ln_partial, dim3(nstr), dim3(256), lds, s, x, (const float*)nullptr, part, HW, C, 0);
-    TD_LAUNCH(k_ln_finalize, dim3((C + 15) / 16), dim3(256), 1024, s, (const float*)part, nstr, HW, C, 0, 1e-5f, mean);
-    TD_LAUNCH(k_ln_partial, dim3(nstr), dim3(256), lds, s, x, (const float*)mean, part, HW, C, 1);
-    TD_LAUNCH(k_ln_finalize, dim3((C + 15) / 16), dim3(256), 1024, s, (const float*)part, nstr, HW, C, 1, 1e-5f, rstd);
+    TD_LAUNCH(k_ln_stats, dim3(nstr), dim3(256), lds, s, x, part, HW, C);                   // part: [2][nstr][C]
+    TD_LAUNCH(k_ln_finalize, dim3((C + 15) / 16), dim3(256), (256 + 16) * 4, s, (const float*)part, nstr, HW, C, 1e-5f, mean, rstd);
     TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
     prof_end(n, s);
 }
@@ -1173,7 +1171,7 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
 extern "C" int tdnet_op_layernorm_hw(const float* x, int HW, int C, const float* g, const float* b, float* out, void* stream) {
     if (C % 4 || 256 % (C / 4)) return td_fail("tdnet_op_layernorm_hw: C must be one of 4*{1,2,4,...,256}");
     float *part = nullptr, *mean = nullptr, *rstd = nullptr;
-    if (dev_alloc(&part, (size_t)512 * C) || dev_alloc(&mean, C) || dev_alloc(&rstd, C)) return -1;
+    if (dev_alloc(&part, (size_t)2 * 512 * C) || dev_alloc(&mean, C) || dev_alloc(&rstd, C)) return -1;
     run_layernorm(nullptr, x, HW, C, g, b, part, mean, rstd, out, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());

@@ -65,7 +65,7 @@ def test_attention(lib):
 
 
 def test_layernorm_ppm_upsample(lib):
-    for hw, c in [(45, 512), (153, 128), (1000, 512)]:
+    for hw, c in [(45, 512), (153, 128), (1000, 512), (2145, 512), (1, 128), (1300, 256)]:   # 2145: empty strips (512 strips of 5 pixels)
         opcheck.layernorm(lib, MEM, hw, c)
     for h, w, pid in [(5, 9, 0), (9, 17, 1), (13, 25, 1), (6, 6, 0), (97 // 4, 193 // 4, 0)]:
         opcheck.ppm(lib, MEM, h, w, pid)
