@@ -117,16 +117,20 @@ def _pp_sequential(T, P, depth):
 
 def test_path_parallel_schedule_matches_sequential():
     ctx = mp.get_context("spawn")
-    for (T, P, depth) in ((9, 4, 3), (6, 2, 1)):                       # td4 (FIFO 3) with a ragged last round; td2 (FIFO 1)
+    # td4 (FIFO 3) on 2 ranks with a ragged last round; td2 (FIFO 1) on 2 ranks; td4 on 4 ranks = one sub-network per rank,
+    # every entry a frame needs comes from a peer (world_size > FIFO depth + 1 is covered by the in-order pushes)
+    for (W, T, P, depth) in ((2, 9, 4, 3), (2, 6, 2, 1), (4, 10, 4, 3)):
         q = ctx.Queue()
         port = _free_port()
-        ps = [ctx.Process(target=_pp_worker, args=(r, 2, port, q, T, P, depth)) for r in range(2)]
+        ps = [ctx.Process(target=_pp_worker, args=(r, W, port, q, T, P, depth)) for r in range(W)]
         for p in ps:
             p.start()
         res = dict(q.get(timeout=300) for _ in ps)
         for p in ps:
             p.join(timeout=60)
             assert p.exitcode == 0
-        assert sorted(res[0]) == list(range(0, T, 2)) and sorted(res[1]) == list(range(1, T, 2))   # rank g serves t = g mod 2
-        merged = {**res[0], **res[1]}
+        merged = {}
+        for r in range(W):
+            assert sorted(res[r]) == list(range(r, T, W))              # rank g serves t = g mod W
+            merged.update(res[r])
         assert merged == _pp_sequential(T, P, depth)                   # every rank's FIFO went through the sequential states
