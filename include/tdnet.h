@@ -4,7 +4,7 @@
  * The reference's boundary for this path is a Python nn.Module API, not a C API:
  *     model = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=...)      Testing/test.py:26
  *     out   = model(image, pos_id=i % path_num)                               Testing/test.py:53
- * tdnet_amd/model/{td4_psp18,td2_psp50}.py keep that Python API and call the entry points below through
+ * tdnet_amd/model/{td4_psp18,td2_psp50,pspnet}.py keep that Python API and call the entry points below through
  * ctypes; INTEGRATION.md shows the stub.  Plain pointers and sizes only -- no torch types cross this line.
  *
  * Conventions
@@ -27,8 +27,9 @@ extern "C" {
 typedef struct tdnet tdnet_t;
 
 typedef struct tdnet_cfg {
-    int32_t model;      /* 4 = td4 (Testing/model/pspnet/td4_psp18.py:29-120), 2 = td2 (td2_psp50.py:29-96)        */
-    int32_t backbone;   /* 18 or 34 (BasicBlock ResNets, resnet.py:218-236)                                         */
+    int32_t model;      /* 4 = td4 (Testing/model/pspnet/td4_psp18.py:29-120), 2 = td2 (td2_psp50.py:29-96),
+                           1 = pspnet, the stateless comparison model (pspnet.py:31-115)                             */
+    int32_t backbone;   /* 18 / 34 (BasicBlock, resnet.py:218-236), 50 / 101 (Bottleneck + deep stem, :62-111,122-131)     */
     int32_t nclass;     /* 19 for Cityscapes (test.py:26)                                                            */
     int32_t height;     /* input H; the LayerNorm affine is [ceil(H/8), ceil(W/8)] (td4_psp18.py:107-110)            */
     int32_t width;      /* input W                                                                                   */
