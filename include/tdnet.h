@@ -36,8 +36,32 @@ typedef struct tdnet_cfg {
     int32_t device;     /* HIP device ordinal                                                                        */
 } tdnet_cfg;
 
+/* Per-handle kernel configuration.  Nothing in this library is process-wide: two handles in one process may differ.
+ * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
+#define TDNET_WINOGRAD_DEFAULT 3
+#define TDNET_ATTENTION_DEFAULT 0
+#define TDNET_STEM_DEFAULT 0
+typedef struct tdnet_opts {
+    int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
+                                convs (Cin >= 256, Cout >= 128), 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) =
+                                F(4x4,3x3) for the stride-1 3x3 convs with Cin, Cout >= 128 (ResNet layers 2-4 + FCN head), 4 = F(4x4,3x3)
+                                for every stride-1 3x3 (test hook).  All fp32.                                                    */
+    int32_t precision;       /* 0 = fp32 MFMA (default; the only mode the 1e-3 logits gate applies to), 1 = fp16 MFMA with fp32
+                                accumulation (BASELINE config 5)                                                                 */
+    int32_t pipeline;        /* conv software pipeline: 0 = one-stage prefetch, 1 (default) = two-stage                           */
+    int32_t gemm_persistent; /* 1 (default) = stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel,
+                                0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */
+    int32_t stagger;         /* start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups                      */
+    int32_t attention;       /* 0 (default) = exact two-pass softmax (row maxima first), 1 = single pass with online softmax        */
+    int32_t stem;            /* 0 (default) = layout change + conv7x7 + max-pool as three kernels, 1 = fused stem                 */
+    int32_t reserved[9];     /* must be 0                                                                                        */
+} tdnet_opts;
+void tdnet_opts_default(tdnet_opts* o);
+
 /* ---- lifecycle: replaces the nn.Module constructor + load_state_dict (td4_psp18.py:32-120, :232-240) ---------- */
-int  tdnet_create(const tdnet_cfg* cfg, tdnet_t** out);
+int  tdnet_create(const tdnet_cfg* cfg, tdnet_t** out);                                  /* default options */
+int  tdnet_create_opts(const tdnet_cfg* cfg, const tdnet_opts* opts /* NULL = defaults */, tdnet_t** out);
+int  tdnet_get_opts(const tdnet_t* h, tdnet_opts* out);
 void tdnet_destroy(tdnet_t* h);
 
 /* One call per state_dict entry, reference key names ("pretrained1.layer4.1.conv2.weight", ...), host fp32
@@ -94,32 +118,11 @@ double tdnet_last_ms(const tdnet_t* h, int which);
 double tdnet_last_flops(const tdnet_t* h, int which);
 double tdnet_last_launches(const tdnet_t* h, int which);
 
-/* Tuning hook (process-wide): conv software pipeline used by handles finalized after the call.
- * 0 = one-stage prefetch (tile s+1 in flight), 1 = two-stage (tile s+2 in flight, LDS writes between the MFMAs).     */
-int tdnet_set_conv_pipeline(int deep);
-/* Precision mode (process-wide, handles finalized after the call): 0 = fp32 MFMA, the default and the only mode that
- * meets the 1e-3 logits gate; 1 = fp16-input MFMA with fp32 accumulation for every conv but the stem (BASELINE config 5). */
-int tdnet_set_conv_precision(int fp16);
-/* Tuning hook: start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups, to de-phase the two
- * workgroups that share a CU.                                                                                       */
-int tdnet_set_conv_stagger(int units);
-/* Conv algorithm (process-wide, handles finalized after the call): 0 = direct implicit GEMM everywhere,
- * 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4 and the FCN head),
- * 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) = Winograd F(4x4,3x3) for the stride-1 3x3 convs with
- * Cin >= 128 and Cout >= 128 (ResNet layers 2-4 and the FCN head), 4 = F(4x4,3x3) for every stride-1 3x3 (test hook).
- * All modes are fp32 and meet the 1e-3 logits gate.                                                                  */
-#define TDNET_WINOGRAD_DEFAULT 3
-int tdnet_set_conv_winograd(int mode);
-/* Current process-wide conv configuration: bit 0 two-stage pipeline, bit 1 fp16-input MFMA, bits 2-4 Winograd mode, bit 5 persistent GEMM. */
-int tdnet_get_conv_config(void);
-/* Tuning hook: 1 (default) = stride-1 1x1 convs and the Winograd GEMMs run on the persistent multi-tile GEMM kernel,
- * 0 = on the one-tile-per-workgroup conv kernel.                                                                     */
-int tdnet_set_gemm_persistent(int on);
-
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */
 double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* stream);
-double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile /* -1: heuristic */, int iters, void* stream);
+double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile /* -1: heuristic */, int iters,
+                        const tdnet_opts* opts /* NULL = defaults */, void* stream);
 
 const char* tdnet_last_error(void);
 const char* tdnet_version(void);
@@ -128,11 +131,10 @@ const char* tdnet_version(void);
 /* NHWC conv: in [H,W,Cin] dev, weight OIHW host [Cout,Cin,KS,KS], bias host [Cout] or NULL, residual dev
  * [Ho,Wo,Cout] or NULL, act 0 none / 1 ReLU / 2 LeakyReLU(0.01); out [Ho,Wo,Cout] dev.                           */
 int tdnet_op_conv2d(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
-                    int Cout, int KS, int stride, int dil, const float* resid_dev, int act, float* out_dev, void* stream);
-/* the same with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64; 3..5: the same tiles on the two-stage pipeline) -- lets tests cover every variant */
-int tdnet_op_conv2d_tile(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
-                         int Cout, int KS, int stride, int dil, const float* resid_dev, int act, int tile,
-                         float* out_dev, void* stream);
+                    int Cout, int KS, int stride, int dil, const float* resid_dev, int act,
+                    const tdnet_opts* opts /* NULL = defaults */,
+                    int tile /* -1 = heuristic; 0: 128x128, 1: 64x128, 2: 128x64, 3..5: the same on the two-stage pipeline */,
+                    float* out_dev, void* stream);
 /* stem: NCHW image [3,H,W] -> conv7x7 s2 p3 (+bias) -> ReLU -> maxpool3x3 s2 p1 -> NHWC [H2,W2,64] (resnet.py:205-208) */
 int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const float* bias_host, float* out_dev, void* stream);
 /* softmax(q k^T / sqrt(dk)) v' + bias + resid: q [Lq,64], k [Lk,64], vp [Lk,DV], bias dev [DV]|NULL, resid [Lq,DV]|NULL */

@@ -19,15 +19,59 @@ Every function cites the reference lines it follows (paths relative to /root/ref
 """
 import math
 import os
-import sys
+from collections import namedtuple
 
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from tdnet_amd import arch  # noqa: E402  (pure-python spec, no HIP)
-
 BN_EPS = 1e-5
+
+# ---- architecture facts, restated HERE from the reference -- the checker does not take its graph description from the product
+# package (tdnet_amd/arch.py states the same facts for the HIP side; tests/test_oracle.py cross-checks the two statements) ----------
+RefBlock = namedtuple("RefBlock", "name kind stride dil1 dil2 downsample")
+
+_BLOCK_COUNTS = {"resnet18": ("basic", (2, 2, 2, 2)), "resnet34": ("basic", (3, 4, 6, 3)),          # resnet.py:218-256
+                 "resnet50": ("bottleneck", (3, 4, 6, 3)), "resnet101": ("bottleneck", (3, 4, 23, 3))}
+
+
+def ref_backbone_blocks(backbone):
+    """Block list of ResNet(dilated=True, multi_grid=True) as resnet.py:138-149 builds it through _make_layer (:172-202):
+    layer1 (64), layer2 (128, stride 2), layer3 (256, stride 1, dilation 2), layer4 (512, stride 1, dilation 4, multi_grid).
+    `dil1` is the block's `dilation` (conv1 of a BasicBlock / the 3x3 of a Bottleneck), `dil2` its `previous_dilation` (conv2 of a
+    BasicBlock, resnet.py:32-37; unused by Bottleneck)."""
+    kind, counts = _BLOCK_COUNTS[backbone]
+    expansion = 4 if kind == "bottleneck" else 1
+    inplanes = 128 if kind == "bottleneck" else 64                  # deep_base for the Bottleneck nets (td2_psp50.py:63-66, resnet.py:118)
+    out = []
+    for li, (planes, nblocks, stride, dilation, multi_grid) in enumerate(
+            ((64, counts[0], 1, 1, False), (128, counts[1], 2, 1, False), (256, counts[2], 1, 2, False), (512, counts[3], 1, 4, True)), 1):
+        downsample = stride != 1 or inplanes != planes * expansion      # resnet.py:173-178
+        if multi_grid:                                                  # :182-184
+            first = 4
+        elif dilation in (1, 2):                                        # :185-187
+            first = 1
+        elif dilation == 4:                                             # :188-190
+            first = 2
+        else:
+            raise RuntimeError("=> unknown dilation size: {}".format(dilation))
+        out.append(RefBlock("layer%d.0" % li, kind, stride, first, dilation, downsample))
+        inplanes = planes * expansion
+        for i in range(1, nblocks):                                     # :195-200
+            out.append(RefBlock("layer%d.%d" % (li, i), kind, 1, (4, 8, 16)[i] if multi_grid else dilation, dilation, False))
+    return out
+
+
+# Attention modules in APPLICATION order per sub-network (0-based path index): forward_path1..4 of td4_psp18.py
+#   path1 :145-147   atn1_2(K[0],V[0],Q[1]) -> atn1_3 -> atn1_4        path2 :166-168   atn2_3 -> atn2_4 -> atn2_1
+#   path3 :185-187   atn3_4 -> atn3_1 -> atn3_2                        path4 :204-206   atn4_1 -> atn4_2 -> atn4_3
+# and td2_psp50.py:120 (atn1) / :138 (atn2).
+REF_ATN_ORDER = {"td4": (("atn1_2", "atn1_3", "atn1_4"), ("atn2_3", "atn2_4", "atn2_1"),
+                         ("atn3_4", "atn3_1", "atn3_2"), ("atn4_1", "atn4_2", "atn4_3")),
+                 "td2": (("atn1",), ("atn2",))}
+# PyramidPooling(path_num, pid) per sub-network: td4_psp18.py:80-83 (path_num//2 = 2; pid 0,1,0,1), td2_psp50.py:76-77 (2; pid 0,1)
+REF_PSP = {"td4": (2, (0, 1, 0, 1)), "td2": (2, (0, 1))}
+# FIFO depth: buffer_contral pops when len > 3 (td4_psp18.py:130) / > 1 (td2_psp50.py:105)
+REF_FIFO = {"td4": 3, "td2": 1}
 
 
 class TorchOps:
@@ -173,9 +217,15 @@ class TDNetRef:
     """Stateful per-frame forward: td4_psp18.py:123-229 / td2_psp50.py:98-155 (FIFO depth P-1, warm-up branch)."""
 
     def __init__(self, spec, state_dict):
+        """spec: anything with .name ("td4" | "td2") and .backbone ("resnet18" ...); everything else the graph needs is restated
+        above from the reference."""
         self.spec = spec
+        self.name, self.path_num = spec.name, {"td4": 4, "td2": 2}[spec.name]
+        self.fifo = REF_FIFO[spec.name]
+        self.psp_path_num, self.pids = REF_PSP[spec.name]
+        self.atn_order = REF_ATN_ORDER[spec.name]
         self.sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in state_dict.items()}
-        self.blocks = arch.backbone_blocks(spec.backbone)
+        self.blocks = ref_backbone_blocks(spec.backbone)
         self.Q, self.K, self.V = [], [], []
         self.trace = None            # optional dict filled with stage outputs of the last frame
 
@@ -187,17 +237,17 @@ class TDNetRef:
             self.trace[name] = val
 
     def forward_lowres(self, img, pos_id):
-        sp, sd = self.spec, self.sd
+        sd = self.sd
         p = pos_id + 1
         c4 = backbone(img, sd, "pretrained%d" % p, self.blocks)
-        z = pyramid_pooling(c4, sd, "psp%d" % p, sp.psp_path_num, sp.pids[pos_id])
+        z = pyramid_pooling(c4, sd, "psp%d" % p, self.psp_path_num, self.pids[pos_id])
         q_cur, v_cur = encoding(z, sd, "enc%d" % p, False)
         self._t("c4", c4); self._t("z", z); self._t("q_cur", q_cur); self._t("v_cur", v_cur)
-        if len(self.Q) < sp.fifo:                                   # warm-up: td4_psp18.py:142-143
+        if len(self.Q) < self.fifo:                                 # warm-up: td4_psp18.py:142-143
             feat = v_cur
         else:
-            names = sp.atn_names[pos_id]
-            if sp.name == "td4":                                     # td4_psp18.py:145-151
+            names = self.atn_order[pos_id]
+            if self.name == "td4":                                   # td4_psp18.py:145-151
                 v2 = attention(self.K[0], self.V[0], self.Q[1], sd, names[0])
                 v3 = attention(self.K[1], v2 + self.V[1], self.Q[2], sd, names[1])
                 v4 = attention(self.K[2], v3 + self.V[2], q_cur, sd, names[2], fea_size=z.shape)
@@ -213,7 +263,7 @@ class TDNetRef:
         q_, k_, v_ = encoding(z, sd, "enc%d" % p, True)              # td4_psp18.py:153-154
         self._t("cache_q", q_); self._t("cache_k", k_); self._t("cache_v", v_)
         self.Q.append(q_); self.K.append(k_); self.V.append(v_)
-        if len(self.Q) > sp.fifo:                                   # buffer_contral: td4_psp18.py:123-134
+        if len(self.Q) > self.fifo:                                 # buffer_contral: td4_psp18.py:123-134
             self.Q.pop(0); self.K.pop(0); self.V.pop(0)
         return out
 
@@ -232,7 +282,7 @@ class PSPNetRef:
     def __init__(self, spec, state_dict):
         self.spec = spec
         self.sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in state_dict.items()}
-        self.blocks = arch.backbone_blocks(spec.backbone)
+        self.blocks = ref_backbone_blocks(spec.backbone)
         self.trace = None
 
     def reset(self):

@@ -18,15 +18,29 @@ class TdnetCfg(ctypes.Structure):
                 ("height", ctypes.c_int32), ("width", ctypes.c_int32), ("device", ctypes.c_int32)]
 
 
+class TdnetOpts(ctypes.Structure):
+    """include/tdnet.h tdnet_opts: per-handle kernel configuration (nothing in the library is process-wide)."""
+    _fields_ = [("winograd", ctypes.c_int32), ("precision", ctypes.c_int32), ("pipeline", ctypes.c_int32),
+                ("gemm_persistent", ctypes.c_int32), ("stagger", ctypes.c_int32), ("attention", ctypes.c_int32),
+                ("stem", ctypes.c_int32), ("reserved", ctypes.c_int32 * 9)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 class TdnetError(RuntimeError):
     pass
 
 
 # name -> (restype, argtypes); every symbol include/tdnet.h declares
 WINOGRAD_DEFAULT = 3          # include/tdnet.h TDNET_WINOGRAD_DEFAULT: F(4x4,3x3) for the wide stride-1 3x3 convs
+c_opts_p = ctypes.POINTER(TdnetOpts)
 
 SYMBOLS = {
+    "tdnet_opts_default": (None, [c_opts_p]),
     "tdnet_create": (ctypes.c_int, [ctypes.POINTER(TdnetCfg), ctypes.POINTER(c_void_p)]),
+    "tdnet_create_opts": (ctypes.c_int, [ctypes.POINTER(TdnetCfg), c_opts_p, ctypes.POINTER(c_void_p)]),
+    "tdnet_get_opts": (ctypes.c_int, [c_void_p, c_opts_p]),
     "tdnet_destroy": (None, [c_void_p]),
     "tdnet_set_weight": (ctypes.c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "tdnet_finalize_weights": (ctypes.c_int, [c_void_p]),
@@ -47,21 +61,13 @@ SYMBOLS = {
     "tdnet_last_ms": (ctypes.c_double, [c_void_p, ctypes.c_int]),
     "tdnet_last_flops": (ctypes.c_double, [c_void_p, ctypes.c_int]),
     "tdnet_last_launches": (ctypes.c_double, [c_void_p, ctypes.c_int]),
-    "tdnet_set_conv_pipeline": (ctypes.c_int, [ctypes.c_int]),
-    "tdnet_set_conv_precision": (ctypes.c_int, [ctypes.c_int]),
-    "tdnet_set_conv_stagger": (ctypes.c_int, [ctypes.c_int]),
-    "tdnet_set_conv_winograd": (ctypes.c_int, [ctypes.c_int]),
-    "tdnet_get_conv_config": (ctypes.c_int, []),
-    "tdnet_set_gemm_persistent": (ctypes.c_int, [ctypes.c_int]),
     "tdnet_bench_mfma_peak": (ctypes.c_double, [ctypes.c_int, ctypes.c_int, c_void_p]),
-    "tdnet_bench_conv": (ctypes.c_double, [ctypes.c_int] * 9 + [c_void_p]),
+    "tdnet_bench_conv": (ctypes.c_double, [ctypes.c_int] * 9 + [c_opts_p, c_void_p]),
     "tdnet_last_error": (ctypes.c_char_p, []),
     "tdnet_version": (ctypes.c_char_p, []),
     "tdnet_op_conv2d": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
-    "tdnet_op_conv2d_tile": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
-                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int,
-                                            c_void_p, c_void_p]),
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, c_opts_p, ctypes.c_int,
+                                       c_void_p, c_void_p]),
     "tdnet_op_stem": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_op_attention": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, c_void_p, c_void_p]),
@@ -92,6 +98,17 @@ class Lib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+
+    def opts(self, **kw):
+        """tdnet_opts with the library defaults, overridden by keyword (winograd=0, precision=1, ...)."""
+        o = TdnetOpts()
+        self.tdnet_opts_default(ctypes.byref(o))
+        for k, v in kw.items():
+            if k not in dict(TdnetOpts._fields_) or k == "reserved":
+                raise TypeError("unknown tdnet_opts field %r" % k)
+            if v is not None:
+                setattr(o, k, int(v))
+        return o
 
     def check(self, rc):
         if rc is not None and rc < 0:

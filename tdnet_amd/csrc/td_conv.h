@@ -348,20 +348,15 @@ static inline ConvTileDims conv_tile_dims(ConvTile t) {
     }
 }
 
-// Set by tdnet_set_conv_pipeline (tuning hook): 0 = single-stage prefetch, 1 = two-stage ("deep") pipeline.
-static int g_conv_deep = 1;      // measured on MI355X: +4..6 % on every layer shape (profiles/r01b_kernel_probe.txt)
-// Set by tdnet_set_conv_precision: 0 = fp32 MFMA (default), 1 = fp16-input MFMA with fp32 accumulate (td_conv_h.h).
-static int g_conv_fp16 = 0;
-// Set by tdnet_set_conv_stagger: start delay (x512 cycles) of the second workgroup on each CU; 0 = off.
-static int g_conv_stagger = 0;
-
+// `deep` (tdnet_opts.pipeline): 0 = single-stage prefetch, 1 = two-stage pipeline (the default: measured +4..6 % on every layer
+// shape on MI355X, profiles/r01b_kernel_probe.txt).
 // Choose the tile: 128-wide N when Cout allows, and the smaller M tile when 128x128 would leave CUs idle.
 // Cost model: the launch ends when the busiest CU has finished its share of the workgroups, so what matters is the
 // per-CU quantisation ceil(blocks / 256 CUs) times the work of one block, divided by the tile's measured relative
 // throughput (profiles/r01b_kernel_probe.txt: 128x128 1.00, 64x128 0.97, 128x64 0.95).  At 1024x2048 this picks 128x128
 // for layers 3-4 (1024 blocks = 4 per CU); at the native 769x1537 (147 M-tiles -> 588 blocks = 2.3 per CU) it picks
 // 64x128 (1172 blocks = 4.6 per CU), which removes most of the last-round idle time.
-static inline ConvTile conv_pick_tile(int M, int Cout) {
+static inline ConvTile conv_pick_tile(int M, int Cout, bool deep) {
     ConvTile best = CT_128x64;
     if (Cout > 64) {
         static const struct { ConvTile t; int bm, bn; double eff; } cand[3] = {
@@ -374,7 +369,7 @@ static inline ConvTile conv_pick_tile(int M, int Cout) {
             if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].t; }
         }
     }
-    return g_conv_deep ? (ConvTile)(best + 3) : best;
+    return deep ? (ConvTile)(best + 3) : best;
 }
 
 static inline int conv_cout_pad(int Cout, ConvTile t) {

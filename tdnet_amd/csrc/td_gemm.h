@@ -187,8 +187,8 @@ static inline bool gemm_supports(int K) { return K % 64 == 0; }
 // workgroup alone keeps the MFMA pipes ~62 % busy, two of three ~90 %).  Measured on the F(4x4) GEMMs of the frame
 // (tools/wino_tile_probe.py): equal rounds -> the three shapes tie; 256-channel layers at 769x1537: 64x128 0.093 ms vs 128x128
 // 0.110 ms (792 tiles of 128x128 = 1.55 rounds of 512).
-static inline ConvTile gemm_pick_tile(long rows, int nbatch, int N) {
-    if (N <= 64) return g_conv_deep ? CT_128x64_DEEP : CT_128x64;
+static inline ConvTile gemm_pick_tile(long rows, int nbatch, int N, bool deep) {
+    if (N <= 64) return deep ? CT_128x64_DEEP : CT_128x64;
     static const struct { ConvTile t; int bm, bn, bpc; double eff; } cand[3] = {
         {CT_128x128, 128, 128, 2, 1.00}, {CT_64x128, 64, 128, 3, 0.97}, {CT_128x64, 128, 64, 3, 0.95}};
     ConvTile best = CT_128x128;
@@ -201,7 +201,7 @@ static inline ConvTile gemm_pick_tile(long rows, int nbatch, int N) {
         const double cost = (double)cand[i].bm * cand[i].bn * (full * cand[i].bpc + (j ? j / u : 0.0)) / cand[i].eff;
         if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].t; }
     }
-    return g_conv_deep ? (ConvTile)(best + 3) : best;
+    return deep ? (ConvTile)(best + 3) : best;
 }
 
 template <int BM, int BN, int WGM, int WGN>

@@ -41,6 +41,24 @@ static int td_fail(const char* fmt, ...) {
         if (e_ != hipSuccess) return td_fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+#define TD_TRY(expr) do { if ((expr) != 0) return -1; } while (0)
+
+// Every C-ABI entry that touches the device runs under the HANDLE's device and restores the caller's current device on exit:
+// PyTorch tracks its own current device, and a library that changed it behind torch's back would misplace later allocations;
+// a handle on cuda:1 used while the current device is 0 would otherwise launch its kernels and side stream on the wrong GPU.
+struct DevGuard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; switched = ok; }
+    }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define TD_ON_DEVICE(n, ...)                                                                      \
+    DevGuard dev_guard_((n)->cfg.device);                                                         \
+    if (!dev_guard_.ok) { td_fail("cannot select HIP device %d", (n)->cfg.device); return __VA_ARGS__; }
+
 extern "C" const char* tdnet_last_error(void) { return g_err; }
 extern "C" const char* tdnet_version(void) { return "tdnet_amd 0.1 (gfx950, fp32 MFMA)"; }
 
@@ -94,6 +112,8 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
+    int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
+    int stagger = 0;                                                   // tdnet_opts.stagger
     int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3)): d_wp = (m+2)^2 packed 1x1 weight sets (td_wino.h)
     float* d_zero = nullptr;                                           // zero bias for the batched GEMM pass
     ConvTile tile = CT_128x128;
@@ -103,31 +123,51 @@ struct ConvLayer {
     double flops_per_pixel() const { return 2.0 * Cout * (stem ? 3.0 * KS * KS : (double)Cin * KS * KS); }
 };
 
-// 1 = stride-1 1x1 convs and the Winograd GEMMs run on the persistent multi-tile GEMM kernel (td_gemm.h), 0 = on k_conv_igemm
-static int g_gemm_persistent = 1;
-// 0 = direct convs only, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (Cin >= 256, Cout >= 128: ResNet layers 3-4
-// and the FCN head), 2 = every stride-1 3x3 conv.  Default 1: measured +20 % frames/s at 1024x2048, +23 % at 769x1537, with
-// logits as close to the fp32 CPU path as the direct kernels' (profiles/r01f_*).
-static int g_conv_wino = TDNET_WINOGRAD_DEFAULT;
+// Per-handle kernel configuration (include/tdnet.h tdnet_opts); nothing here is process-wide: two handles in one process may differ.
+extern "C" void tdnet_opts_default(tdnet_opts* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->winograd = TDNET_WINOGRAD_DEFAULT;   // F(4x4,3x3) for the stride-1 3x3 convs with Cin, Cout >= 128
+    o->precision = 0;                       // fp32 MFMA: the only mode the 1e-3 logits gate applies to
+    o->pipeline = 1;                        // two-stage conv prefetch
+    o->gemm_persistent = 1;                 // stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel
+    o->stagger = 0;
+    o->attention = TDNET_ATTENTION_DEFAULT;
+    o->stem = TDNET_STEM_DEFAULT;
+}
+static tdnet_opts opts_or_default(const tdnet_opts* o) {
+    tdnet_opts d;
+    tdnet_opts_default(&d);
+    if (!o) return d;
+    d = *o;
+    d.winograd = d.winograd < 0 ? 0 : d.winograd > 4 ? 4 : d.winograd;
+    d.precision = d.precision ? 1 : 0;
+    d.pipeline = d.pipeline ? 1 : 0;
+    d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
+    d.stagger = d.stagger < 0 ? 0 : d.stagger > 64 ? 64 : d.stagger;
+    return d;
+}
 
 static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2 * pad - dil * (KS - 1) - 1) / stride + 1; }
 
 // Upload a BN-folded OIHW weight + bias as a ConvLayer for an output of M pixels.
 static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& b, int Cout, int Cin, int KS,
-                           int stride, int dil, int act, bool stem, long M, int forced_tile = -1) {
+                           int stride, int dil, int act, bool stem, long M, const tdnet_opts& o, int forced_tile = -1) {
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
+    L.pers = o.gemm_persistent; L.stagger = o.stagger;
+    const bool deep = o.pipeline != 0;
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
-    const bool wino_ok = g_conv_wino && !g_conv_fp16 && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
-                         (g_conv_wino == 2 || g_conv_wino == 4 || (Cin >= (g_conv_wino == 3 ? 128 : 256) && Cout >= 128));
-    L.wino = !wino_ok ? 0 : g_conv_wino >= 3 ? 4 : 2;
+    const bool wino_ok = o.winograd && !o.precision && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
+                         (o.winograd == 2 || o.winograd == 4 || (Cin >= (o.winograd == 3 ? 128 : 256) && Cout >= 128));
+    L.wino = !wino_ok ? 0 : o.winograd >= 3 ? 4 : 2;
     if (L.wino) {
         // nb = (m+2)^2 batched [T x Cin] x [Cin x Cout] GEMMs, T = M / m^2 tiles: nb * T rows in total -> pick the tile for that many workgroups
         const int nb = (L.wino + 2) * (L.wino + 2);
-        const bool pers = g_gemm_persistent && gemm_supports(Cin);
+        const bool pers = o.gemm_persistent && gemm_supports(Cin);
         L.tile = forced_tile >= 0 ? (ConvTile)forced_tile
-               : pers ? gemm_pick_tile(wino_tiles_estimate(M, dil, L.wino), nb, Cout)
-                      : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout);
+               : pers ? gemm_pick_tile(wino_tiles_estimate(M, dil, L.wino), nb, Cout, deep)
+                      : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout, deep);
         L.CoutPad = conv_cout_pad(Cout, L.tile);
         L.nsteps = conv_nsteps(Cin, 1, false);
         std::vector<std::vector<float>> U;
@@ -145,9 +185,9 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         TD_HIP(hipMemcpy(L.d_zero, zz.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     }
-    L.h16 = g_conv_fp16 && !stem && Cin % 64 == 0;
-    const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && g_gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
-    L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout) : conv_pick_tile((int)M, Cout);
+    L.h16 = o.precision && !stem && Cin % 64 == 0;
+    const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && o.gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
+    L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout, deep) : conv_pick_tile((int)M, Cout, deep);
     L.CoutPad = conv_cout_pad(Cout, L.tile);
     if (L.h16) {
         L.nsteps = conv_nsteps_h(Cin, KS);
@@ -196,6 +236,7 @@ struct ProfRec { int family; int dominant; hipEvent_t e0, e1; double flops; };  
 
 struct tdnet {
     tdnet_cfg cfg;
+    tdnet_opts opts;                                                   // per-handle kernel configuration (never process-wide)
     int P = 0, DV = 0, MID = 0, FIFO = 0, C = 512, SC = 64;            // C = backbone output channels, SC = stem output channels
     bool deep = false;
     int H = 0, W = 0, H1 = 0, W1 = 0, H2 = 0, W2 = 0, h = 0, w = 0, hk = 0, wk = 0, Lq = 0, Lk = 0;
@@ -315,7 +356,9 @@ static void build_expected(tdnet* n) {
     }
 }
 
-extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) {
+extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) { return tdnet_create_opts(cfg, nullptr, out); }
+
+extern "C" int tdnet_create_opts(const tdnet_cfg* cfg, const tdnet_opts* opts, tdnet_t** out) {
     if (!cfg || !out) return td_fail("tdnet_create: null argument");
     if (cfg->model != 4 && cfg->model != 2 && cfg->model != 1)
         return td_fail("tdnet_create: model must be 4 (td4), 2 (td2) or 1 (single-frame PSPNet), got %d", cfg->model);
@@ -327,9 +370,14 @@ extern "C" int tdnet_create(const tdnet_cfg* cfg, tdnet_t** out) {
         return td_fail("tdnet_create: resnet101 is the PSPNet baseline's backbone (pspnet.py:36); psp accepts 50 or 101");
     if (cfg->nclass < 1 || cfg->nclass > 32) return td_fail("tdnet_create: nclass must be in 1..32");
     if (cfg->height < 9 || cfg->width < 9) return td_fail("tdnet_create: input too small");
-    TD_HIP(hipSetDevice(cfg->device));
+    {
+        int ndev = 0;
+        TD_HIP(hipGetDeviceCount(&ndev));
+        if (cfg->device < 0 || cfg->device >= ndev) return td_fail("tdnet_create: device %d out of range (%d visible)", cfg->device, ndev);
+    }
     tdnet* n = new tdnet();
     n->cfg = *cfg;
+    n->opts = opts_or_default(opts);
     n->P = cfg->model;
     const int exp = cfg->backbone >= 50 ? 4 : 1;                       // Bottleneck expansion (td2_psp50.py:63-66)
     n->deep = cfg->backbone >= 50;
@@ -360,6 +408,7 @@ static void free_path(PathLayers& p) {
 }
 extern "C" void tdnet_destroy(tdnet_t* n) {
     if (!n) return;
+    TD_ON_DEVICE(n);
     for (auto& p : n->paths) free_path(p);
     for (float* q : {n->img4, n->s1, n->s1b, n->bx, n->bt, n->br, n->bu, n->rowpart, n->pooled, n->ppmfeat, n->z, n->v_cur, n->q1, n->q_cur,
                      n->k1, n->vp, n->chain_a, n->chain_b, n->feat, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, n->headmid,
@@ -478,6 +527,7 @@ static double frame_flops(const tdnet* n);
 extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     if (!n) return td_fail("tdnet_finalize_weights: null handle");
     if (n->finalized) return td_fail("tdnet_finalize_weights: already finalized");
+    TD_ON_DEVICE(n, -1);
     for (auto& kv : n->expected) {
         const std::string& k = kv.first;
         if (k.compare(0, 10, "pretrained") == 0 && (k.find(".fc.weight") != std::string::npos || k.find(".fc.bias") != std::string::npos)) continue;
@@ -494,14 +544,14 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         const std::string pre = n->cfg.model == 1 ? std::string("pretrained") : std::string(b);
         if (n->deep) {                                                 // conv3x3 s2 3->64, conv3x3 64->64, conv3x3 64->128 (+bn1)
             Folded f0 = fold(n, pre + ".conv1.0.weight", "", pre + ".conv1.1", 64);
-            if (make_conv_layer(L.stem, f0.w, f0.b, 64, 3, 3, 2, 1, 1, true, (long)n->H1 * n->W1)) return -1;
+            if (make_conv_layer(L.stem, f0.w, f0.b, 64, 3, 3, 2, 1, 1, true, (long)n->H1 * n->W1, n->opts)) return -1;
             Folded f1 = fold(n, pre + ".conv1.3.weight", "", pre + ".conv1.4", 64);
-            if (make_conv_layer(L.stem2, f1.w, f1.b, 64, 64, 3, 1, 1, 1, false, (long)n->H1 * n->W1)) return -1;
+            if (make_conv_layer(L.stem2, f1.w, f1.b, 64, 64, 3, 1, 1, 1, false, (long)n->H1 * n->W1, n->opts)) return -1;
             Folded f2 = fold(n, pre + ".conv1.6.weight", "", pre + ".bn1", 128);
-            if (make_conv_layer(L.stem3, f2.w, f2.b, 128, 64, 3, 1, 1, 1, false, (long)n->H1 * n->W1)) return -1;
+            if (make_conv_layer(L.stem3, f2.w, f2.b, 128, 64, 3, 1, 1, 1, false, (long)n->H1 * n->W1, n->opts)) return -1;
         } else {
             Folded f = fold(n, pre + ".conv1.weight", "", pre + ".bn1", 64);
-            if (make_conv_layer(L.stem, f.w, f.b, 64, 3, 7, 2, 1, 1, true, (long)n->H1 * n->W1)) return -1;
+            if (make_conv_layer(L.stem, f.w, f.b, 64, 3, 7, 2, 1, 1, true, (long)n->H1 * n->W1, n->opts)) return -1;
         }
         int ch = n->H2, cw = n->W2;
         for (auto& s : n->bspec) {
@@ -512,21 +562,21 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             B.bott = s.bott;
             if (s.bott) {
                 Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.planes);
-                if (make_conv_layer(B.c1, f1.w, f1.b, s.planes, s.cin, 1, 1, 1, 1, false, (long)ch * cw)) return -1;
+                if (make_conv_layer(B.c1, f1.w, f1.b, s.planes, s.cin, 1, 1, 1, 1, false, (long)ch * cw, n->opts)) return -1;
                 Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.planes);
-                if (make_conv_layer(B.c2, f2.w, f2.b, s.planes, s.planes, 3, s.stride, s.dil1, 1, false, M)) return -1;
+                if (make_conv_layer(B.c2, f2.w, f2.b, s.planes, s.planes, 3, s.stride, s.dil1, 1, false, M, n->opts)) return -1;
                 Folded f3 = fold(n, bp + ".conv3.weight", "", bp + ".bn3", s.cout);
-                if (make_conv_layer(B.c3, f3.w, f3.b, s.cout, s.planes, 1, 1, 1, 1, false, M)) return -1;   // ReLU after the residual add
+                if (make_conv_layer(B.c3, f3.w, f3.b, s.cout, s.planes, 1, 1, 1, 1, false, M, n->opts)) return -1;   // ReLU after the residual add
             } else {
                 Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.cout);
-                if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M)) return -1;
+                if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M, n->opts)) return -1;
                 Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.cout);
-                if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M)) return -1;
+                if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M, n->opts)) return -1;
             }
             B.has_ds = s.ds;
             if (s.ds) {
                 Folded fd = fold(n, bp + ".downsample.0.weight", "", bp + ".downsample.1", s.cout);
-                if (make_conv_layer(B.ds, fd.w, fd.b, s.cout, s.cin, 1, s.stride, 1, 0, false, M)) return -1;
+                if (make_conv_layer(B.ds, fd.w, fd.b, s.cout, s.cin, 1, s.stride, 1, 0, false, M, n->opts)) return -1;
             }
             L.blocks.push_back(B);
             ch = oh; cw = ow;
@@ -545,7 +595,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             }
             if (upload(&L.d_ppm_w, pw) || upload(&L.d_ppm_b, pb)) return -1;
             Folded fh = fold(n, "head.conv5.1.weight", "", "head.conv5.2", n->MID);
-            if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, 2 * C, 3, 1, 1, 1, false, n->Lq)) return -1;
+            if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, 2 * C, 3, 1, 1, 1, false, n->Lq, n->opts)) return -1;
             if (upload(&L.d_cls_w, T(n, "head.conv5.5.weight")) || upload(&L.d_cls_b, T(n, "head.conv5.5.bias"))) return -1;
             continue;
         }
@@ -564,20 +614,20 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         const std::string ep = b;
         {
             Folded fv = fold(n, ep + ".w_vs.0.conv.weight", ep + ".w_vs.0.conv.bias", "", DV);
-            if (make_conv_layer(L.enc_v, fv.w, fv.b, DV, C, 1, 1, 1, 0, false, n->Lq)) return -1;
+            if (make_conv_layer(L.enc_v, fv.w, fv.b, DV, C, 1, 1, 1, 0, false, n->Lq, n->opts)) return -1;
             Folded q0 = fold(n, ep + ".w_qs.0.conv.weight", ep + ".w_qs.0.conv.bias", ep + ".w_qs.0.bn", 64);
-            if (make_conv_layer(L.enc_q0, q0.w, q0.b, 64, C, 1, 1, 1, 2, false, n->Lq)) return -1;
+            if (make_conv_layer(L.enc_q0, q0.w, q0.b, 64, C, 1, 1, 1, 2, false, n->Lq, n->opts)) return -1;
             Folded q1 = fold(n, ep + ".w_qs.1.conv.weight", ep + ".w_qs.1.conv.bias", "", 64);
-            if (make_conv_layer(L.enc_q1, q1.w, q1.b, 64, 64, 1, 1, 1, 0, false, n->Lq)) return -1;
+            if (make_conv_layer(L.enc_q1, q1.w, q1.b, 64, 64, 1, 1, 1, 0, false, n->Lq, n->opts)) return -1;
             Folded k0 = fold(n, ep + ".w_ks.0.conv.weight", ep + ".w_ks.0.conv.bias", ep + ".w_ks.0.bn", 64);
-            if (make_conv_layer(L.enc_k0, k0.w, k0.b, 64, C, 1, 4, 1, 2, false, n->Lk)) return -1;   // stride 4 = the key sub-sampling
+            if (make_conv_layer(L.enc_k0, k0.w, k0.b, 64, C, 1, 4, 1, 2, false, n->Lk, n->opts)) return -1;   // stride 4 = the key sub-sampling
             Folded k1 = fold(n, ep + ".w_ks.1.conv.weight", ep + ".w_ks.1.conv.bias", "", 64);
-            if (make_conv_layer(L.enc_k1, k1.w, k1.b, 64, 64, 1, 1, 1, 0, false, n->Lk)) return -1;
+            if (make_conv_layer(L.enc_k1, k1.w, k1.b, 64, 64, 1, 1, 1, 0, false, n->Lk, n->opts)) return -1;
         }
         for (auto& an : atn_order(n->cfg.model, p)) {
             AtnLayer A;
             std::vector<float> nob;
-            if (make_conv_layer(A.fc, T(n, an + ".fc.0.conv.weight"), nob, DV, DV, 1, 1, 1, 0, false, n->Lk)) return -1;
+            if (make_conv_layer(A.fc, T(n, an + ".fc.0.conv.weight"), nob, DV, DV, 1, 1, 1, 0, false, n->Lk, n->opts)) return -1;
             if (upload(&A.d_bias, T(n, an + ".fc.0.conv.bias"))) return -1;
             L.atn.push_back(A);
         }
@@ -586,7 +636,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         snprintf(b, sizeof(b), "head%d.conv5", p + 1);
         const std::string hp = b;
         Folded fh = fold(n, hp + ".0.weight", "", hp + ".1", n->MID);
-        if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, DV, 3, 1, 1, 1, false, n->Lq)) return -1;
+        if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, DV, 3, 1, 1, 1, false, n->Lq, n->opts)) return -1;
         if (upload(&L.d_cls_w, T(n, hp + ".4.weight")) || upload(&L.d_cls_b, T(n, hp + ".4.bias"))) return -1;
         (void)NC;
     }
@@ -643,11 +693,11 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         else TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
         prof_end(n, s);
         prof_begin(n, 0, 2, 2.0 * nb * T * (double)L.Cin * L.Cout, s);
-        if (g_gemm_persistent && gemm_supports(L.Cin)) {
+        if (L.pers && gemm_supports(L.Cin)) {
             GemmArgs ga;
             ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
             ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0;
-            gemm_launch(ga, L.tile, g_gemm_persistent > 1 ? g_gemm_persistent : 0, s);
+            gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
         } else {
             ConvArgs g;
             g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
@@ -668,14 +718,14 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = g_conv_stagger; a.nbatch = 1;
+    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
-    else if (g_gemm_persistent && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
+    else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
         ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0;
-        gemm_launch(ga, L.tile, g_gemm_persistent > 1 ? g_gemm_persistent : 0, s);
+        gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;
@@ -732,8 +782,8 @@ static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* o
     prof_end(n, s);
 }
 static int run_classifier(tdnet* n, const float* x, int HW, int C, int NC, const float* wgt, const float* bias, float* out, hipStream_t s) {
-    prof_begin(n, 2, false, 0, s);
     if (C % 16) return td_fail("classifier: C=%d is not a multiple of 16", C);
+    prof_begin(n, 2, false, 0, s);
     const int grid = (HW + 63) / 64, lds = (NC * C + 4 * NC * 64) * 4;
     if (NC <= 19) TD_LAUNCH((k_classifier<19>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
     else TD_LAUNCH((k_classifier<32>), dim3(grid), dim3(256), lds, s, x, wgt, bias, out, HW, C, NC);
@@ -777,13 +827,13 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
     TD_HIP(hipStreamWaitEvent(c, n->ev_fork, 0));
     if (n->P == 4) {
         const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
-        run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c);
+        TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c));
         if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c)) return -1;   // v2 + V[1]
-        run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c);
+        TD_TRY(run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c));
         if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c)) return -1;   // v3 + V[2]
-        run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c);                                              // (v3 + V[2]) W^T
+        TD_TRY(run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c));                                              // (v3 + V[2]) W^T
     } else {
-        run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c);
+        TD_TRY(run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c));
     }
     TD_HIP(hipEventRecord(n->ev_join, c));
     return 0;
@@ -794,27 +844,27 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     // backbone (resnet.py:204-215)
     run_stem_pre(n, img, n->H, n->W, n->img4, s);
     if (n->deep) {                                                     // resnet.py:122-131
-        run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1b, s);
-        run_conv(n, L.stem2, n->s1b, n->H1, n->W1, nullptr, n->s1, s);
-        run_conv(n, L.stem3, n->s1, n->H1, n->W1, nullptr, n->br, s);   // 128 ch at H1 x W1 -> br (sized for it below)
+        TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1b, s));
+        TD_TRY(run_conv(n, L.stem2, n->s1b, n->H1, n->W1, nullptr, n->s1, s));
+        TD_TRY(run_conv(n, L.stem3, n->s1, n->H1, n->W1, nullptr, n->br, s));   // 128 ch at H1 x W1 -> br (sized for it below)
     } else {
-        run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s);
+        TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s));
     }
     run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s);
     int ch = n->H2, cw = n->W2;
     for (auto& B : L.blocks) {
         int oh, ow;
         if (B.bott) {                                                  // resnet.py:91-111
-            run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s);                        // 1x1, input resolution
-            run_conv(n, B.c2, n->bt, ch, cw, nullptr, n->bu, s, &oh, &ow);              // 3x3 (stride, dilation)
+            TD_TRY(run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s));                        // 1x1, input resolution
+            TD_TRY(run_conv(n, B.c2, n->bt, ch, cw, nullptr, n->bu, s, &oh, &ow));              // 3x3 (stride, dilation)
             const float* res = n->bx;
-            if (B.has_ds) { run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s); res = n->br; }
-            run_conv(n, B.c3, n->bu, oh, ow, res, n->bx, s);                            // 1x1 x4 + residual + ReLU (in place when res == bx)
+            if (B.has_ds) { TD_TRY(run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s)); res = n->br; }
+            TD_TRY(run_conv(n, B.c3, n->bu, oh, ow, res, n->bx, s));                            // 1x1 x4 + residual + ReLU (in place when res == bx)
         } else {
-            run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow);
+            TD_TRY(run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow));
             const float* res = n->bx;
-            if (B.has_ds) { run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s); res = n->br; }
-            run_conv(n, B.c2, n->bt, oh, ow, res, n->bx, s);            // in-place on bx when res == bx (same element)
+            if (B.has_ds) { TD_TRY(run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s)); res = n->br; }
+            TD_TRY(run_conv(n, B.c2, n->bt, oh, ow, res, n->bx, s));            // in-place on bx when res == bx (same element)
         }
         ch = oh; cw = ow;
     }
@@ -822,21 +872,21 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     // pyramid pooling slice (td4_psp18.py:271-284)
     if (n->cfg.model == 1) {                                           // pspnet.py:73-89: PSPHead on c4, no temporal state
         run_ppm(n, c4, n->h, n->w, n->C, n->C, n->C / 4, L.d_ppm_w, L.d_ppm_b, 0, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
-        run_conv(n, L.head3, n->z, n->h, n->w, nullptr, n->headmid, s);
-        run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s);
+        TD_TRY(run_conv(n, L.head3, n->z, n->h, n->w, nullptr, n->headmid, s));
+        TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
         return n->failed ? -1 : 0;
     }
     run_ppm(n, c4, n->h, n->w, n->C, n->C / 2, n->C / 8, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
     // Encoding, pre=False (transformer.py:52-56)
-    run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s);
-    run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s);
-    run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, s);
+    TD_TRY(run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s));
+    TD_TRY(run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s));
+    TD_TRY(run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, s));
     // Encoding, pre=True (transformer.py:34-50) -> pending cache entry; q_ and v_ are the stride-4 subsample of q_cur / v_cur
     const int slot = free_slot(n);
     if (slot < 0) return td_fail("internal: no free cache slot");
     CacheSlot& cs = n->slots[slot];
-    run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, s);
-    run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, s);
+    TD_TRY(run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, s));
+    TD_TRY(run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, s));
     prof_begin(n, 2, false, 0, s);
     TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
     TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, s, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
@@ -861,8 +911,8 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
         feat = n->feat;
     }
     run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, s);
-    run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s);
-    run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s);
+    TD_TRY(run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s));
+    TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
     // FIFO push (td4_psp18.py:153-154, :123-134)
     const int slot = n->pending_slot;
     n->pending_slot = -1;
@@ -891,6 +941,7 @@ static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s)
 
 extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* logits, void* stream) {
     if (!n || !img || !logits) return td_fail("tdnet_forward: null argument");
+    TD_ON_DEVICE(n, -1);
     hipStream_t s = (hipStream_t)stream;
     if (forward_lowres(n, img, pos_id, s)) return -1;
     prof_begin(n, 2, false, 0, s);
@@ -901,12 +952,14 @@ extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* lo
 }
 extern "C" int tdnet_argmax(tdnet_t* n, const float* logits, int32_t* labels, void* stream) {
     if (!n || !logits || !labels) return td_fail("tdnet_argmax: null argument");
+    TD_ON_DEVICE(n, -1);
     TD_LAUNCH(k_argmax, dim3(td_grid_for((long)n->H * n->W)), dim3(256), 0, (hipStream_t)stream, logits, labels, n->cfg.nclass, (long)n->H * n->W);
     TD_HIP(hipGetLastError());
     return 0;
 }
 extern "C" int tdnet_forward_labels(tdnet_t* n, const float* img, int pos_id, int32_t* labels, void* stream) {
     if (!n || !img || !labels) return td_fail("tdnet_forward_labels: null argument");
+    TD_ON_DEVICE(n, -1);
     hipStream_t s = (hipStream_t)stream;
     if (forward_lowres(n, img, pos_id, s)) return -1;
     prof_begin(n, 2, false, 0, s);
@@ -922,6 +975,7 @@ extern "C" int tdnet_forward_labels(tdnet_t* n, const float* img, int pos_id, in
 // propagates.  The FIFO of every rank therefore holds exactly what the sequential td4_psp18.py:123-154 would hold.
 extern "C" int tdnet_encode(tdnet_t* n, const float* img, int pos_id, void* stream) {
     if (!n || !img) return td_fail("tdnet_encode: null argument");
+    TD_ON_DEVICE(n, -1);
     if (frame_checks(n, pos_id, "tdnet_encode")) return -1;
     if (n->cfg.model == 1) return td_fail("tdnet_encode: pspnet has no temporal state; use tdnet_forward");
     if (n->pending_slot >= 0) return td_fail("tdnet_encode: the previous encoded frame has not been propagated");
@@ -941,6 +995,7 @@ static int propagate_lowres(tdnet* n, hipStream_t s) {
 }
 extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
     if (!n || !logits) return td_fail("tdnet_propagate: null argument");
+    TD_ON_DEVICE(n, -1);
     hipStream_t s = (hipStream_t)stream;
     if (propagate_lowres(n, s)) return -1;
     launch_upsample(n->lowres, n->cfg.nclass, n->h, n->w, n->H, n->W, logits, s);
@@ -949,6 +1004,7 @@ extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
 }
 extern "C" int tdnet_propagate_labels(tdnet_t* n, int32_t* labels, void* stream) {
     if (!n || !labels) return td_fail("tdnet_propagate_labels: null argument");
+    TD_ON_DEVICE(n, -1);
     hipStream_t s = (hipStream_t)stream;
     if (propagate_lowres(n, s)) return -1;
     TD_LAUNCH(k_upsample_argmax, dim3(td_grid_for((long)n->H * n->W)), dim3(256), 0, s, (const float*)n->lowres, labels, n->cfg.nclass,
@@ -967,6 +1023,7 @@ extern "C" int tdnet_cache_dims(const tdnet_t* n, int* Lk, int* dk, int* dv) {
 extern "C" int tdnet_cache_export(tdnet_t* n, float* q, float* k, float* v, void* stream) {
     if (!n || !q || !k || !v) return td_fail("tdnet_cache_export: null argument");
     if (n->pending_slot < 0) return td_fail("tdnet_cache_export: no encoded frame (call tdnet_encode first)");
+    TD_ON_DEVICE(n, -1);
     const CacheSlot& c = n->slots[n->pending_slot];
     hipStream_t s = (hipStream_t)stream;
     TD_HIP(hipMemcpyAsync(q, c.q, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -977,6 +1034,7 @@ extern "C" int tdnet_cache_export(tdnet_t* n, float* q, float* k, float* v, void
 extern "C" int tdnet_cache_push(tdnet_t* n, const float* q, const float* k, const float* v, void* stream) {
     if (!n || !q || !k || !v) return td_fail("tdnet_cache_push: null argument");
     if (n->cfg.model == 1) return td_fail("tdnet_cache_push: pspnet has no cache");
+    TD_ON_DEVICE(n, -1);
     const int slot = free_slot(n);
     if (slot < 0) return td_fail("internal: no free cache slot");
     const CacheSlot& c = n->slots[slot];
@@ -1001,6 +1059,7 @@ extern "C" int tdnet_fifo_len(const tdnet_t* n) { return n ? (int)n->fifo.size()
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_t capacity) {
     if (!n || !name || !host) return td_fail("tdnet_get_stage: null argument");
+    TD_ON_DEVICE(n, -1);
     const std::string s = name;
     const float* src = nullptr;
     long rows = n->Lq, C = 0;
@@ -1065,18 +1124,11 @@ static double frame_flops(const tdnet* n) {
 }
 extern "C" double tdnet_flops_per_frame(const tdnet_t* n) { return n && n->finalized ? n->flops_frame : -1.0; }
 
-// Precision mode for handles finalized AFTER the call: 0 = fp32 MFMA (default, meets the 1e-3 logits gate),
-// 1 = fp16-input MFMA with fp32 accumulation for every conv except the stem (BASELINE config 5 "fp16 MFMA").
-extern "C" int tdnet_set_conv_precision(int fp16) { g_conv_fp16 = fp16 ? 1 : 0; return 0; }
-// 0 = direct convolutions (default), 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (layers 3-4), 2 = for every stride-1 3x3
-extern "C" int tdnet_set_conv_winograd(int mode) { g_conv_wino = mode < 0 ? 0 : mode > 4 ? 4 : mode; return 0; }
-// bit 0: two-stage pipeline, bit 1: fp16-input MFMA, bits 2-4: Winograd mode, bit 5: persistent GEMM, bits 8..: stagger
-extern "C" int tdnet_get_conv_config(void) { return (g_conv_deep & 1) | ((g_conv_fp16 & 1) << 1) | ((g_conv_wino & 7) << 2) | ((g_gemm_persistent ? 1 : 0) << 5) | (g_conv_stagger << 8); }
-// 0 = off, 1 = on, n > 1 = on with the grid forced to n workgroups (test hook: many tiles per workgroup)
-extern "C" int tdnet_set_gemm_persistent(int on) { g_gemm_persistent = on < 0 ? 0 : on; return 0; }
-extern "C" int tdnet_set_conv_stagger(int units) { g_conv_stagger = units < 0 ? 0 : units > 64 ? 64 : units; return 0; }
-// Tuning hook: selects the conv software pipeline for handles finalized AFTER the call (0: one-stage prefetch, 1: two-stage).
-extern "C" int tdnet_set_conv_pipeline(int deep) { g_conv_deep = deep ? 1 : 0; return 0; }
+extern "C" int tdnet_get_opts(const tdnet_t* n, tdnet_opts* out) {
+    if (!n || !out) return td_fail("tdnet_get_opts: null argument");
+    *out = n->opts;
+    return 0;
+}
 
 extern "C" int tdnet_set_profiling(tdnet_t* n, int on) {
     if (!n) return td_fail("tdnet_set_profiling: null handle");
@@ -1113,34 +1165,24 @@ extern "C" double tdnet_last_launches(const tdnet_t* n, int which) { return prof
 // single-operator entry points (tests)
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const float* w_host, const float* bias_host, int Cout, int KS,
-                               int stride, int dil, const float* resid, int act, float* out, void* stream) {
+                               int stride, int dil, const float* resid, int act, const tdnet_opts* opts, int tile, float* out,
+                               void* stream) {
+    // tile < 0: the heuristic's tile for this shape; 0..CT_COUNT-1: forced (0: 128x128, 1: 64x128, 2: 128x64, 3..5: the same on the
+    // two-stage pipeline) -- lets tests cover every variant
     if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d: KS must be 1 or 3");
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d: tile must be < %d", CT_COUNT);
+    const tdnet_opts o = opts_or_default(opts);
     ConvLayer L;
     std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
     if (bias_host) b.assign(bias_host, bias_host + Cout);
     const int pad = dil * (KS / 2);
     const long M = (long)out_size(H, KS, stride, dil, pad) * out_size(W, KS, stride, dil, pad);
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M)) return -1;
-    run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M, o, tile < 0 ? -1 : tile)) return -1;
+    const int rc = run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
     free_conv_layer(L);
-    return 0;
-}
-extern "C" int tdnet_op_conv2d_tile(const float* in, int H, int W, int Cin, const float* w_host, const float* bias_host, int Cout,
-                                    int KS, int stride, int dil, const float* resid, int act, int tile, float* out, void* stream) {
-    // same as tdnet_op_conv2d with a forced tile configuration (0: 128x128, 1: 64x128, 2: 128x64) -- test/tuning hook
-    if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_tile: KS must be 1 or 3");
-    if (tile < 0 || tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_tile: tile must be 0..%d", CT_COUNT - 1);
-    ConvLayer L;
-    std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
-    if (bias_host) b.assign(bias_host, bias_host + Cout);
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, 0, tile)) return -1;
-    run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
-    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
-    TD_HIP(hipGetLastError());
-    free_conv_layer(L);
-    return 0;
+    return rc;
 }
 extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host, const float* bias_host, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -1148,7 +1190,7 @@ extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host
     ConvLayer L;
     std::vector<float> w(w_host, w_host + 64 * 3 * 49), b;
     if (bias_host) b.assign(bias_host, bias_host + 64);
-    if (make_conv_layer(L, w, b, 64, 3, 7, 2, 1, 1, true, (long)H1 * W1)) return -1;
+    if (make_conv_layer(L, w, b, 64, 3, 7, 2, 1, 1, true, (long)H1 * W1, opts_or_default(nullptr))) return -1;
     float *img4 = nullptr, *s1 = nullptr;
     if (dev_alloc(&img4, (size_t)H * W * 4) || dev_alloc(&s1, (size_t)H1 * W1 * 64)) return -1;
     run_stem_pre(nullptr, img, H, W, img4, s);
@@ -1245,7 +1287,9 @@ extern "C" double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* str
     return ms > 0.f ? flop / (ms * 1e-3) / 1e12 : -1.0;
 }
 // Average device time (ms, HIP events on `stream`) of `iters` launches of one conv configuration on random data.
-extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile, int iters, void* stream) {
+extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile, int iters,
+                                   const tdnet_opts* opts, void* stream) {
+    const tdnet_opts o = opts_or_default(opts);
     if ((KS != 1 && KS != 3) || Cin % 32 || tile < -1 || tile >= CT_COUNT) { td_fail("tdnet_bench_conv: bad arguments"); return -1.0; }
     hipStream_t s = (hipStream_t)stream;
     ConvLayer L;
@@ -1256,7 +1300,7 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     for (auto& v : x) v = rnd();
     const int pad_ = dil * (KS / 2);
     const long M_ = (long)out_size(H, KS, stride, dil, pad_) * out_size(W, KS, stride, dil, pad_);
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, M_, tile)) return -1.0;   // tile -1: the heuristic's choice for this M
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, M_, o, tile)) return -1.0;   // tile -1: the heuristic's choice for this M
     float *din = nullptr, *dout = nullptr;
     if (upload(&din, x)) return -1.0;
     const int Ho = out_size(H, KS, stride, dil, L.pad), Wo = out_size(W, KS, stride, dil, L.pad);

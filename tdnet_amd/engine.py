@@ -20,11 +20,13 @@ def _ptr(a):
 
 
 class Engine:
-    def __init__(self, model, backbone, nclass, height, width, device=0, lib=None):
+    def __init__(self, model, backbone, nclass, height, width, device=0, lib=None, opts=None):
+        """opts: None (library defaults) or a dict of tdnet_opts fields (winograd=, precision=, pipeline=, ...): per handle."""
         self.lib = lib or _capi.lib()
         self.cfg = _capi.TdnetCfg(model, backbone, nclass, height, width, device)
         h = ctypes.c_void_p()
-        self.lib.check(self.lib.tdnet_create(ctypes.byref(self.cfg), ctypes.byref(h)))
+        o = self.lib.opts(**(opts or {}))
+        self.lib.check(self.lib.tdnet_create_opts(ctypes.byref(self.cfg), ctypes.byref(o), ctypes.byref(h)))
         self.h = h
         self.finalized = False
 
@@ -91,6 +93,11 @@ class Engine:
         n = self.lib.check(self.lib.tdnet_get_stage(self.h, name.encode(), out.ctypes.data, out.size))
         assert n == out.size, (name, n, out.size)
         return out.reshape(shape)
+
+    def opts(self):
+        o = _capi.TdnetOpts()
+        self.lib.check(self.lib.tdnet_get_opts(self.h, ctypes.byref(o)))
+        return o.as_dict()
 
     def flops_per_frame(self):
         return self.lib.tdnet_flops_per_frame(self.h)

@@ -27,7 +27,9 @@ class _TDNetBase(nn.Module):
     _spec_name = None      # "td4" / "td2"
 
     def __init__(self, nclass=21, norm_layer=None, backbone="resnet18", dilated=True, aux=True, multi_grid=True,
-                 path_num=None, model_path=None, synthetic_seed=None):
+                 path_num=None, model_path=None, synthetic_seed=None, kernel_opts=None):
+        """kernel_opts (not in the reference): dict of include/tdnet.h tdnet_opts fields for THIS instance's handle, e.g.
+        {"winograd": 0} for all-direct convs or {"precision": 1} for the fp16-MFMA mode; None = library defaults."""
         super().__init__()
         assert backbone == "resnet50" or backbone == "resnet34" or backbone == "resnet18"
         assert path_num == self._model_id
@@ -40,6 +42,8 @@ class _TDNetBase(nn.Module):
         self.nclass = nclass
         self.backbone = backbone
         self.synthetic_seed = synthetic_seed
+        self.kernel_opts = dict(kernel_opts or {})
+        self._pending_shape = None
         self.spec = arch.model_spec(self._spec_name, nclass, backbone)
         self._state = None
         self._engine = None
@@ -64,7 +68,14 @@ class _TDNetBase(nn.Module):
         return self
 
     def state_dict(self, *a, **k):
-        return dict(self._state or {})
+        """{name: CPU tensor} with the reference's keys, so torch.save(model.state_dict()) round-trips like the reference's
+        checkpoints (td4_psp18.py:236-237); num_batches_tracked entries are int64 scalars as nn.BatchNorm2d registers them."""
+        from collections import OrderedDict
+        out = OrderedDict()
+        for name, v in (self._state or {}).items():
+            a_ = np.asarray(v)
+            out[name] = torch.from_numpy(np.array(a_, dtype=np.int64 if name.endswith("num_batches_tracked") else np.float32))
+        return out
 
     # ---- engine ----------------------------------------------------------------------------------------------
     def _get_engine(self, img):
@@ -91,7 +102,7 @@ class _TDNetBase(nn.Module):
             raise RuntimeError("Given normalized_shape=%s, expected input with shape [*, %d, %d], but got input of size"
                                "[%d, %d, %d, %d]" % (list(ln.shape), ln.shape[0], ln.shape[1], n, self.spec.d_v, h, w))
         try:
-            eng = Engine(self._model_id, int(self.backbone[6:]), self.nclass, H, W, dev)
+            eng = Engine(self._model_id, int(self.backbone[6:]), self.nclass, H, W, dev, opts=self.kernel_opts)
             eng.load_state_dict(sd)
         except TdnetError as e:
             raise RuntimeError("Error(s) in loading state_dict for %s:\n\t%s" % (type(self).__name__, e))
@@ -99,7 +110,7 @@ class _TDNetBase(nn.Module):
         return eng
 
     # ---- nn.Module surface used by Testing/test.py:40-41,53 ------------------------------------------------------
-    def forward(self, img, pos_id=0):
+    def _check_frame(self, img, pos_id):
         if not torch.is_tensor(img) or img.dim() != 4 or img.shape[1] != 3:
             raise RuntimeError("expected an image tensor [1,3,H,W]")
         if img.device.type != "cuda":
@@ -108,6 +119,9 @@ class _TDNetBase(nn.Module):
             raise RuntimeError("batch size must be 1: the K/Q/V FIFO holds one video stream (test.py feeds [1,3,H,W])")
         if pos_id not in range(self.path_num):
             raise RuntimeError("pos_id must be t mod %d" % self.path_num)
+
+    def forward(self, img, pos_id=0):
+        self._check_frame(img, pos_id)
         img = img.contiguous().float()
         eng = self._get_engine(img)
         out = torch.empty((1, self.nclass, img.shape[2], img.shape[3]), device=img.device, dtype=torch.float32)
@@ -116,8 +130,7 @@ class _TDNetBase(nn.Module):
 
     def forward_labels(self, img, pos_id=0):
         """model(img,pos_id).max(1)[1] without materialising the full-resolution logits; int32 [1,H,W]."""
-        if img.device.type != "cuda":
-            raise TdnetError("tdnet_amd runs on MI355X only (no CPU fallback)")
+        self._check_frame(img, pos_id)
         img = img.contiguous().float()
         eng = self._get_engine(img)
         out = torch.empty((1, img.shape[2], img.shape[3]), device=img.device, dtype=torch.int32)
@@ -125,17 +138,9 @@ class _TDNetBase(nn.Module):
         return out
 
     # ---- split frame + cache transport (path-parallel single stream: parallel.PathParallelStream) ------------------
-    def _check_cuda(self, img):
-        if not torch.is_tensor(img) or img.dim() != 4 or img.shape[1] != 3 or img.shape[0] != 1:
-            raise RuntimeError("expected an image tensor [1,3,H,W]")
-        if img.device.type != "cuda":
-            raise TdnetError("tdnet_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % img.device.type)
-
     def encode(self, img, pos_id=0):
         """First half of forward(): backbone + pyramid slice + Encoding; the frame's cache entry is left pending."""
-        self._check_cuda(img)
-        if pos_id not in range(self.path_num):
-            raise RuntimeError("pos_id must be t mod %d" % self.path_num)
+        self._check_frame(img, pos_id)
         img = img.contiguous().float()
         eng = self._get_engine(img)
         self._pending_shape = (img.shape[2], img.shape[3], img.device)
@@ -143,7 +148,10 @@ class _TDNetBase(nn.Module):
 
     def propagate(self, labels=False):
         """Second half of forward() for the pending frame, against the FIFO as it stands; returns logits (or int32 labels)."""
+        if self._engine is None or self._pending_shape is None:
+            raise RuntimeError("propagate(): no encoded frame is pending (call encode(img, pos_id) first)")
         H, W, dev = self._pending_shape
+        self._pending_shape = None
         s = torch.cuda.current_stream(dev).cuda_stream
         if labels:
             out = torch.empty((1, H, W), device=dev, dtype=torch.int32)
@@ -155,8 +163,15 @@ class _TDNetBase(nn.Module):
 
     def cache_entry_numel(self):
         """(q, k, v) element counts of one cache entry: [Lk,64], [Lk,64], [Lk,d_v]."""
+        if self._engine is None:
+            raise RuntimeError("cache_entry_numel(): the geometry is known once a frame has been encoded; use cache_entry_numel_for(H, W) before")
         lk, dk, dv = self._engine.cache_dims()
         return lk * dk, lk * dk, lk * dv
+
+    def cache_entry_numel_for(self, H, W):
+        """The same from the input size alone (arch): lets every rank of a path-parallel group size its buffers before any frame."""
+        lk = arch.key_size(arch.feat_size(H)) * arch.key_size(arch.feat_size(W))
+        return lk * self.spec.d_k, lk * self.spec.d_k, lk * self.spec.d_v
 
     def cache_export(self, q, k, v):
         """Copy the pending frame's cache entry into the given contiguous fp32 CUDA tensors."""

@@ -15,7 +15,7 @@ class pspnet(_TDNetBase):
     _spec_name = "psp"
 
     def __init__(self, nclass=21, norm_layer=None, backbone="resnet101", dilated=True, aux=True, multi_grid=True,
-                 model_path=None, synthetic_seed=None):
+                 model_path=None, synthetic_seed=None, kernel_opts=None):
         if backbone not in ("resnet50", "resnet101"):
             if backbone in ("resnet18", "resnet34"):
                 raise NotImplementedError("PSPNet with a BasicBlock backbone is not a configuration the reference ships")
@@ -26,6 +26,8 @@ class pspnet(_TDNetBase):
         self.nclass = nclass
         self.backbone = backbone
         self.synthetic_seed = synthetic_seed
+        self.kernel_opts = dict(kernel_opts or {})
+        self._pending_shape = None
         self.spec = arch.model_spec("psp", nclass, backbone)
         self._state = None
         self._engine = None

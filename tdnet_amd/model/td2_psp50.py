@@ -12,5 +12,5 @@ class td2_psp50(_TDNetBase):
     _spec_name = "td2"
 
     def __init__(self, nclass=21, norm_layer=None, backbone="resnet50", dilated=True, aux=True, multi_grid=True,
-                 path_num=None, model_path=None, synthetic_seed=None):
-        super().__init__(nclass, norm_layer, backbone, dilated, aux, multi_grid, path_num, model_path, synthetic_seed)
+                 path_num=None, model_path=None, synthetic_seed=None, kernel_opts=None):
+        super().__init__(nclass, norm_layer, backbone, dilated, aux, multi_grid, path_num, model_path, synthetic_seed, kernel_opts)

@@ -42,7 +42,9 @@ class TorchMem:
         return torch.cuda.current_stream().cuda_stream
 
 
-def conv(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed=0, tol=1e-4):
+def conv(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed=0, tol=1e-4, opts=None):
+    """opts: dict of tdnet_opts fields for this one call (e.g. {"winograd": 0}); None = library defaults."""
+    import ctypes
     g = np.random.default_rng(seed)
     x = g.standard_normal((H, W, Cin)).astype(np.float32)
     w = (g.standard_normal((Cout, Cin, KS, KS)) * (1.0 / np.sqrt(Cin * KS * KS))).astype(np.float32)
@@ -59,12 +61,9 @@ def conv(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed
     elif act == 2:
         ref = F.leaky_relu(ref, 0.01)
     dx, dr, out = mem.put(x), (mem.put(r) if resid else None), mem.empty((Ho, Wo, Cout))
-    if tile is None:
-        rc = lib.tdnet_op_conv2d(mem.ptr(dx), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, KS, stride, dil, mem.ptr(dr), act,
-                                 mem.ptr(out), mem.stream)
-    else:
-        rc = lib.tdnet_op_conv2d_tile(mem.ptr(dx), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, KS, stride, dil, mem.ptr(dr),
-                                      act, tile, mem.ptr(out), mem.stream)
+    o = lib.opts(**(opts or {}))
+    rc = lib.tdnet_op_conv2d(mem.ptr(dx), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, KS, stride, dil, mem.ptr(dr), act,
+                             ctypes.byref(o), -1 if tile is None else tile, mem.ptr(out), mem.stream)
     lib.check(rc)
     err = float(np.abs(mem.get(out) - ref[0].permute(1, 2, 0).numpy()).max())
     assert err <= tol, ("conv", H, W, Cin, Cout, KS, stride, dil, act, resid, tile, err)

@@ -19,32 +19,27 @@ def lib():
     return emu_util.emu_lib()
 
 
-@pytest.fixture()
-def direct_convs(lib):
-    """Force the direct implicit-GEMM kernels (the library default routes wide stride-1 3x3 convs to Winograd)."""
-    lib.tdnet_set_conv_winograd(0)
-    yield
-    lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
+DIRECT = {"winograd": 0}     # force the direct implicit-GEMM kernels (the library default routes wide stride-1 3x3 convs to Winograd)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
-def test_conv_variants(lib, direct_convs, tile):
-    opcheck.conv(lib, MEM, 13, 21, 64, 128, 3, 1, 2, 1, True, tile)       # dilated 3x3 + residual + ReLU
-    opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, tile)       # stride 2, Cout not a tile multiple
-    opcheck.conv(lib, MEM, 11, 19, 64, 19, 1, 1, 1, 2, False, tile)       # 1x1, 19 channels, LeakyReLU
-    opcheck.conv(lib, MEM, 17, 9, 128, 64, 1, 2, 1, 0, True, tile)        # 1x1 stride-2 downsample
-    opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, False, tile)      # dilation 4, two N tiles
-    opcheck.conv(lib, MEM, 7, 9, 32, 64, 1, 1, 1, 0, False, tile)         # a single K step (pipeline prologue only)
-    opcheck.conv(lib, MEM, 7, 9, 64, 64, 1, 1, 1, 0, True, tile)          # two K steps
-    opcheck.conv(lib, MEM, 7, 9, 96, 64, 1, 1, 1, 1, False, tile)         # three K steps (odd tail of the 2-stage loop)
+def test_conv_variants(lib, tile):
+    opcheck.conv(lib, MEM, 13, 21, 64, 128, 3, 1, 2, 1, True, tile, opts=DIRECT)       # dilated 3x3 + residual + ReLU
+    opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, tile, opts=DIRECT)       # stride 2, Cout not a tile multiple
+    opcheck.conv(lib, MEM, 11, 19, 64, 19, 1, 1, 1, 2, False, tile, opts=DIRECT)       # 1x1, 19 channels, LeakyReLU
+    opcheck.conv(lib, MEM, 17, 9, 128, 64, 1, 2, 1, 0, True, tile, opts=DIRECT)        # 1x1 stride-2 downsample
+    opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, False, tile, opts=DIRECT)      # dilation 4, two N tiles
+    opcheck.conv(lib, MEM, 7, 9, 32, 64, 1, 1, 1, 0, False, tile, opts=DIRECT)         # a single K step (pipeline prologue only)
+    opcheck.conv(lib, MEM, 7, 9, 64, 64, 1, 1, 1, 0, True, tile, opts=DIRECT)          # two K steps
+    opcheck.conv(lib, MEM, 7, 9, 96, 64, 1, 1, 1, 1, False, tile, opts=DIRECT)         # three K steps (odd tail of the 2-stage loop)
 
 
-def test_conv_auto_tile_and_edges(lib, direct_convs):
-    opcheck.conv(lib, MEM, 20, 23, 64, 64, 1, 4, 1, 2, False)             # the stride-4 key sub-sampling conv
-    opcheck.conv(lib, MEM, 9, 17, 128, 256, 3, 1, 8, 1, True)             # dilation 8 larger than the image half
-    opcheck.conv(lib, MEM, 5, 9, 256, 512, 3, 1, 16, 1, False)            # dilation 16 (resnet34 multi-grid): all taps but centre padded
-    opcheck.conv(lib, MEM, 40, 40, 32, 128, 3, 1, 1, 1, False)            # several M tiles, ragged last tile
-    opcheck.conv(lib, MEM, 1, 1, 32, 32, 3, 1, 1, 0, False)               # single pixel
+def test_conv_auto_tile_and_edges(lib):
+    opcheck.conv(lib, MEM, 20, 23, 64, 64, 1, 4, 1, 2, False, opts=DIRECT)             # the stride-4 key sub-sampling conv
+    opcheck.conv(lib, MEM, 9, 17, 128, 256, 3, 1, 8, 1, True, opts=DIRECT)             # dilation 8 larger than the image half
+    opcheck.conv(lib, MEM, 5, 9, 256, 512, 3, 1, 16, 1, False, opts=DIRECT)            # dilation 16 (resnet34 multi-grid): all taps but centre padded
+    opcheck.conv(lib, MEM, 40, 40, 32, 128, 3, 1, 1, 1, False, opts=DIRECT)            # several M tiles, ragged last tile
+    opcheck.conv(lib, MEM, 1, 1, 32, 32, 3, 1, 1, 0, False, opts=DIRECT)               # single pixel
 
 
 def test_stem(lib):
@@ -82,7 +77,7 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
     h, w = arch.feat_size(H), arch.feat_size(W)
     hk, wk = arch.key_size(h), arch.key_size(w)
     g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
-    T = 1 + max(int(k.split("_")[0][1:]) for k in g.files if k.startswith("f"))
+    T = min(8, 1 + max(int(k.split("_")[0][1:]) for k in g.files if k.startswith("f")))   # td4: t = 6, 7 are paths 3, 4 in steady state
     e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib)
     e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
     shapes = {"c4": (1, spec.d_model, h, w), "z": (1, spec.d_model, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64),
@@ -117,19 +112,18 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
 
 def test_winograd_conv_and_pipeline(lib, golden_dir):
     """Winograd F(2x2,3x3) mode (td_wino.h): every dilation, ragged sizes, then the td4 pipeline with layers 3-4 on it."""
-    lib.tdnet_set_conv_winograd(2)
-    try:
+    if True:
         for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
                   (5, 9, 256, 512, 3, 1, 16, 2, False), (40, 40, 32, 128, 3, 1, 1, 1, False), (1, 1, 32, 32, 3, 1, 1, 0, False),
                   (7, 7, 32, 64, 3, 1, 3, 1, True)]:
-            opcheck.conv(lib, MEM, *a)
-        opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False)          # stride 2 is not eligible: direct path
-        lib.tdnet_set_conv_winograd(1)
+            opcheck.conv(lib, MEM, *a, opts={"winograd": 2})
+        opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, opts={"winograd": 2})          # stride 2 is not eligible: direct path
         name, bb, H, W = "td4", "resnet18", 33, 65
         spec = arch.model_spec(name, 19, bb)
         h, w = arch.feat_size(H), arch.feat_size(W)
         g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
-        e = Engine(4, 18, 19, H, W, 0, lib=lib)
+        e = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"winograd": 1})
+        assert e.opts()["winograd"] == 1
         e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
         for t, x in enumerate(weights.synth_video(H, W, 5, seed=1)):
             out = np.full((1, 19, H, W), 7e7, np.float32)
@@ -137,28 +131,24 @@ def test_winograd_conv_and_pipeline(lib, golden_dir):
             assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 1e-4 * np.abs(g["f%d_c4" % t]).max()
             assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
         e.close()
-    finally:
-        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
 
 
 def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
     """Winograd F(4x4,3x3) (td_wino.h k_wino4_in / k_wino4_out, 36 batched GEMMs): every dilation, ragged sizes (tiles hanging
     over the image, images smaller than a tile), residual/activation variants, then the td4 pipeline with layers 3-4 and the
     head on it (mode 3, the wide convs) against the goldens captured from the real reference."""
-    lib.tdnet_set_conv_winograd(4)
-    try:
+    if True:
         worst = 0.0
         for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
                   (5, 9, 256, 512, 3, 1, 16, 2, False), (40, 40, 32, 128, 3, 1, 1, 1, False), (1, 1, 32, 32, 3, 1, 1, 0, False),
                   (7, 7, 32, 64, 3, 1, 3, 1, True), (16, 32, 64, 64, 3, 1, 1, 2, True)]:
-            worst = max(worst, opcheck.conv(lib, MEM, *a, tol=2e-4))       # F4's per-conv error is ~6x F2's; outputs are O(1)
-        opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False)           # stride 2 is not eligible: direct path
-        lib.tdnet_set_conv_winograd(3)
+            worst = max(worst, opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4}))       # F4's per-conv error is ~6x F2's; outputs are O(1)
+        opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, opts={"winograd": 4})           # stride 2 is not eligible: direct path
         name, bb, H, W = "td4", "resnet18", 33, 65
         spec = arch.model_spec(name, 19, bb)
         h, w = arch.feat_size(H), arch.feat_size(W)
         g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
-        e = Engine(4, 18, 19, H, W, 0, lib=lib)
+        e = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"winograd": 3})
         e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
         for t, x in enumerate(weights.synth_video(H, W, 5, seed=1)):
             out = np.full((1, 19, H, W), 7e7, np.float32)
@@ -167,30 +157,42 @@ def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
             assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
             assert (out[0].argmax(0) == g["f%d_logits" % t][0].argmax(0)).all()
         e.close()
-    finally:
-        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
 
 
 def test_persistent_gemm_multi_tile(lib):
     """td_gemm.h: stride-1 1x1 convs and Winograd GEMMs on the persistent kernel, with the grid forced small so every
     workgroup walks several tiles (pipeline running across tile boundaries, odd/even tile counts, idle workgroups)."""
-    try:
-        for cap in (1, 3, 5, 8, 11):
-            lib.tdnet_set_gemm_persistent(cap if cap > 1 else 2)
-            for tile in (3, 4, 5):
-                opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True, tile)     # 4 K steps of 32, ragged M and N
-                opcheck.conv(lib, MEM, 40, 40, 64, 64, 1, 1, 1, 0, False, tile)      # one period per tile
-                opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True, tile)      # K = 96: odd step count -> single-tile kernel
-            lib.tdnet_set_conv_winograd(2)
-            opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True)                # 16 batches x tiles over few workgroups
-            lib.tdnet_set_conv_winograd(4)
-            opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4)      # 36 batches
-            lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
-        lib.tdnet_set_gemm_persistent(0)                                              # the non-persistent fallback stays correct
-        opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True)
-    finally:
-        lib.tdnet_set_gemm_persistent(1)
-        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
+    for cap in (1, 3, 5, 8, 11):
+        pers = cap if cap > 1 else 2
+        for tile in (3, 4, 5):
+            o = {"gemm_persistent": pers}
+            opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True, tile, opts=o)     # 4 K steps of 32, ragged M and N
+            opcheck.conv(lib, MEM, 40, 40, 64, 64, 1, 1, 1, 0, False, tile, opts=o)      # one period per tile
+            opcheck.conv(lib, MEM, 23, 31, 96, 160, 1, 1, 1, 1, True, tile, opts=o)      # K = 96: odd step count -> single-tile kernel
+        opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, opts={"gemm_persistent": pers, "winograd": 2})   # 16 batches x tiles over few workgroups
+        opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4, opts={"gemm_persistent": pers, "winograd": 4})   # 36 batches
+    opcheck.conv(lib, MEM, 23, 31, 128, 160, 1, 1, 1, 1, True, opts={"gemm_persistent": 0})   # the non-persistent fallback stays correct
+    opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4, opts={"gemm_persistent": 0, "winograd": 4})
+
+
+def test_two_handles_with_different_options_coexist(lib, golden_dir):
+    """Nothing is process-wide: an all-direct handle and a Winograd F(4x4) handle created side by side keep their own configuration
+    and both meet the gate on the reference goldens (frames interleaved between the two handles)."""
+    name, bb, H, W = "td2", "resnet18", 33, 65
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    ea = Engine(2, 18, 19, H, W, 0, lib=lib, opts={"winograd": 0})
+    eb = Engine(2, 18, 19, H, W, 0, lib=lib, opts={"winograd": 4, "pipeline": 0})
+    assert ea.opts()["winograd"] == 0 and eb.opts()["winograd"] == 4 and eb.opts()["pipeline"] == 0 and ea.opts()["pipeline"] == 1
+    sd = weights.synth_state_dict(spec, h, w, 0)
+    ea.load_state_dict(sd); eb.load_state_dict(sd)
+    for t, x in enumerate(weights.synth_video(H, W, 3, seed=1)):
+        for e in (ea, eb):
+            out = np.full((1, 19, H, W), 7e7, np.float32)
+            e.forward(x, t % 2, out)
+            assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
+    ea.close(); eb.close()
 
 
 @pytest.mark.parametrize("name,T", [("td4", 7), ("td2", 4)])

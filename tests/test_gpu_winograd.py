@@ -11,27 +11,23 @@ pytestmark = pytest.mark.gpu
 
 def test_winograd_ops_and_model():
     lib, mem = _capi.lib(), opcheck.TorchMem()
-    lib.tdnet_set_conv_winograd(2)
-    try:
+    if True:
         for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
                   (5, 9, 256, 512, 3, 1, 16, 2, False), (1, 1, 32, 32, 3, 1, 1, 0, False), (97, 193, 256, 256, 3, 1, 2, 1, True)]:
-            opcheck.conv(lib, mem, *a)
-        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tol=2e-4)
-        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 8, 1, True, tol=2e-4)
-        opcheck.conv(lib, mem, 128, 256, 256, 256, 3, 1, 2, 1, True, tol=2e-4)
-        lib.tdnet_set_conv_winograd(1)
+            opcheck.conv(lib, mem, *a, opts={"winograd": 2})
+        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tol=2e-4, opts={"winograd": 2})
+        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 8, 1, True, tol=2e-4, opts={"winograd": 2})
+        opcheck.conv(lib, mem, 128, 256, 256, 256, 3, 1, 2, 1, True, tol=2e-4, opts={"winograd": 2})
         import test_gpu_model as tm
-        tm._vs_oracle("td4", "resnet18", 257, 513, 6)
-        tm._vs_oracle("td4", "resnet18", 1024, 2048, 5)
-        tm._vs_oracle("td2", "resnet34", 180, 240, 3)
-        lib.tdnet_set_conv_winograd(4)                                  # F(4x4,3x3) on every stride-1 3x3
+        tm._vs_oracle("td4", "resnet18", 257, 513, 8, kernel_opts={"winograd": 1})
+        tm._vs_oracle("td4", "resnet18", 1024, 2048, 5, kernel_opts={"winograd": 1})
+        tm._vs_oracle("td2", "resnet34", 180, 240, 3, kernel_opts={"winograd": 1})
+        # F(4x4,3x3) on every stride-1 3x3
         for a in [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
                   (5, 9, 256, 512, 3, 1, 16, 2, False), (1, 1, 32, 32, 3, 1, 1, 0, False), (97, 193, 256, 256, 3, 1, 2, 1, True)]:
-            opcheck.conv(lib, mem, *a, tol=2e-4)
-        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tol=5e-4)    # K = 512 sums through the +-8 output transform
-        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 8, 1, True, tol=5e-4)
-        opcheck.conv(lib, mem, 128, 256, 256, 256, 3, 1, 2, 1, True, tol=5e-4)
-        tm._vs_oracle("td4", "resnet18", 257, 513, 6)                   # mode 4: stricter than the default (layer1 on F4 as well)
-        tm._vs_oracle("td4", "resnet18", 1024, 2048, 5)
-    finally:
-        lib.tdnet_set_conv_winograd(_capi.WINOGRAD_DEFAULT)
+            opcheck.conv(lib, mem, *a, tol=2e-4, opts={"winograd": 4})
+        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tol=5e-4, opts={"winograd": 4})    # K = 512 sums through the +-8 output transform
+        opcheck.conv(lib, mem, 128, 256, 512, 512, 3, 1, 8, 1, True, tol=5e-4, opts={"winograd": 4})
+        opcheck.conv(lib, mem, 128, 256, 256, 256, 3, 1, 2, 1, True, tol=5e-4, opts={"winograd": 4})
+        tm._vs_oracle("td4", "resnet18", 257, 513, 8, kernel_opts={"winograd": 4})   # mode 4: stricter than the default (layer1 on F4 as well)
+        tm._vs_oracle("td4", "resnet18", 1024, 2048, 5, kernel_opts={"winograd": 4})

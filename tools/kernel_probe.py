@@ -5,12 +5,12 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes  # noqa: E402
 import torch  # noqa: E402
 
 from tdnet_amd import _capi  # noqa: E402
 
 lib = _capi.lib()
-lib.tdnet_set_conv_winograd(0)          # this probe measures the direct kernels
 torch.zeros(1, device="cuda")
 out = {"mfma_peak_tflops": {}}
 for wps in (1, 2, 4):
@@ -25,10 +25,10 @@ names = ["128x128", "64x128", "128x64", "128x128D", "64x128D", "128x64D"]
 # quantisation probe: the same layer4 conv at 1, 2, 4, 8 workgroup rounds (M = 16k .. 131k pixels)
 for Hq in (64, 128, 256, 512):
     gf = 2.0 * Hq * 256 * 512 * 512 * 9 / 1e9
-    ms = lib.tdnet_bench_conv(Hq, 256, 512, 512, 3, 1, 4, 3, 10, None)
+    ms = lib.tdnet_bench_conv(Hq, 256, 512, 512, 3, 1, 4, 3, 10, ctypes.byref(lib.opts(winograd=0)), None)
     print("layer4 512->512 d4 at %dx256 (%d blocks): %.3f ms %.1f TF" % (Hq, Hq * 256 // 128 * 4, ms, gf / ms), flush=True)
 for prec in (0, 1):
-  lib.tdnet_set_conv_precision(prec)
+  o = lib.opts(winograd=0, precision=prec)          # this probe measures the direct kernels
   print("---- conv precision:", "fp16-input MFMA" if prec else "fp32 MFMA", flush=True)
   for (nm, H, W, Cin, Cout, KS, st, dil) in SHAPES:
     Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
@@ -37,7 +37,6 @@ for prec in (0, 1):
     for t in (range(6) if prec == 0 else (3, 4, 5)):
         if Cout <= 64 and t not in (2, 5):
             continue
-        ms = lib.tdnet_bench_conv(H, W, Cin, Cout, KS, st, dil, t, 20, None)
+        ms = lib.tdnet_bench_conv(H, W, Cin, Cout, KS, st, dil, t, 20, ctypes.byref(o), None)
         row[names[t]] = "%.3f ms %.1f TF" % (ms, gf / ms)
     print("%-22s %6.1f GFLOP  " % (nm, gf) + "  ".join("%s: %s" % kv for kv in row.items()), flush=True)
-lib.tdnet_set_conv_precision(0)

@@ -119,9 +119,13 @@ def main():
     meta = "torch %s, threads %d" % (torch.__version__, THREADS)
 
     # ---- small, fully traced cases (every stage boundary) -------------------------------------------------
-    cases = [("td4", "resnet18", 33, 65, 6, True), ("td2", "resnet18", 33, 65, 4, True),
-             ("td2", "resnet34", 33, 65, 3, False), ("td4", "resnet18", 65, 129, 6, False),
-             ("td2", "resnet18", 49, 81, 3, False), ("td2", "resnet50", 33, 65, 3, True)]
+    # T: every path in steady state at least twice (td4: warm-up = frames 0..2, so T = 11 gives paths 3,0,1,2 | 3,0,1,2 at t = 3..10;
+    # td2: warm-up = frame 0, T = 5 gives paths 1,0,1,0).  forward_path3 (atn3_4 -> atn3_1 -> atn3_2, td4_psp18.py:176-195) first
+    # runs in steady state at t = 6.
+    cases = [("td4", "resnet18", 33, 65, 11, True), ("td2", "resnet18", 33, 65, 5, True),
+             ("td2", "resnet34", 33, 65, 5, False), ("td4", "resnet18", 65, 129, 11, False),
+             ("td2", "resnet18", 49, 81, 5, False), ("td2", "resnet50", 33, 65, 5, True),
+             ("td4", "resnet34", 33, 65, 11, False)]            # td4_psp18.py:52-66 accepts resnet34 too
     for name, bb, H, W, T, full in cases:
         spec, m = build_reference(name, bb, H, W, seed=0)
         frames = weights.synth_video(H, W, T, seed=1)
@@ -138,16 +142,22 @@ def main():
 
     # ---- full-size digests (statistics + strided samples only) --------------------------------------------
     digests = {}
-    for name, bb, H, W, T in [("td2", "resnet18", 512, 1024, 4), ("td4", "resnet18", 1024, 2048, 6),
-                              ("td4", "resnet18", 769, 1537, 5), ("td2", "resnet34", 720, 960, 3),
-                              ("td2", "resnet50", 769, 1537, 3)]:
+    # per-frame digests (tag_f<t>_*) from the first steady-state frame on, so that every path's steady-state wiring is pinned at
+    # full size too; the un-suffixed keys describe the last frame.
+    for name, bb, H, W, T in [("td2", "resnet18", 512, 1024, 5), ("td4", "resnet18", 1024, 2048, 8),
+                              ("td4", "resnet18", 769, 1537, 8), ("td2", "resnet34", 720, 960, 4),
+                              ("td2", "resnet50", 769, 1537, 3), ("td2", "resnet18", 1024, 2048, 4)]:
         spec, m = build_reference(name, bb, H, W, seed=0)
         frames = weights.synth_video(H, W, T, seed=1)
+        tag = "%s_%s_%dx%d" % (name, bb, H, W)
         with torch.no_grad():
             for t, x in enumerate(frames):
                 out = m(torch.from_numpy(x), pos_id=t % spec.path_num).numpy()
+                if t >= spec.fifo:
+                    digests["%s_f%d_stats" % (tag, t)] = np.array([out.min(), out.max(), out.mean(), np.sqrt((out.astype(np.float64) ** 2).sum())], dtype=np.float64)
+                    digests["%s_f%d_sample" % (tag, t)] = out[0, :, ::61, ::67].astype(np.float32)
+                    digests["%s_f%d_labels_sample" % (tag, t)] = out[0].argmax(0)[::61, ::67].astype(np.int16)
         lab = out[0].argmax(0)
-        tag = "%s_%s_%dx%d" % (name, bb, H, W)
         top2 = np.sort(out[0], axis=0)[-2:]
         gap = top2[1] - top2[0]
         digests[tag + "_last_frame"] = np.array(T - 1)

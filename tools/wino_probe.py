@@ -2,6 +2,7 @@
 """GPU-box probe: direct vs Winograd F(2x2,3x3) vs F(4x4,3x3) time per layer shape (same launch path as the model)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
 import torch
 from tdnet_amd import _capi
 lib = _capi.lib(); torch.zeros(1, device="cuda")
@@ -12,9 +13,7 @@ for (nm, H, W, Cin, Cout, d) in SHAPES:
     gf = 2.0 * H * W * Cout * Cin * 9 / 1e9
     out = []
     for mode in (0, 2, 4):
-        lib.tdnet_set_conv_winograd(mode)
-        t = 5 if Cout <= 64 else 3
-        ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 3, 1, d, t, 20, None) for _ in range(2))
+        o = lib.opts(winograd=mode)
+        ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 3, 1, d, -1, 20, ctypes.byref(o), None) for _ in range(2))
         out.append("%s %.3f ms (%.0f TF eff.)" % ({0: "direct", 2: "F2", 4: "F4"}[mode], ms, gf / ms))
     print("%-24s %6.1f GFLOP  %s" % (nm, gf, "   ".join(out)), flush=True)
-lib.tdnet_set_conv_winograd(1)
