@@ -26,7 +26,9 @@ struct GemmArgs {
     int tiles_m, tiles_n; // per batch
 };
 
-template <int BM, int BN, int WGM, int WGN>
+// ROLE only names the launch for the profiler (rocprofv3 aggregates by symbol): 0 = a stride-1 1x1 convolution, 1 = the (m+2)^2
+// batched GEMMs of a Winograd conv -- the frame's dominant kernel, whose roofline bench.py reports.  Same code either way.
+template <int BM, int BN, int WGM, int WGN, int ROLE>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
@@ -211,7 +213,8 @@ static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t 
     const long total = (long)a.tiles_m * a.tiles_n * a.nbatch;
     long grid = grid_cap > 0 ? grid_cap : 256L * bpc;
     if (grid > total) grid = total;
-    TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
+    if (a.nbatch > 1) TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 1>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
+    else TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 0>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
 }
 // grid_cap > 0 forces the number of workgroups (tests: several tiles per workgroup on small problems)
 static inline void gemm_launch(const GemmArgs& a, ConvTile tile, int grid_cap, hipStream_t s) {

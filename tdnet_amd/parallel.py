@@ -96,22 +96,33 @@ class PathParallelStream:
     bit-identical to one GPU serving the stream, and W frames finish in about one frame's latency.
 
     `stage` is duck-typed (the model classes of tdnet_amd.model implement it): encode(img, pos_id), propagate(labels=) -> out,
-    cache_entry_numel() -> (nq, nk, nv), cache_export(q, k, v), cache_push(q, k, v).
+    cache_entry_numel_for(H, W) -> (nq, nk, nv), cache_export(q, k, v), cache_push(q, k, v).
+
+    `frame_size` = (H, W) of the stream.  The exchange buffers are sized from it (pure arithmetic on the architecture), NOT from a
+    live engine: a rank that owns no frame of a short first round (T < world) still knows the geometry and takes part in every
+    collective, so no rank can fail alone and leave the others waiting in an all-gather.  It is required when world > 1 and
+    checked in the constructor, i.e. identically on every rank and before any collective.
     """
 
-    def __init__(self, stage, path_num, rank=None, world=None, device=None):
+    def __init__(self, stage, path_num, rank=None, world=None, device=None, frame_size=None):
         self.stage, self.P = stage, path_num
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
         self.device = device
+        if self.world > 1 and frame_size is None:
+            raise ValueError("PathParallelStream: frame_size=(H, W) is required when world_size > 1")
+        self.frame_size = None if frame_size is None else (int(frame_size[0]), int(frame_size[1]))
         self._buf = None
 
     def owner(self, t):
         return t % self.world
 
-    def _buffers(self):
+    def _buffers(self, frames=()):
         if self._buf is None:
-            nq, nk, nv = self.stage.cache_entry_numel()
+            if self.frame_size is None:                               # world == 1: every frame is ours
+                f = next(x for x in frames if x is not None)
+                self.frame_size = (int(f.shape[-2]), int(f.shape[-1]))
+            nq, nk, nv = self.stage.cache_entry_numel_for(*self.frame_size)
             self._sizes = (nq, nk, nv)
             self._buf = torch.zeros(self.world, nq + nk + nv, dtype=torch.float32, device=self.device)
         return self._buf
@@ -143,9 +154,7 @@ class PathParallelStream:
             mine = r0 + self.rank if self.rank < n_valid else None
             if mine is not None:
                 self.stage.encode(frames[mine], pos_id=(first_frame + mine) % self.P)
-            buf = self._buffers() if (mine is not None or self._buf is not None) else None
-            if buf is None:                                           # a rank that never owned a frame still needs the geometry
-                raise RuntimeError("rank %d owns no frame of the first round: feed at least world_size frames" % self.rank)
+            buf = self._buffers(frames)
             if mine is not None:
                 self.stage.cache_export(*self._split(buf[self.rank]))
             self._exchange(buf, n_valid)

@@ -1,0 +1,72 @@
+"""bench.py's launch contract (CPU, gloo): `python bench.py --gpus N` WITHOUT a launcher starts the N ranks itself and proves
+they met (world_size_seen from an all-reduce), the launcher form `python -m torch.distributed.run ... bench.py --gpus N` works
+the same, a WORLD_SIZE that disagrees with --gpus is an error, and the N = 1 line keeps its shape.  --dry-run swaps the model
+for a no-op (there is no CPU path for the model) but runs the real launch / rendezvous / weight-broadcast / barrier / timing-
+reduction code; its `value` is null so it can never be mistaken for a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["OMP_NUM_THREADS"] = "2"
+    return e
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_self_spawn_two_ranks_over_gloo():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    line = _last_json(out)
+    assert line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["backend"] == "gloo"
+    assert line["dry_run"] is True and line["value"] is None          # plumbing only: never a measurement
+    assert len(line["per_rank_fps"]) == 2 and all(v > 0 for v in line["per_rank_fps"])
+    assert line["rccl_bcast_ms"] > 0 and line["bcast_bytes"] > 1e6      # the weight blob really crossed the process boundary
+    assert line["steps"] == 2 and line["scaling"] == "weak"
+    assert sum(1 for l in out.splitlines() if l.startswith("{")) == 1    # ONE line, from rank 0
+
+
+def test_launcher_form_and_world_size_mismatch():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), BENCH]
+    r = subprocess.run(base + ["--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    assert _last_json(r.stdout.decode(errors="replace"))["world_size_seen"] == 2
+    # the driver's launcher started 2 ranks but the flag says 4: refuse, do not print a line under the wrong label
+    r = subprocess.run(base + ["--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode != 0 and not [l for l in out.splitlines() if l.startswith("{")], out[-2000:]
+
+
+def test_single_rank_line_and_no_gpu_refusal():
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--dry-run"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-3000:]
+    line = _last_json(r.stdout.decode(errors="replace"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "world_size_seen"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["world_size_seen"] == 1 and line["rccl_bcast_ms"] == 0.0
+    # without --dry-run there is no CPU path: --gpus 2 on a box without 2 GPUs must exit non-zero instead of running one rank
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2"], env=_env(), cwd=ROOT,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode != 0 and "refusing" in out and not [l for l in out.splitlines() if l.startswith("{")]

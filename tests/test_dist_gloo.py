@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -69,7 +70,7 @@ class _ToyStage:
         self.pending = (torch.full((self.n,), f), torch.full((self.n,), f + 0.25 * pos_id), torch.full((2 * self.n,), -f))
         self.cur = (f, pos_id)
 
-    def cache_entry_numel(self):
+    def cache_entry_numel_for(self, H, W):
         return self.n, self.n, 2 * self.n
 
     def cache_export(self, q, k, v):
@@ -101,7 +102,7 @@ def _toy_frames(T):
 def _pp_worker(rank, world, port, q, T, P, depth):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     parallel.init_distributed("gloo")
-    pp = parallel.PathParallelStream(_ToyStage(depth), P, device=torch.device("cpu"))
+    pp = parallel.PathParallelStream(_ToyStage(depth), P, device=torch.device("cpu"), frame_size=(2, 2))
     outs = pp.process(_toy_frames(T))
     q.put((rank, {t: float(o) for t, o in outs.items()}))
     dist.destroy_process_group()
@@ -119,7 +120,9 @@ def test_path_parallel_schedule_matches_sequential():
     ctx = mp.get_context("spawn")
     # td4 (FIFO 3) on 2 ranks with a ragged last round; td2 (FIFO 1) on 2 ranks; td4 on 4 ranks = one sub-network per rank,
     # every entry a frame needs comes from a peer (world_size > FIFO depth + 1 is covered by the in-order pushes)
-    for (W, T, P, depth) in ((2, 9, 4, 3), (2, 6, 2, 1), (4, 10, 4, 3)):
+    # (4, 3, ...): a stream SHORTER than one round -- rank 3 owns no frame at all and must still take part in every collective
+    # (the geometry comes from frame_size, not from a live engine) instead of failing alone while its peers wait
+    for (W, T, P, depth) in ((2, 9, 4, 3), (2, 6, 2, 1), (4, 10, 4, 3), (4, 3, 4, 3)):
         q = ctx.Queue()
         port = _free_port()
         ps = [ctx.Process(target=_pp_worker, args=(r, W, port, q, T, P, depth)) for r in range(W)]
@@ -129,6 +132,8 @@ def test_path_parallel_schedule_matches_sequential():
         for p in ps:
             p.join(timeout=60)
             assert p.exitcode == 0
+        with pytest.raises(ValueError):                                # required on every rank, checked before any collective
+            parallel.PathParallelStream(_ToyStage(depth), P, rank=0, world=W, device=torch.device("cpu"))
         merged = {}
         for r in range(W):
             assert sorted(res[r]) == list(range(r, T, W))              # rank g serves t = g mod W
