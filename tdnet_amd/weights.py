@@ -35,7 +35,11 @@ def _rng(seed, name):
     return np.random.Generator(np.random.Philox(key=[int(seed) & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
 
 
-def synth_tensor(name, shape, seed):
+def synth_tensor(name, shape, seed, init="calibrated"):
+    """init = "calibrated" (default, see below) or "reference": SURVEY.md 8d's original recipe -- every conv ~ N(0, 2/(k*k*C_out)) as
+    resnet.py:162-165 initialises its convs, no q/k gain, no depth normalisation.  With it activations grow ~8x through the 512->64
+    projections and the attention scores reach the hundreds; it exists to STRESS the kernels (relative-error gate,
+    tests/test_gpu_model.py::test_uncalibrated_reference_init), not to pin absolute logits."""
     g = _rng(seed, name)
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":
@@ -50,6 +54,8 @@ def synth_tensor(name, shape, seed):
         return g.uniform(0.5, 1.5, shape).astype(np.float32)
     if leaf == "running_mean":
         return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 4 and init == "reference":
+        return (np.sqrt(2.0 / (shape[2] * shape[3] * shape[0])) * g.standard_normal(shape)).astype(np.float32)
     if len(shape) == 4:
         # conv weight: He-style normal as resnet.py:162-165, but with n = k*k*max(C_in, C_out) instead of the
         # reference's k*k*C_out: fan-out scaling blows activations up 8x through the 512->64 projections, which
@@ -61,7 +67,7 @@ def synth_tensor(name, shape, seed):
         return wt * np.float32(QK_GAIN) if _is_qk_out(name) else wt
     if len(shape) == 1 and leaf == "weight":                # BN gamma
         return g.uniform(0.5, 1.5, shape).astype(np.float32)
-    if leaf == "bias" and _is_qk_out(name):
+    if leaf == "bias" and _is_qk_out(name) and init != "reference":
         return (0.05 * QK_GAIN * g.standard_normal(shape)).astype(np.float32)
     if leaf == "bias":
         is_bn = name.endswith(("bn1.bias", "bn2.bias", "bn3.bias", "bn.bias", "conv1.1.bias", "conv1.4.bias")) or ".downsample.1." in name \
@@ -75,7 +81,7 @@ _BN_LAST = {False: re.compile(r"^pretrained\d*\.layer\d\.\d+\.bn2\.weight$"),   
             True: re.compile(r"^pretrained\d*\.layer\d\.\d+\.bn3\.weight$")}       # Bottleneck: bn3
 
 
-def synth_state_dict(spec, h, w, seed=0):
+def synth_state_dict(spec, h, w, seed=0, init="calibrated"):
     """{name: np.ndarray} with exactly the reference's keys for `spec` at feature size h x w.
 
     The gamma of every residual branch's last BN is scaled by (8 / n_blocks)^0.77: each BasicBlock adds its branch
@@ -85,9 +91,11 @@ def synth_state_dict(spec, h, w, seed=0):
     nblocks = len(arch.backbone_blocks(spec.backbone))
     # measured with the CPU oracle: these factors keep c4 rms of ResNet-34 / ResNet-50 at the ResNet-18 level (~9 at full size)
     g2 = np.float32(BOTTLENECK_GAIN * (16.0 / nblocks) ** BOTTLENECK_DEPTH_EXP if arch.is_bottleneck(spec.backbone) else (8.0 / nblocks) ** 0.77)
+    if init == "reference":
+        g2 = np.float32(1.0)
     out = {}
     for k, s in arch.state_dict_shapes(spec, h, w).items():
-        t = synth_tensor(k, s, seed)
+        t = synth_tensor(k, s, seed, init)
         if g2 != 1.0 and _BN_LAST[arch.is_bottleneck(spec.backbone)].match(k):
             t = t * g2
         out[k] = t

@@ -85,10 +85,10 @@ class Wino:
                 out[:, :, py::dil, px::dil] = Y[:, :, :h, :wd]
         return out
 
-def run(kind, H=129, W=257, T=6, dtype=torch.float32):
+def run(kind, H=129, W=257, T=6, dtype=torch.float32, init="calibrated", cmin=256):
     spec = arch.model_spec("td4", 19, "resnet18")
     h, w = arch.feat_size(H), arch.feat_size(W)
-    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in weights.synth_state_dict(spec, h, w, 0).items()}
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in weights.synth_state_dict(spec, h, w, 0, init).items()}
     if dtype == torch.float64:
         sd = {k: v.double() for k, v in sd.items()}
     ref = tdnet_ref.TDNetRef(spec, sd)
@@ -97,7 +97,7 @@ def run(kind, H=129, W=257, T=6, dtype=torch.float32):
     def patched(x, wt, bias=None, stride=1, padding=0, dilation=1, groups=1):
         dl = dilation if isinstance(dilation, int) else dilation[0]
         st = stride if isinstance(stride, int) else stride[0]
-        if wn is not None and wt.shape[2] == 3 and st == 1 and wt.shape[1] >= 256 and wt.shape[0] >= 128:
+        if wn is not None and wt.shape[2] == 3 and st == 1 and wt.shape[1] >= cmin and wt.shape[0] >= 128:
             y = wn.conv(x, wt, dl)
             return y if bias is None else y + bias.view(1, -1, 1, 1)
         return orig(x, wt, bias, stride, padding, dilation, groups)
@@ -114,6 +114,19 @@ def run(kind, H=129, W=257, T=6, dtype=torch.float32):
         tdnet_ref.set_ops(prev)
     return outs
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "reference-init":
+    # SURVEY 8d's original init (no calibration): what matters is the error RELATIVE to the logits' scale
+    torch.set_num_threads(8)
+    truth = run("direct", dtype=torch.float64, init="reference", T=5)
+    scale = float(np.sqrt(np.mean([np.mean(a ** 2) for a in truth])))
+    print("reference init: logits rms %.3e, max %.3e" % (scale, max(np.abs(a).max() for a in truth)))
+    for kind in ("direct", "f2", "f4"):
+        o = run(kind, init="reference", T=5, cmin=128)
+        err = max(np.abs(a - b).max() for a, b in zip(o, truth))
+        rms = np.sqrt(np.mean([np.mean((a - b) ** 2) for a, b in zip(o, truth)]))
+        flips = sum(int((a[0].argmax(0) != b[0].argmax(0)).sum()) for a, b in zip(o, truth))
+        print("%-7s vs fp64 truth: max|dlogit| %.3e (%.2e of rms)  rms err %.3e (%.2e of rms)  label flips %d" % (kind, err, err / scale, rms, rms / scale, flips), flush=True)
+    sys.exit(0)
 if __name__ == "__main__":
     torch.set_num_threads(32)
     for k in ("f2", "f4", "f4h"):

@@ -150,6 +150,45 @@ def test_direct_conv_mode_meets_the_same_gate():
     _vs_oracle("td4", "resnet18", 1024, 2048, 5, kernel_opts={"winograd": 0})
 
 
+@pytest.mark.parametrize("wino", [0, 1, 3])
+def test_uncalibrated_reference_init(wino):
+    """Stress with SURVEY 8d's ORIGINAL init (every conv ~ N(0, 2/(k k C_out)), no q/k gain, no depth normalisation): activations
+    grow ~8x through the 512->64 projections, scores reach the hundreds, logits the tens -- the absolute 1e-3 gate stops being
+    meaningful (the reference's own fp32 CPU evaluation is 1.7e-3 away from an fp64 evaluation of the same graph at this size), so
+    the gate is RELATIVE to what fp32 itself can deliver: against an fp64 evaluation of the oracle graph ("truth"),
+        max|gpu - truth| <= 4 x max|fp32 CPU oracle - truth|   and   rms(gpu - truth) <= 3 x rms(fp32 CPU oracle - truth),
+    and a label may differ from the truth's only inside the truth's top-2 tie band.  All three conv algorithms (direct, Winograd
+    F(2x2), F(4x4)) must pass: Winograd's extra rounding error is a constant factor (measured on the CPU model of the kernels,
+    tests/numerics_winograd.py reference-init: rms 1.0x / 2.3x, max 1.8x / 3.0x the direct path's), not something the calibrated
+    weights were hiding."""
+    H, W, T = 129, 257, 5
+    spec = arch.model_spec("td4", 19, "resnet18")
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0, init="reference")
+    ref32 = tdnet_ref.TDNetRef(spec, sd)
+    ref64 = tdnet_ref.TDNetRef(spec, {k: torch.from_numpy(np.asarray(v)).double() for k, v in sd.items()})
+    m = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None, kernel_opts={"winograd": wino}).eval().to("cuda")
+    m.load_state_dict(sd)
+    tdnet_ref.tune_threads()
+    e_gpu, e_cpu, s_gpu, s_cpu, n = 0.0, 0.0, 0.0, 0.0, 0
+    with torch.no_grad():
+        for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
+            xt = torch.from_numpy(x)
+            out = m(xt.cuda(), pos_id=t % 4).cpu().double().numpy()
+            truth = ref64.forward(xt.double(), t % 4).numpy()
+            cpu = ref32.forward(xt, t % 4).double().numpy()
+            dg, dc = out - truth, cpu - truth
+            e_gpu, e_cpu = max(e_gpu, float(np.abs(dg).max())), max(e_cpu, float(np.abs(dc).max()))
+            s_gpu, s_cpu, n = s_gpu + float((dg ** 2).sum()), s_cpu + float((dc ** 2).sum()), n + dg.size
+            bad = out[0].argmax(0) != truth[0].argmax(0)
+            if bad.any():
+                top2 = np.sort(truth[0], axis=0)[-2:]
+                assert ((top2[1] - top2[0])[bad] <= 2 * float(np.abs(dg).max())).all(), (wino, t, "label flip outside the tie band")
+    r_gpu, r_cpu = (s_gpu / n) ** 0.5, (s_cpu / n) ** 0.5
+    print("reference init, winograd=%d: max err gpu %.2e vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f)"
+          % (wino, e_gpu, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu))
+    assert e_gpu <= 4.0 * e_cpu and r_gpu <= 3.0 * r_cpu, (wino, e_gpu, e_cpu, r_gpu, r_cpu)
+
+
 def test_properties_determinism_labels_reset():
     H, W = 129, 257
     frames = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, 6, seed=3)]

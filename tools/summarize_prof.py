@@ -13,7 +13,7 @@ def short(n):
     return n.replace("void ", "").split("(")[0][:70]
 
 
-for sub in ("prof", "prof50", "pmc_sq", "pmc_fetch", "pmc_write"):
+for sub in ("prof", "pmc_sq", "pmc_fetch", "pmc_write"):
     d = os.path.join(root, sub)
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     cfiles = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
