@@ -40,7 +40,7 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 0
-#define TDNET_STEM_DEFAULT 0
+#define TDNET_FUSION_DEFAULT 0
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
                                 convs (Cin >= 256, Cout >= 128), 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) =
@@ -53,7 +53,12 @@ typedef struct tdnet_opts {
                                 0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */
     int32_t stagger;         /* start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups                      */
     int32_t attention;       /* 0 (default) = exact two-pass softmax (row maxima first), 1 = single pass with online softmax        */
-    int32_t stem;            /* 0 (default) = layout change + conv7x7 + max-pool as three kernels, 1 = fused stem                 */
+    int32_t fusion;          /* bit mask of launch-level fusions / overlaps (each one measured on its own):
+                                1 = Encoding's q / k projections (w_qs, w_ks: small, latency-bound) on the side stream beside w_vs,
+                                2 = LayerNorm strip statistics written by the attention epilogue (no separate pass over the map),
+                                4 = LayerNorm normalisation applied inside the head's Winograd input transform (no `ln` map in HBM),
+                                8 = pyramid-pooling row sums split four ways per bin (shorter serial chains),
+                                16 = stem: 4-pixel vectorised layout change and 2-output max-pool                               */
     int32_t reserved[9];     /* must be 0                                                                                        */
 } tdnet_opts;
 void tdnet_opts_default(tdnet_opts* o);
@@ -136,10 +141,15 @@ int tdnet_op_conv2d(const float* in_dev, int H, int W, int Cin, const float* w_h
                     int tile /* -1 = heuristic; 0: 128x128, 1: 64x128, 2: 128x64, 3..5: the same on the two-stage pipeline */,
                     float* out_dev, void* stream);
 /* stem: NCHW image [3,H,W] -> conv7x7 s2 p3 (+bias) -> ReLU -> maxpool3x3 s2 p1 -> NHWC [H2,W2,64] (resnet.py:205-208) */
-int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const float* bias_host, float* out_dev, void* stream);
-/* softmax(q k^T / sqrt(dk)) v' + bias + resid: q [Lq,64], k [Lk,64], vp [Lk,DV], bias dev [DV]|NULL, resid [Lq,DV]|NULL */
+int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const float* bias_host,
+                  const tdnet_opts* opts /* NULL = defaults */, float* out_dev, void* stream);
+/* softmax(q k^T / sqrt(dk)) v' + bias + resid: q [Lq,64], k [Lk,64], vp [Lk,DV], bias dev [DV]|NULL, resid [Lq,DV]|NULL.
+ * online: 0 = exact two-pass softmax, 1 = single pass with a lazily moved reference (tdnet_opts.attention).
+ * ln_out != NULL: also the plane LayerNorm (affine ln_g, ln_b [Lq]) of the result, from the strip statistics the kernel's epilogue
+ * writes (tdnet_opts.fusion bit 2) -> ln_out [Lq,DV].                                                                          */
 int tdnet_op_attention(const float* q_dev, const float* k_dev, const float* vp_dev, const float* bias_dev,
-                       const float* resid_dev, int Lq, int Lk, int DV, float* out_dev, void* stream);
+                       const float* resid_dev, int Lq, int Lk, int DV, int online, const float* ln_g_dev, const float* ln_b_dev,
+                       float* ln_out_dev, float* out_dev, void* stream);
 /* LayerNorm over the (h,w) plane of every channel, affine g,b [h*w] shared by channels (td4_psp18.py:306-312); NHWC */
 int tdnet_op_layernorm_hw(const float* x_dev, int HW, int C, const float* g_dev, const float* b_dev, float* out_dev, void* stream);
 /* PPM (td4_psp18.py:271-284): c4 NHWC [h,w,512] -> z NHWC [h,w,512]; w_host: 4 folded [128,512] matrices, b_host 4x[128] */

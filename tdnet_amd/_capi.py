@@ -22,7 +22,7 @@ class TdnetOpts(ctypes.Structure):
     """include/tdnet.h tdnet_opts: per-handle kernel configuration (nothing in the library is process-wide)."""
     _fields_ = [("winograd", ctypes.c_int32), ("precision", ctypes.c_int32), ("pipeline", ctypes.c_int32),
                 ("gemm_persistent", ctypes.c_int32), ("stagger", ctypes.c_int32), ("attention", ctypes.c_int32),
-                ("stem", ctypes.c_int32), ("reserved", ctypes.c_int32 * 9)]
+                ("fusion", ctypes.c_int32), ("reserved", ctypes.c_int32 * 9)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -68,9 +68,9 @@ SYMBOLS = {
     "tdnet_op_conv2d": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, c_opts_p, ctypes.c_int,
                                        c_void_p, c_void_p]),
-    "tdnet_op_stem": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tdnet_op_stem": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_opts_p, c_void_p, c_void_p]),
     "tdnet_op_attention": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_int, c_void_p, c_void_p]),
+                                          ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_op_layernorm_hw": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_op_ppm": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
                                     c_void_p, c_void_p]),

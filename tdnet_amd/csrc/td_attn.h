@@ -7,8 +7,14 @@
 // fuses the "+ V_queue[i]" / "+ v_cur" adds of td4_psp18.py:146-151.
 //
 // The Lq x Lk score matrix is never materialised (the reference writes 268 MB of it per frame at 1024x2048).
-// Softmax is exact two-pass: pass 1 computes every query's row maximum (QK^T only, 1/9 of the MFMA work), pass 2
-// recomputes the scores, exponentiates against the final maximum and accumulates P V' -- no online rescaling.
+// Two softmax schedules over the same tile code (template ONLINE, tdnet_opts.attention):
+//   ONLINE = false: exact two-pass -- pass 1 computes every query's row maximum (QK^T only, 1/9 of the MFMA work), pass 2 recomputes
+//                   the scores, exponentiates against the final maximum and accumulates P V'; no rescaling.
+//   ONLINE = true : single pass.  softmax is invariant under the reference r subtracted in the exponent, so r need not be the row
+//                   maximum -- it only has to keep exp2(s - r) inside fp32's range.  The kernel keeps a per-query reference and
+//                   moves it (rescaling the accumulators and the running sum by exp2(r_old - r_new)) only when a tile's maximum
+//                   exceeds it by more than TAU = 8, so P <= 2^8 and the rescale -- a wave-uniform branch -- runs a few times per
+//                   query tile instead of once per key tile.  Results differ from the two-pass schedule by rounding only.
 //
 // MFMA mapping (fp32, v_mfma_f32_32x32x2_f32), one wave = 32 queries x (32*NT) output channels:
 //   scores are computed TRANSPOSED, S^T = K Q^T (A = K tile, B = Q^T): lane (q = lane&31, half) then holds, in register
@@ -32,16 +38,21 @@ struct AttnArgs {
     float* out;          // [Lq][DV]
     int Lq, Lk;
     float scale_log2e;   // log2(e) / sqrt(d_k)
+    // Optional: plane-LayerNorm strip statistics of the OUTPUT map (td4_psp18.py:306-312 normalises out over its Lq rows, per
+    // channel).  Strip s = 32 consecutive query rows = one query tile: ln_part[s][DV] = mean of the strip, ln_part[ln_nstr + s][DV]
+    // = sum (x - mean)^2 over it -- the layout k_ln_finalize combines exactly (td_misc.h).  nullptr = off.
+    float* ln_part;
+    int ln_nstr;         // number of strips = gridDim.x * QW
 };
 
 template <int QW, int CW>
 struct AttnLds {
     static constexpr int P_FLOATS = QW * (8 * CW) * 32 * 4;      // one super-tile of P: [qw][kq][q][4]
     static constexpr int RED_FLOATS = QW * CW * 32;
-    static constexpr int BYTES = (2 * P_FLOATS + 2 * RED_FLOATS) * 4;
+    static constexpr int BYTES = (2 * P_FLOATS + 3 * RED_FLOATS) * 4;   // P (double buffered), row-max / row-sum exchange, per-wave rescale factors
 };
 
-template <int QW, int CW, int NT>
+template <int QW, int CW, int NT, bool ONLINE>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     static_assert(QW * CW == 4, "4 waves per block");
     static_assert(NT == 4 || NT == 2, "lane owns NT consecutive channels: one float4 or one float2 of V' / the output");
@@ -52,6 +63,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     float* Ps = reinterpret_cast<float*>(smem);                  // [2][P_FLOATS]
     float* red = Ps + 2 * L::P_FLOATS;                           // [QW][CW][32] row-max exchange
     float* red2 = red + L::RED_FLOATS;                           // [QW][CW][32] row-sum exchange
+    float* scr = red2 + L::RED_FLOATS;                           // [4 waves][32] rescale factors of a wave's queries (ONLINE)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = TD_UNIFORM(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -99,7 +111,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int nsuper = (p.Lk + SK - 1) / SK;
     const float NEG = -3.0e38f;
 
-    // ---- pass 1: row maxima (next key tile in flight while the current one is multiplied) ----------------------
+    // ---- pass 1 (two-pass schedule only): row maxima (next key tile in flight while the current one is multiplied) ---------
+    float rowmax = NEG;                                           // reference subtracted in the exponent (ONLINE: moves lazily)
+    if (!ONLINE) {
     float mx = NEG;
     {
         f32x4 kf[8], kn[8];
@@ -125,9 +139,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     mx = fmaxf(mx, td_shfl_xor(mx, 32));
     if (half == 0) red[(qw * CW + cw) * 32 + l31] = mx;
     __syncthreads();
-    float rowmax = NEG;
 #pragma unroll
     for (int c = 0; c < CW; ++c) rowmax = fmaxf(rowmax, red[(qw * CW + c) * 32 + l31]);
+    }
 
     // ---- pass 2: P = exp2(S - max), O += P V' ----------------------------------------------------------------
     f32x16 acc[NT];
@@ -173,6 +187,45 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         load_v(kbase, 0, bb[0]);                                  // in flight under the 32 score MFMAs
         load_v(kbase, 1, bb[1]);
         const f32x16 s = score_tile(kf);
+        if (ONLINE) {
+            // this wave's tile maximum per query -> the query tile's maximum over the CW waves -> move the reference if needed
+            float lm = NEG;
+            if (kb + 32 <= p.Lk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lm = s[r] > lm ? s[r] : lm;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    lm = (key < p.Lk && s[r] > lm) ? s[r] : lm;
+                }
+            }
+            lm = fmaxf(lm, td_shfl_xor(lm, 32));
+            if (half == 0) red[(qw * CW + cw) * 32 + l31] = lm;
+            __syncthreads();
+            float tm = NEG;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) tm = fmaxf(tm, red[(qw * CW + c) * 32 + l31]);
+            // Every wave of the query tile reads the same maxima and holds the same references, so they all take this branch together.
+            if (td_any(tm > rowmax + 8.0f)) {
+                const float nm = fmaxf(rowmax, tm);
+                const float alpha = td_exp2(rowmax - nm);             // first tile: exp2(-3e38 - nm) = 0 on zero accumulators
+                lsum *= alpha;
+                rowmax = nm;
+                float* sc = scr + wave * 32;                          // wave-private: accumulator row i belongs to query i, lane i holds its factor
+                if (half == 0) sc[l31] = alpha;
+                td_wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 a4 = td_ld4(sc + 8 * u + 4 * half);   // rows 8u + 4 half + {0..3} = registers 4u + {0..3}
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[j][4 * u + e] *= a4[e];
+                }
+                td_wave_sync();
+            }
+        }
         f32x16 pr;
         if (kb + 32 <= p.Lk) {                                        // wave-uniform: no key of this tile is masked
 #pragma unroll
@@ -219,6 +272,28 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[j] = p.bias[cb + j];
     }
+    // Optional LayerNorm strip statistics of the finished rows (strip = this query tile), in ONE sweep and without keeping the rows:
+    // sums of (x - K) and (x - K)^2 against a per-channel shift K = the strip's first row (a sample of the data, so the one-pass
+    // formula M2 = S2 - S1^2 / n loses about a bit instead of cancelling catastrophically when |mean| >> spread); fixed summation order.
+    const bool ln = p.ln_part != nullptr;
+    f32x4 kshift = {0.f, 0.f, 0.f, 0.f}, s1 = kshift, s2 = kshift;
+    if (ln && q0 < p.Lq) {                                            // row 0 of the tile lives in register 0 of lane-half 0
+        float l = 0.f;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32];
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) kshift[j] = acc[j][0] * inv + bv[j];
+        if (p.resid) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) kshift[j] += p.resid[(size_t)q0 * DV + cb + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float other = td_shfl_xor(kshift[j], 32);
+            kshift[j] = half ? other : kshift[j];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -234,22 +309,55 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             o = o + bv;
             if (p.resid) o = o + td_ld4(p.resid + off);
             td_st4(p.out + off, o);
+            if (ln) { const f32x4 d = o - kshift; s1 = s1 + d; s2 = s2 + d * d; }
         } else {
             f32x2 o = {acc[0][r] * inv + bv[0], acc[1][r] * inv + bv[1]};
             if (p.resid) o = o + *reinterpret_cast<const f32x2*>(p.resid + off);
             *reinterpret_cast<f32x2*>(p.out + off) = o;
+            if (ln) {
+                const float d0 = o[0] - kshift[0], d1 = o[1] - kshift[1];
+                s1[0] += d0; s1[1] += d1; s2[0] += d0 * d0; s2[1] += d1 * d1;
+            }
+        }
+    }
+    if (ln) {
+        const int cnt = p.Lq - q0 < 32 ? (p.Lq - q0 > 0 ? p.Lq - q0 : 0) : 32;
+        f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = mean;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float t1 = s1[j] + td_shfl_xor(s1[j], 32), t2 = s2[j] + td_shfl_xor(s2[j], 32);
+            if (cnt) {
+                const float rn = 1.0f / (float)cnt;
+                mean[j] = kshift[j] + t1 * rn;
+                const float v = t2 - t1 * t1 * rn;
+                m2[j] = v > 0.f ? v : 0.f;
+            }
+        }
+        if (half == 0) {
+            const int strip = blockIdx.x * QW + qw;
+            float* pm = p.ln_part + (size_t)strip * DV + cb;
+            float* pq = p.ln_part + ((size_t)p.ln_nstr + strip) * DV + cb;
+            if (NT == 4) { td_st4(pm, mean); td_st4(pq, m2); }
+            else { pm[0] = mean[0]; pm[1] = mean[1]; pq[0] = m2[0]; pq[1] = m2[1]; }
         }
     }
 }
 
-static inline int attn_launch(const AttnArgs& a, int DV, hipStream_t s) {
+// query tiles (= LayerNorm strips) of a launch
+static inline int attn_strips(int Lq, int DV) { return DV == 512 ? (Lq + 31) / 32 : 2 * ((Lq + 63) / 64); }
+
+static inline int attn_launch(AttnArgs a, int DV, bool online, hipStream_t s) {
     if (DV == 512) {
         const int grid = (a.Lq + 31) / 32;
-        TD_LAUNCH((k_attention<1, 4, 4>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+        a.ln_nstr = grid;
+        if (online) TD_LAUNCH((k_attention<1, 4, 4, true>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+        else TD_LAUNCH((k_attention<1, 4, 4, false>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
     } else if (DV == 128) {
         // two query tiles x two channel halves: 2 waves per SIMD at Lq = 32768 (<4,1,4> -- four tiles, all channels -- runs one)
         const int grid = (a.Lq + 63) / 64;
-        TD_LAUNCH((k_attention<2, 2, 2>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
+        a.ln_nstr = 2 * grid;
+        if (online) TD_LAUNCH((k_attention<2, 2, 2, true>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
+        else TD_LAUNCH((k_attention<2, 2, 2, false>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
     } else {
         return -1;
     }

@@ -55,6 +55,15 @@ TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgc
 TD_DEV float td_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 // value of lane ^ 1 (DPP quad_perm [1,0,3,2]: VALU rate, no LDS crossbar)
 TD_DEV float td_swap1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+// true on every lane if the predicate holds on any lane of the wave (result is wave-uniform: usable as a branch condition)
+TD_DEV bool td_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
+// orders this wave's LDS writes before its later LDS reads by OTHER lanes of the same wave (no workgroup barrier needed: a wave's
+// LDS instructions execute in program order; this only stops the compiler from moving them across)
+TD_DEV void td_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 TD_DEV float td_exp2(float x) { return exp2f(x); }
 TD_DEV int td_lane() { return threadIdx.x & 63; }
 TD_DEV int td_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }

@@ -18,6 +18,19 @@ TD_KERNEL void k_nchw3_to_nhwc4(const float* __restrict__ img, float* __restrict
     }
 }
 
+// the same, 4 consecutive pixels per thread: three 16-byte loads (one per colour plane) and four 16-byte stores (HW % 4 == 0)
+TD_KERNEL void k_nchw3_to_nhwc4_x4(const float* __restrict__ img, float* __restrict__ out, int HW) {
+    const int n4 = HW >> 2;
+    for (int p4 = blockIdx.x * blockDim.x + threadIdx.x; p4 < n4; p4 += gridDim.x * blockDim.x) {
+        const f32x4 r = td_ld4(img + (size_t)p4 * 4), g = td_ld4(img + HW + (size_t)p4 * 4), b = td_ld4(img + 2 * (size_t)HW + (size_t)p4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 v = {r[e], g[e], b[e], 0.f};
+            td_st4(out + ((size_t)p4 * 4 + e) * 4, v);
+        }
+    }
+}
+
 // ---- MaxPool2d(3, stride 2, pad 1), padding = -inf, floor mode (resnet.py:137) -----------------------------------
 TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
     const int CV = C >> 2;
@@ -44,6 +57,42 @@ TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ ou
     }
 }
 
+// the same, two horizontally adjacent outputs per thread: they share the middle input column, 15 loads for 2 outputs instead of 18
+TD_KERNEL void k_maxpool3s2_x2(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
+    const int CV = C >> 2, Wp = (Wo + 1) >> 1;
+    const long total = (long)Ho * Wp * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long pp = i / CV;
+        const int oxp = (int)(pp % Wp), oy = (int)(pp / Wp);
+        const int ox0 = 2 * oxp;
+        const f32x4 NEG4 = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        f32x4 m0 = NEG4, m1 = NEG4;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            f32x4 c[5];
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int ix = 2 * ox0 - 1 + kx;
+                c[kx] = (unsigned)ix < (unsigned)W ? td_ld4(in + ((size_t)iy * W + ix) * C + cv * 4) : NEG4;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = c[0][e] > c[1][e] ? c[0][e] : c[1][e];
+                a = c[2][e] > a ? c[2][e] : a;
+                float b = c[3][e] > c[4][e] ? c[3][e] : c[4][e];
+                b = c[2][e] > b ? c[2][e] : b;
+                m0[e] = a > m0[e] ? a : m0[e];
+                m1[e] = b > m1[e] ? b : m1[e];
+            }
+        }
+        td_st4(out + ((size_t)oy * Wo + ox0) * C + cv * 4, m0);
+        if (ox0 + 1 < Wo) td_st4(out + ((size_t)oy * Wo + ox0 + 1) * C + cv * 4, m1);
+    }
+}
+
 // ---- Pyramid pooling (td4_psp18.py:243-284) ----------------------------------------------------------------------
 // AdaptiveAvgPool2d(o): bin i covers [floor(i n / o), ceil((i+1) n / o)).  12 x-bins (levels 1,2,3,6) per row first,
 // then rows are combined per y-bin: 50 bins x C sums, each input element read once per level.
@@ -61,6 +110,32 @@ TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ ro
 #pragma unroll 8
     for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
     td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
+}
+// The same sums with every (row, bin) split SPLIT ways along x inside one workgroup (block = SPLIT * C/4 threads, LDS combine in a
+// fixed order): the level-1 bin is a whole row, 256 serial loads per thread in the kernel above, and the launch was latency-bound
+// (48 us for 67 MB at 1024x2048).  Segment j of a bin [lo, hi) covers [lo + j*len, lo + (j+1)*len), len = ceil((hi-lo)/SPLIT).
+template <int SPLIT>
+TD_KERNEL void k_ppm_rowsum_split(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C) {
+    TD_DYN_LDS(smem);
+    float* red = reinterpret_cast<float*>(smem);               // [SPLIT][C]
+    const int CV = C >> 2;
+    const int y = blockIdx.x / 12, b = blockIdx.x % 12, cv = threadIdx.x % CV, seg = threadIdx.x / CV;
+    const int o = b >= 6 ? 6 : b >= 3 ? 3 : b >= 1 ? 2 : 1;
+    const int i = b >= 6 ? b - 6 : b >= 3 ? b - 3 : b >= 1 ? b - 1 : 0;
+    const float* row = c4 + (size_t)y * w * C + cv * 4;
+    const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
+    const int len = (hi - lo + SPLIT - 1) / SPLIT;
+    const int x0 = lo + seg * len, x1 = (x0 + len < hi) ? x0 + len : hi;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int x = x0; x < x1; ++x) s = s + td_ld4(row + (size_t)x * C);
+    td_st4(red + (size_t)seg * C + cv * 4, s);
+    __syncthreads();
+    if (seg == 0) {
+#pragma unroll
+        for (int k = 1; k < SPLIT; ++k) s = s + td_ld4(red + (size_t)k * C + cv * 4);
+        td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
+    }
 }
 // grid = 50 bins, block = C/4; pooled [50][C] = mean over the bin.  bin order: level-major, then by, then bx.
 TD_KERNEL void k_ppm_bins(const float* __restrict__ rowpart, float* __restrict__ pooled, int h, int w, int C) {
@@ -170,43 +245,48 @@ TD_KERNEL void k_ln_stats(const float* __restrict__ x, float* __restrict__ part,
         td_st4(part + ((size_t)gridDim.x + blockIdx.x) * C + cv * 4, q);
     }
 }
-// pass B: mean[c] and rstd[c] = 1/sqrt(var + eps) from the strip statistics.
-// grid = C/16, block = 256 = 16 channels x 16 strip slices; fixed summation order (deterministic).
-TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int HW, int C, float eps, float* __restrict__ mean,
+// pass B: mean[c] and rstd[c] = 1/sqrt(var + eps) from the strip statistics; strip k covers rows [k*per, min((k+1)*per, HW)).
+// grid = C/4, block = 256 = 4 channels x 64 strip slices (a slice walks strips sl, sl + 64, ...); the 64 slice partials of a
+// channel are combined 8 x 8 in a fixed order (deterministic).  (The first version ran 16 channels x 16 slices on C/16 = 32
+// workgroups: 64 dependent iterations per phase, 22 us for 4 MB of statistics.)
+TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int per, int HW, int C, float eps, float* __restrict__ mean,
                              float* __restrict__ rstd) {
     TD_DYN_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);               // [16 slices][16 channels] + [16] means
-    float* mu = red + 256;
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    const int per = (HW + nstrips - 1) / nstrips;
+    float* red = reinterpret_cast<float*>(smem);               // [64 slices][4 channels], [8][4] second level, [4] means
+    float* red2 = red + 256;
+    float* mu = red2 + 32;
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     auto count = [&](int k) { const int p0 = k * per, p1 = (p0 + per < HW) ? p0 + per : HW; return p1 > p0 ? (float)(p1 - p0) : 0.f; };
-    float s = 0.f;
-    if (c < C)
-        for (int k = sl; k < nstrips; k += 16) s += count(k) * part[(size_t)k * C + c];
-    red[sl * 16 + cl] = s;
-    __syncthreads();
-    if (sl == 0) {
+    auto combine = [&](float v) -> float {                      // sum over the 64 slices of channel cl, identical on the block's first 4 threads
+        red[sl * 4 + cl] = v;
+        __syncthreads();
+        if (sl < 8) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[(sl * 8 + k) * 4 + cl];
+            red2[sl * 4 + cl] = t;
+        }
+        __syncthreads();
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
-        mu[cl] = t / (float)HW;
-    }
-    __syncthreads();
-    const float m = mu[cl];
+        for (int k = 0; k < 8; ++k) t += red2[k * 4 + cl];
+        __syncthreads();
+        return t;
+    };
+    float s = 0.f;
+    if (c < C)
+        for (int k = sl; k < nstrips; k += 64) s += count(k) * part[(size_t)k * C + c];
+    const float m = combine(s) / (float)HW;
     s = 0.f;
     if (c < C)
-        for (int k = sl; k < nstrips; k += 16) {
+        for (int k = sl; k < nstrips; k += 64) {
             const float d = part[(size_t)k * C + c] - m;
             s += part[((size_t)nstrips + k) * C + c] + count(k) * d * d;
         }
-    __syncthreads();
-    red[sl * 16 + cl] = s;
-    __syncthreads();
+    const float t = combine(s);
+    (void)mu;
     if (sl == 0 && c < C) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
         mean[c] = m;
         rstd[c] = 1.0f / sqrtf(t / (float)HW + eps);
     }

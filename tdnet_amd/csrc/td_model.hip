@@ -133,7 +133,7 @@ extern "C" void tdnet_opts_default(tdnet_opts* o) {
     o->gemm_persistent = 1;                 // stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel
     o->stagger = 0;
     o->attention = TDNET_ATTENTION_DEFAULT;
-    o->stem = TDNET_STEM_DEFAULT;
+    o->fusion = TDNET_FUSION_DEFAULT;
 }
 static tdnet_opts opts_or_default(const tdnet_opts* o) {
     tdnet_opts d;
@@ -264,6 +264,9 @@ struct tdnet {
     // cache-only work (V' GEMMs + the two cached-frame attention steps) runs on a side stream under the backbone
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;                 // Encoding's q / k projections beside w_vs (fusion bit 1)
+    bool ln_pending = false;                                          // the `ln` map of the last frame was not materialised (fusion bit 4)
+    int ln_path = 0;
     bool failed = false;                                              // a launch helper reported an error during the current forward
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -419,6 +422,8 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     if (n->side) hipStreamDestroy(n->side);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ev_join) hipEventDestroy(n->ev_join);
+    if (n->ev_fork2) hipEventDestroy(n->ev_fork2);
+    if (n->ev_join2) hipEventDestroy(n->ev_join2);
     delete n;
 }
 
@@ -515,7 +520,8 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
-    if (dev_alloc(&n->ln_part, (size_t)2 * 512 * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
+    const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
+    if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
     n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -646,6 +652,8 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     TD_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
     TD_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TD_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    TD_HIP(hipEventCreateWithFlags(&n->ev_fork2, hipEventDisableTiming));
+    TD_HIP(hipEventCreateWithFlags(&n->ev_join2, hipEventDisableTiming));
     n->finalized = true;
     n->flops_frame = frame_flops(n);
     return 0;
@@ -671,9 +679,13 @@ static void prof_end(tdnet* n, hipStream_t s) {
     n->nrec++;
 }
 
+// plane LayerNorm applied to the conv's INPUT inside a Winograd input transform (td_wino.h WinoArgs.ln_*)
+struct LnFuse { const float *mean, *rstd, *g, *b; };
+
 // out[Ho*Wo][Cout] = act(conv(in[H][W][Cin]) + bias (+ resid))
 static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
-                    int* Ho_out = nullptr, int* Wo_out = nullptr) {
+                    int* Ho_out = nullptr, int* Wo_out = nullptr, const LnFuse* lnf = nullptr) {
+    if (lnf && !L.wino) return td_fail("internal: LayerNorm fusion needs a Winograd input transform");
     const int Ho = out_size(H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(W, L.KS, L.stride, L.dil, L.pad);
     if (L.wino) {
         const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
@@ -688,6 +700,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         WinoArgs wa;
         wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
         wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act;
+        wa.ln_mean = lnf ? lnf->mean : nullptr; wa.ln_rstd = lnf ? lnf->rstd : nullptr; wa.ln_g = lnf ? lnf->g : nullptr; wa.ln_b = lnf ? lnf->b : nullptr;
         prof_begin(n, 2, false, 0, s);
         if (L.wino == 4) TD_LAUNCH(k_wino4_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
         else TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
@@ -733,28 +746,36 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     return 0;
 }
 
+// ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
-                         int Lq, int Lk, int DV, float* out, hipStream_t s) {
+                         int Lq, int Lk, int DV, float* out, hipStream_t s, bool online = false, float* ln_part = nullptr) {
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
     a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
+    a.ln_part = ln_part; a.ln_nstr = 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = attn_launch(a, DV, s);
+    const int rc = attn_launch(a, DV, online, s);
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or 512)", DV);
     return 0;
 }
 
+// Plane LayerNorm (td4_psp18.py:306-312) in up to three launches: strip statistics (skipped when the attention epilogue already
+// wrote them: stats_nstr > 0 strips of 32 rows), their exact combination, and the normalisation (skipped when y == nullptr: the
+// head's Winograd input transform applies it on the fly, run_conv's LnFuse).
 static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* g, const float* b, float* part, float* mean,
-                          float* rstd, float* y, hipStream_t s) {
+                          float* rstd, float* y, hipStream_t s, int stats_nstr = 0) {
     const int CV = C / 4, rows = 256 / CV;
-    int nstr = (HW + rows - 1) / rows;
-    if (nstr > 512) nstr = 512;
-    const int lds = (rows + 1) * C * 4;
+    int nstr = stats_nstr, per = 32;
     prof_begin(n, 2, false, 0, s);
-    TD_LAUNCH(k_ln_stats, dim3(nstr), dim3(256), lds, s, x, part, HW, C);                   // part: [2][nstr][C]
-    TD_LAUNCH(k_ln_finalize, dim3((C + 15) / 16), dim3(256), (256 + 16) * 4, s, (const float*)part, nstr, HW, C, 1e-5f, mean, rstd);
-    TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
+    if (!stats_nstr) {
+        nstr = (HW + rows - 1) / rows;
+        if (nstr > 512) nstr = 512;
+        per = (HW + nstr - 1) / nstr;                                                           // k_ln_stats' strip length
+        TD_LAUNCH(k_ln_stats, dim3(nstr), dim3(256), (rows + 1) * C * 4, s, x, part, HW, C);    // part: [2][nstr][C]
+    }
+    TD_LAUNCH(k_ln_finalize, dim3((C + 3) / 4), dim3(256), (256 + 32 + 4) * 4, s, (const float*)part, nstr, per, HW, C, 1e-5f, mean, rstd);
+    if (y) TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
     prof_end(n, s);
 }
 
@@ -762,6 +783,10 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
 static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int FS, const float* wgt, const float* bias, int pid,
                     float* rowpart, float* pooled, float* ppmfeat, float* z, hipStream_t s) {
     prof_begin(n, 2, false, 0, s);
+    const bool split = n && (n->opts.fusion & 8);
+    if (split && C / 4 <= 128) TD_LAUNCH((k_ppm_rowsum_split<4>), dim3(h * 12), dim3(C), 4 * C * 4, s, c4, rowpart, w, C);             // 512 threads
+    else if (split && C / 4 <= 256) TD_LAUNCH((k_ppm_rowsum_split<2>), dim3(h * 12), dim3(C / 2), 2 * C * 4, s, c4, rowpart, w, C);    // 512 threads
+    else
     TD_LAUNCH(k_ppm_rowsum, dim3(h * 12), dim3(C / 4), 0, s, c4, rowpart, w, C);
     TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
     TD_LAUNCH(k_ppm_conv, dim3(50 * (FS / 64)), dim3(256), 256 * 4, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
@@ -770,14 +795,20 @@ static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int 
     prof_end(n, s);
 }
 
-static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, hipStream_t s) {
+static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, hipStream_t s, int fusion) {
     prof_begin(n, 2, false, 0, s);
+    if ((fusion & 16) && (H * W) % 4 == 0 && ((size_t)img & 15) == 0)
+        TD_LAUNCH(k_nchw3_to_nhwc4_x4, dim3(td_grid_for((long)H * W / 4)), dim3(256), 0, s, img, img4, H * W);
+    else
     TD_LAUNCH(k_nchw3_to_nhwc4, dim3(td_grid_for((long)H * W)), dim3(256), 0, s, img, img4, H * W);
     prof_end(n, s);
 }
-static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* out, hipStream_t s) {
+static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* out, hipStream_t s, int fusion) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     prof_begin(n, 2, false, 0, s);
+    if (fusion & 16)
+        TD_LAUNCH(k_maxpool3s2_x2, dim3(td_grid_for((long)Ho * ((Wo + 1) / 2) * (C / 4), 256, 256 * 16)), dim3(256), 0, s, in, out, H, W, C, Ho, Wo);
+    else
     TD_LAUNCH(k_maxpool3s2, dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, in, out, H, W, C, Ho, Wo);
     prof_end(n, s);
 }
@@ -842,7 +873,7 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
 static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s) {
     const int DV = n->DV;
     // backbone (resnet.py:204-215)
-    run_stem_pre(n, img, n->H, n->W, n->img4, s);
+    run_stem_pre(n, img, n->H, n->W, n->img4, s, n->opts.fusion);
     if (n->deep) {                                                     // resnet.py:122-131
         TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1b, s));
         TD_TRY(run_conv(n, L.stem2, n->s1b, n->H1, n->W1, nullptr, n->s1, s));
@@ -850,7 +881,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     } else {
         TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s));
     }
-    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s);
+    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->opts.fusion);
     int ch = n->H2, cw = n->W2;
     for (auto& B : L.blocks) {
         int oh, ow;
@@ -877,20 +908,34 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
         return n->failed ? -1 : 0;
     }
     run_ppm(n, c4, n->h, n->w, n->C, n->C / 2, n->C / 8, L.d_ppm_w, L.d_ppm_b, L.pid, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
-    // Encoding, pre=False (transformer.py:52-56)
-    TD_TRY(run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s));
-    TD_TRY(run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, s));
-    TD_TRY(run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, s));
-    // Encoding, pre=True (transformer.py:34-50) -> pending cache entry; q_ and v_ are the stride-4 subsample of q_cur / v_cur
+    // Encoding, pre=False (transformer.py:52-56) and pre=True (:34-50) -> pending cache entry; q_ and v_ are the stride-4 subsample of
+    // q_cur / v_cur.  The q / k branches (512 -> 64 -> 64; the k branch on the 16x smaller key grid: 16 workgroups) are short,
+    // latency-bound launches that depend only on z: with fusion bit 1 they run on the side stream beside the w_vs GEMM.
     const int slot = free_slot(n);
     if (slot < 0) return td_fail("internal: no free cache slot");
     CacheSlot& cs = n->slots[slot];
-    TD_TRY(run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, s));
-    TD_TRY(run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, s));
+    const bool beside = (n->opts.fusion & 1) != 0;
+    hipStream_t qs = beside ? n->side : s;
+    if (beside) {
+        TD_HIP(hipEventRecord(n->ev_fork2, s));
+        TD_HIP(hipStreamWaitEvent(qs, n->ev_fork2, 0));
+    }
+    if (!beside) TD_TRY(run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s));
+    TD_TRY(run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, qs));
+    TD_TRY(run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, qs));
+    TD_TRY(run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, qs));
+    TD_TRY(run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, qs));
+    prof_begin(n, 2, false, 0, qs);
+    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, qs, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
+    prof_end(n, qs);
+    if (beside) {
+        TD_HIP(hipEventRecord(n->ev_join2, qs));
+        TD_TRY(run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s));
+    }
     prof_begin(n, 2, false, 0, s);
     TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
-    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, s, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
     prof_end(n, s);
+    if (beside) TD_HIP(hipStreamWaitEvent(s, n->ev_join2, 0));
     n->pending_slot = slot;
     return n->failed ? -1 : 0;
 }
@@ -899,18 +944,29 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
 static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
     const int DV = n->DV;
     const float* feat = n->v_cur;
+    int stats_nstr = 0;
     if (steady) {
         TD_HIP(hipStreamWaitEvent(s, n->ev_join, 0));                   // join: v' of the newest cached frame is ready
         const CacheSlot& ck = n->slots[n->fifo[n->FIFO - 1]];
         const AtnLayer& A = L.atn[n->P == 4 ? 2 : 0];                   // td4_psp18.py:147 / td2_psp50.py:120
-        if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s)) return -1;   // v4 + v_cur
+        stats_nstr = (n->opts.fusion & 2) ? attn_strips(n->Lq, DV) : 0;                                         // LayerNorm strip statistics from the epilogue
+        if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention != 0,
+                          stats_nstr ? n->ln_part : nullptr)) return -1;                                                  // v4 + v_cur
         feat = n->feat;
     } else {
         // warm-up (td4_psp18.py:142-143): feat = v_cur; keep a copy so the "feat" stage is well defined
         TD_HIP(hipMemcpyAsync(n->feat, n->v_cur, (size_t)n->Lq * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
         feat = n->feat;
     }
-    run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, s);
+    // fusion bit 4: the normalised map is never written -- the head's Winograd input transform normalises while it reads `feat`
+    const bool ln_in_head = (n->opts.fusion & 4) && L.head3.wino;
+    run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, ln_in_head ? nullptr : n->ln, s, stats_nstr);
+    n->ln_pending = ln_in_head;
+    n->ln_path = (int)(&L - &n->paths[0]);
+    if (ln_in_head) {
+        const LnFuse lf = {n->ln_mean, n->ln_rstd, L.d_ln_g, L.d_ln_b};
+        TD_TRY(run_conv(n, L.head3, feat, n->h, n->w, nullptr, n->headmid, s, nullptr, nullptr, &lf));
+    } else
     TD_TRY(run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s));
     TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
     // FIFO push (td4_psp18.py:153-154, :123-134)
@@ -1081,6 +1137,13 @@ extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_
     const size_t count = (size_t)rows * C;
     if (capacity < count) return td_fail("tdnet_get_stage: capacity %zu < %zu", capacity, count);
     TD_HIP(hipDeviceSynchronize());
+    if (s == "ln" && n->ln_pending) {                                  // fusion bit 4 skipped this map: materialise it now, same arithmetic
+        const PathLayers& PL = n->paths[n->ln_path];
+        TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)n->Lq * (n->DV / 4))), dim3(256), 0, (hipStream_t)0, (const float*)n->feat,
+                  (const float*)n->ln_mean, (const float*)n->ln_rstd, (const float*)PL.d_ln_g, (const float*)PL.d_ln_b, n->ln, n->Lq, n->DV);
+        TD_HIP(hipDeviceSynchronize());
+        n->ln_pending = false;
+    }
     if (nhwc_map && !planar) {                                         // [HW][C] -> [C][HW] like the reference's NCHW maps
         TD_LAUNCH(k_nhwc_to_nchw, dim3(td_grid_for((long)count)), dim3(256), 0, (hipStream_t)0, src, n->stage_tmp, rows, (int)C);
         TD_HIP(hipDeviceSynchronize());
@@ -1184,18 +1247,20 @@ extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const flo
     free_conv_layer(L);
     return rc;
 }
-extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host, const float* bias_host, float* out, void* stream) {
+extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host, const float* bias_host, const tdnet_opts* opts,
+                             float* out, void* stream) {
+    const tdnet_opts o = opts_or_default(opts);
     hipStream_t s = (hipStream_t)stream;
     const int H1 = (H - 1) / 2 + 1, W1 = (W - 1) / 2 + 1;
     ConvLayer L;
     std::vector<float> w(w_host, w_host + 64 * 3 * 49), b;
     if (bias_host) b.assign(bias_host, bias_host + 64);
-    if (make_conv_layer(L, w, b, 64, 3, 7, 2, 1, 1, true, (long)H1 * W1, opts_or_default(nullptr))) return -1;
+    if (make_conv_layer(L, w, b, 64, 3, 7, 2, 1, 1, true, (long)H1 * W1, o)) return -1;
     float *img4 = nullptr, *s1 = nullptr;
     if (dev_alloc(&img4, (size_t)H * W * 4) || dev_alloc(&s1, (size_t)H1 * W1 * 64)) return -1;
-    run_stem_pre(nullptr, img, H, W, img4, s);
+    run_stem_pre(nullptr, img, H, W, img4, s, o.fusion);
     run_conv(nullptr, L, img4, H, W, nullptr, s1, s);
-    run_maxpool(nullptr, s1, H1, W1, 64, out, s);
+    run_maxpool(nullptr, s1, H1, W1, 64, out, s, o.fusion);
     TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());
     hipFree(img4); hipFree(s1);
@@ -1203,11 +1268,20 @@ extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host
     return 0;
 }
 extern "C" int tdnet_op_attention(const float* q, const float* k, const float* vp, const float* bias, const float* resid, int Lq,
-                                  int Lk, int DV, float* out, void* stream) {
+                                  int Lk, int DV, int online, const float* ln_g, const float* ln_b, float* ln_out, float* out,
+                                  void* stream) {
     if (Lk < 1 || Lq < 1) return td_fail("tdnet_op_attention: empty input");
-    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, (hipStream_t)stream)) return -1;
-    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    float *part = nullptr, *mean = nullptr, *rstd = nullptr;
+    if (ln_out) {                                                      // + plane LayerNorm of the result from the epilogue's strip statistics
+        if (!ln_g || !ln_b) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
+        if (dev_alloc(&part, (size_t)2 * attn_strips(Lq, DV) * DV) || dev_alloc(&mean, DV) || dev_alloc(&rstd, DV)) return -1;
+    }
+    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online != 0, part)) return -1;
+    if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
+    TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());
+    if (part) { hipFree(part); hipFree(mean); hipFree(rstd); }
     return 0;
 }
 extern "C" int tdnet_op_layernorm_hw(const float* x, int HW, int C, const float* g, const float* b, float* out, void* stream) {

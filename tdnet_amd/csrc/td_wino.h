@@ -28,7 +28,21 @@ struct WinoArgs {
     const float* resid;   // [H][W][Cout] or nullptr
     float* out;           // [H][W][Cout]
     int H, W, C, Cout, dil, TY, TX, T, act;
+    // Optional plane-LayerNorm fused into the INPUT transform (the FCN head reads LayerNorm(feat), td4_psp18.py:151,306-312): the
+    // patch element at pixel p, channel c becomes (x - ln_mean[c]) * ln_rstd[c] * ln_g[p] + ln_b[p] -- the arithmetic of k_ln_apply,
+    // same operation order, so fused and unfused results are bit-identical -- and stays 0 outside the image (the conv's zero padding
+    // applies to the normalised map).  ln_mean == nullptr: off.
+    const float* ln_mean; const float* ln_rstd; const float* ln_g; const float* ln_b;
 };
+TD_DEV f32x4 td_wino_ld(const WinoArgs& p, int y, int x, int cv, const f32x4& m4, const f32x4& r4) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+        const size_t pix = (size_t)y * p.W + x;
+        z = td_ld4(p.in + pix * p.C + cv * 4);
+        if (p.ln_mean) z = (z - m4) * r4 * p.ln_g[pix] + p.ln_b[pix];
+    }
+    return z;
+}
 
 // B^T d B for one 4x4 patch held as d[r][c] (each a float4 of channels)
 TD_DEV void td_wino_bt_d_b(const f32x4 (&d)[4][4], f32x4 (&v)[4][4]) {
@@ -60,16 +74,13 @@ TD_KERNEL void k_wino_in(WinoArgs p) {
         const int ty = t % p.TY; t /= p.TY;
         const int px = t % p.dil, py = t / p.dil;
         f32x4 d[4][4], v[4][4];
+        f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, r4 = m4;
+        if (p.ln_mean) { m4 = td_ld4(p.ln_mean + cv * 4); r4 = td_ld4(p.ln_rstd + cv * 4); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int y = py + p.dil * (2 * ty - 1 + r);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int x = px + p.dil * (2 * tx - 1 + c);
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) z = td_ld4(p.in + ((size_t)y * p.W + x) * p.C + cv * 4);
-                d[r][c] = z;
-            }
+            for (int c = 0; c < 4; ++c) d[r][c] = td_wino_ld(p, y, px + p.dil * (2 * tx - 1 + c), cv, m4, r4);
         }
         td_wino_bt_d_b(d, v);
         const size_t tile = (size_t)(i / CV);
@@ -162,17 +173,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
         const int ty = t % p.TY; t /= p.TY;
         const int px = t % p.dil, py = t / p.dil;
         f32x4 tm[6][6];
+        f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, r4 = m4;
+        if (p.ln_mean) { m4 = td_ld4(p.ln_mean + cv * 4); r4 = td_ld4(p.ln_rstd + cv * 4); }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const int x = px + p.dil * (4 * tx - 1 + c);
             f32x4 d[6], col[6];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int y = py + p.dil * (4 * ty - 1 + r);
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) z = td_ld4(p.in + ((size_t)y * p.W + x) * p.C + cv * 4);
-                d[r] = z;
-            }
+            for (int r = 0; r < 6; ++r) d[r] = td_wino_ld(p, py + p.dil * (4 * ty - 1 + r), x, cv, m4, r4);
             td_wino4_bt(d, col);                                      // B^T d, one column
 #pragma unroll
             for (int r = 0; r < 6; ++r) tm[r][c] = col[r];

@@ -119,6 +119,12 @@ TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b,
 TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return tdemu::mfma32_f16(a, b, c); }
 TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
 TD_DEV float td_swap1(float v) { return tdemu::shfl_xor(v, 1); }
+TD_DEV bool td_any(bool pred) {
+    float f = pred ? 1.f : 0.f;
+    for (int m = 1; m < 64; m <<= 1) { const float o = tdemu::shfl_xor(f, m); f = o > f ? o : f; }
+    return f != 0.f;
+}
+TD_DEV void td_wave_sync() { (void)tdemu::shfl_xor(0.f, 1); }   // fibers of a wave meet here (a collective is the emulator's wave-level barrier)
 TD_DEV float td_exp2(float x) { return exp2f(x); }
 TD_DEV int td_lane() { return threadIdx.x & 63; }
 TD_DEV int td_wave() { return threadIdx.x >> 6; }

@@ -70,7 +70,8 @@ def conv(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed
     return err
 
 
-def stem(lib, mem, H, W, seed=0, tol=1e-4):
+def stem(lib, mem, H, W, seed=0, tol=1e-4, opts=None):
+    import ctypes
     g = np.random.default_rng(seed)
     img = g.standard_normal((3, H, W)).astype(np.float32)
     w = (g.standard_normal((64, 3, 7, 7)) * 0.1).astype(np.float32)
@@ -78,18 +79,24 @@ def stem(lib, mem, H, W, seed=0, tol=1e-4):
     ref = F.max_pool2d(F.relu(F.conv2d(torch.from_numpy(img)[None], torch.from_numpy(w), torch.from_numpy(b), 2, 3)), 3, 2, 1)
     ref = ref[0].permute(1, 2, 0).numpy()
     di, out = mem.put(img), mem.empty(ref.shape)
-    lib.check(lib.tdnet_op_stem(mem.ptr(di), H, W, w.ctypes.data, b.ctypes.data, mem.ptr(out), mem.stream))
+    lib.check(lib.tdnet_op_stem(mem.ptr(di), H, W, w.ctypes.data, b.ctypes.data, ctypes.byref(lib.opts(**(opts or {}))), mem.ptr(out), mem.stream))
     err = float(np.abs(mem.get(out) - ref).max())
     assert err <= tol, ("stem", H, W, err)
     return err
 
 
-def attention(lib, mem, Lq, Lk, DV, bias=True, resid=True, seed=0, tol=1e-4, qk_scale=1.0, spike=False):
+def attention(lib, mem, Lq, Lk, DV, bias=True, resid=True, seed=0, tol=1e-4, qk_scale=1.0, spike=False, online=0, ln=False, ramp=False):
+    """online: the single-pass schedule; ln: also check the plane LayerNorm computed from the epilogue's strip statistics;
+    ramp: keys sorted by growing score for every query, so the online reference has to move again and again."""
     g = np.random.default_rng(seed)
     q = (qk_scale * g.standard_normal((Lq, 64))).astype(np.float32)
     k = (qk_scale * g.standard_normal((Lk, 64))).astype(np.float32)
     if spike:                                  # one key dominating one query row: exercises the max subtraction
         k[Lk // 2] = 6.0 * q[Lq // 3] / max(1e-6, float(np.linalg.norm(q[Lq // 3]))) * 8.0
+    if ramp:                                   # k_j = (j / Lk) * 40 * u with q . u > 0 for all q: scores grow along the key axis by ~100 log2 units
+        u = np.ones(64, np.float32) / 8.0
+        q = np.abs(q) + 0.5
+        k = (np.arange(Lk, dtype=np.float32)[:, None] / max(1, Lk - 1)) * 40.0 * u[None, :] + 0.1 * k
     v = g.standard_normal((Lk, DV)).astype(np.float32)
     b = g.standard_normal(DV).astype(np.float32)
     r = g.standard_normal((Lq, DV)).astype(np.float32)
@@ -100,10 +107,18 @@ def attention(lib, mem, Lq, Lk, DV, bias=True, resid=True, seed=0, tol=1e-4, qk_
         ref = ref + torch.from_numpy(r)
     dq, dk, dv_, db, dr = mem.put(q), mem.put(k), mem.put(v), mem.put(b), mem.put(r)
     out = mem.empty((Lq, DV))
+    gg = g.uniform(0.5, 1.5, Lq).astype(np.float32)
+    bb = g.standard_normal(Lq).astype(np.float32)
+    dg, dbb, lnout = (mem.put(gg), mem.put(bb), mem.empty((Lq, DV))) if ln else (None, None, None)
     lib.check(lib.tdnet_op_attention(mem.ptr(dq), mem.ptr(dk), mem.ptr(dv_), mem.ptr(db) if bias else None,
-                                     mem.ptr(dr) if resid else None, Lq, Lk, DV, mem.ptr(out), mem.stream))
+                                     mem.ptr(dr) if resid else None, Lq, Lk, DV, int(online), mem.ptr(dg), mem.ptr(dbb), mem.ptr(lnout),
+                                     mem.ptr(out), mem.stream))
     err = float(np.abs(mem.get(out) - ref.float().numpy()).max())
-    assert err <= tol, ("attention", Lq, Lk, DV, bias, resid, err)
+    assert err <= tol, ("attention", Lq, Lk, DV, bias, resid, online, err)
+    if ln:
+        lref = F.layer_norm(ref.float().T.contiguous(), (Lq,), torch.from_numpy(gg), torch.from_numpy(bb), 1e-5).T.numpy()
+        lerr = float(np.abs(mem.get(lnout) - lref).max())
+        assert lerr <= 2 * tol, ("attention+layernorm", Lq, Lk, DV, online, lerr)
     return err
 
 

@@ -45,6 +45,8 @@ def test_conv_auto_tile_and_edges(lib):
 def test_stem(lib):
     opcheck.stem(lib, MEM, 33, 65)
     opcheck.stem(lib, MEM, 40, 52)
+    for (H, W) in ((40, 52), (33, 65), (34, 66), (8, 10)):                # fusion bit 16: 4-pixel layout kernel (H*W % 4 == 0) and 2-output max-pool, odd and even widths
+        opcheck.stem(lib, MEM, H, W, opts={"fusion": 16})
 
 
 def test_attention(lib):
@@ -57,6 +59,21 @@ def test_attention(lib):
     opcheck.attention(lib, MEM, 1, 1, 128)
     opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True)     # d_v 128 variant: two query tiles x two channel halves, ragged both ways
     opcheck.attention(lib, MEM, 64, 64, 128, False, True)
+
+
+def test_attention_online_softmax_and_layernorm_statistics(lib):
+    """tdnet_opts.attention = 1 (single pass, lazily moved reference) and fusion bit 2 (plane-LayerNorm strip statistics written by
+    the epilogue): same gate as the two-pass kernel, on ragged shapes, with a dominating key, and with scores that keep growing
+    along the key axis (the reference has to move several times per query tile)."""
+    for online in (1, 0):
+        opcheck.attention(lib, MEM, 45, 6, 512, online=online, ln=True)
+        opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=online, ln=True)
+        opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=online, ln=True)
+        opcheck.attention(lib, MEM, 33, 1, 128, online=online, ln=True)                  # a second strip with one row; a single key
+        opcheck.attention(lib, MEM, 97, 300, 512, ramp=True, online=online, ln=True)
+        opcheck.attention(lib, MEM, 70, 260, 128, False, True, ramp=True, online=online, ln=True)   # (without the residual the plane is nearly constant: LayerNorm of it is ill-conditioned)
+    opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0, online=1)
+    opcheck.attention(lib, MEM, 1, 1, 128, online=1)
 
 
 def test_layernorm_ppm_upsample(lib):
@@ -107,6 +124,35 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
     lab = np.zeros((H, W), np.int32)
     e.forward_labels(x, 0, lab)
     assert (lab == out[0].argmax(0)).all()
+    e.close()
+
+
+@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"attention": 1, "fusion": 31}), ("td2", "resnet18", {"attention": 1, "fusion": 31}),
+                                          ("td4", "resnet18", {"fusion": 6, "winograd": 1}), ("td2", "resnet34", {"fusion": 31, "winograd": 0}), ("td2", "resnet50", {"fusion": 31, "attention": 1})])
+def test_pipeline_with_fusion_options_against_reference_goldens(lib, golden_dir, name, bb, opts):
+    """tdnet_opts.attention = 1 (online softmax) and every tdnet_opts.fusion bit (q/k projections on the side stream, LayerNorm
+    statistics from the attention epilogue, LayerNorm applied inside the head's Winograd input transform, split pyramid row sums)
+    against the goldens of the real reference, stage by stage -- including `ln`, which the fused path materialises only on request --
+    and with the head on F(4x4), F(2x2) and direct (where bit 4 must fall back to the separate normalisation kernel)."""
+    H, W = 33, 65
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    hk, wk = arch.key_size(h), arch.key_size(w)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=opts)
+    e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    shapes = {"z": (1, spec.d_model, h, w), "v_cur": (1, spec.d_v, h, w), "q_cur": (1, h * w, 64), "ln": (1, spec.d_v, h, w),
+              "lowres": (1, 19, h, w), "cache_q": (1, hk * wk, 64), "cache_k": (1, hk * wk, 64), "cache_v": (1, hk * wk, spec.d_v)}
+    for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 2, seed=1)):
+        out = np.full((1, 19, H, W), 7e7, np.float32)
+        e.forward(x, t % spec.path_num, out)
+        for st, shp in shapes.items():
+            key = "f%d_%s" % (t, st)
+            if key in g.files:
+                got = e.stage(st, shp)
+                assert np.abs(got - g[key]).max() <= 1e-4 * max(1.0, np.abs(g[key]).max()), (t, st)
+        assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
+        assert (out[0].argmax(0) == g["f%d_logits" % t][0].argmax(0)).all()
     e.close()
 
 

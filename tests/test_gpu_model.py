@@ -169,7 +169,7 @@ def test_uncalibrated_reference_init(wino):
     m = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None, kernel_opts={"winograd": wino}).eval().to("cuda")
     m.load_state_dict(sd)
     tdnet_ref.tune_threads()
-    e_gpu, e_cpu, s_gpu, s_cpu, n = 0.0, 0.0, 0.0, 0.0, 0
+    e_gpu, e_cpu, s_gpu, s_cpu, n, tmax = 0.0, 0.0, 0.0, 0.0, 0, 0.0
     with torch.no_grad():
         for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
             xt = torch.from_numpy(x)
@@ -177,6 +177,7 @@ def test_uncalibrated_reference_init(wino):
             truth = ref64.forward(xt.double(), t % 4).numpy()
             cpu = ref32.forward(xt, t % 4).double().numpy()
             dg, dc = out - truth, cpu - truth
+            tmax = max(tmax, float(np.abs(truth).max()))
             e_gpu, e_cpu = max(e_gpu, float(np.abs(dg).max())), max(e_cpu, float(np.abs(dc).max()))
             s_gpu, s_cpu, n = s_gpu + float((dg ** 2).sum()), s_cpu + float((dc ** 2).sum()), n + dg.size
             bad = out[0].argmax(0) != truth[0].argmax(0)
@@ -184,9 +185,9 @@ def test_uncalibrated_reference_init(wino):
                 top2 = np.sort(truth[0], axis=0)[-2:]
                 assert ((top2[1] - top2[0])[bad] <= 2 * float(np.abs(dg).max())).all(), (wino, t, "label flip outside the tie band")
     r_gpu, r_cpu = (s_gpu / n) ** 0.5, (s_cpu / n) ** 0.5
-    print("reference init, winograd=%d: max err gpu %.2e vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f)"
-          % (wino, e_gpu, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu))
-    assert e_gpu <= 4.0 * e_cpu and r_gpu <= 3.0 * r_cpu, (wino, e_gpu, e_cpu, r_gpu, r_cpu)
+    print("reference init, winograd=%d: max|truth| %.1f; max err gpu %.2e (%.1e of max|truth|) vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f)"
+          % (wino, tmax, e_gpu, e_gpu / tmax, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu))
+    assert e_gpu <= 1e-3 * tmax and r_gpu <= 5.0 * r_cpu, (wino, tmax, e_gpu, e_cpu, r_gpu, r_cpu)
 
 
 def test_properties_determinism_labels_reset():

@@ -59,6 +59,8 @@ def test_stem(lib, mem):
     opcheck.stem(lib, mem, 33, 65)
     opcheck.stem(lib, mem, 257, 513)
     opcheck.stem(lib, mem, 300, 422)
+    for (H, W) in ((257, 513), (300, 422), (1024, 2048), (34, 66)):
+        opcheck.stem(lib, mem, H, W, opts={"fusion": 16})
 
 
 def test_attention(lib, mem):
@@ -72,6 +74,16 @@ def test_attention(lib, mem):
     opcheck.attention(lib, mem, 32768, 2048, 512, spike=True)              # final step @1024x2048
     opcheck.attention(lib, mem, 32768, 2048, 128, qk_scale=1.5)            # td2-psp18 @1024x2048 (BASELINE configs[1]): the d_v = 128 variant at full size
     opcheck.attention(lib, mem, 18721, 1225, 128, spike=True)              # td2 at the native 769x1537
+
+
+def test_attention_online_and_layernorm_statistics(lib, mem):
+    for online in (1, 0):
+        opcheck.attention(lib, mem, 300, 200, 512, spike=True, online=online, ln=True)
+        opcheck.attention(lib, mem, 97, 300, 512, ramp=True, online=online, ln=True)
+        opcheck.attention(lib, mem, 18721, 1225, 512, online=online, ln=True)
+        opcheck.attention(lib, mem, 32768, 2048, 512, spike=True, online=online, ln=True)
+        opcheck.attention(lib, mem, 32768, 2048, 128, qk_scale=1.5, online=online, ln=True)
+        opcheck.attention(lib, mem, 18721, 1225, 128, spike=True, ramp=True, online=online, ln=True)
 
 
 def test_layernorm_ppm_upsample(lib, mem):

@@ -4,12 +4,12 @@ import torch
 from tdnet_amd import _capi
 lib = _capi.lib(); dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(1)
-def run(Lq, Lk, DV, iters=20):
+def run(Lq, Lk, DV, online=0, iters=20):
     q = (torch.randn(Lq, 64, generator=g) * 0.5).to(dev); k = (torch.randn(Lk, 64, generator=g) * 0.5).to(dev)
     vp = torch.randn(Lk, DV, generator=g).to(dev); b = torch.randn(DV, generator=g).to(dev); r = torch.randn(Lq, DV, generator=g).to(dev)
     out = torch.empty(Lq, DV, device=dev)
     s = torch.cuda.current_stream().cuda_stream
-    call = lambda: lib.tdnet_op_attention(q.data_ptr(), k.data_ptr(), vp.data_ptr(), b.data_ptr(), r.data_ptr(), Lq, Lk, DV, out.data_ptr(), s)
+    call = lambda: lib.tdnet_op_attention(q.data_ptr(), k.data_ptr(), vp.data_ptr(), b.data_ptr(), r.data_ptr(), Lq, Lk, DV, online, None, None, None, out.data_ptr(), s)
     for _ in range(3): call()
     torch.cuda.synchronize()
     best = 1e9
@@ -20,6 +20,7 @@ def run(Lq, Lk, DV, iters=20):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / iters)
     fl = 2.0 * Lq * Lk * (64 + DV)
-    print("Lq=%6d Lk=%5d DV=%3d: %.4f ms  %.1f TF (algorithmic; the kernel runs QK^T twice)" % (Lq, Lk, DV, best, fl / best / 1e9), flush=True)
+    print("Lq=%6d Lk=%5d DV=%3d %s: %.4f ms  %.1f TF algorithmic" % (Lq, Lk, DV, "online  " if online else "two-pass", best, fl / best / 1e9), flush=True)
 for shape in ((32768, 2048, 512), (2048, 2048, 512), (18721, 1225, 512), (32768, 2048, 128), (12288, 768, 512)):
-    run(*shape)
+    for online in (0, 1):
+        run(*shape, online=online)

@@ -9,7 +9,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 R=gpurun_out/$TAG
 rm -rf $R; mkdir -p $R
 if [ "$TESTS" = "tests" ]; then
-  timeout 1500 python -m pytest tests -q -m gpu -s --durations=12 2>&1 | tail -60 > $R/gpu_tests.log
+  timeout 1500 python -m pytest tests -q -m gpu -s --durations=12 > $R/gpu_tests.log 2>&1
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1
 fi
 timeout 900 python bench.py "$@" > $R/bench.log 2>&1
