@@ -92,6 +92,22 @@ static void yield() {
     cur = nx;
     tdemu_switch(&me->sp, nx->sp);
 }
+// the same inside the current fiber's wave: lanes waiting in a wave collective only need their 63 wave-mates to arrive, so there is no
+// point in visiting the other waves' fibers (which sit in their own collectives) -- 4x fewer context switches per MFMA at 256 threads
+static void yield_in_wave() {
+    Fiber* me = cur;
+    const int idx = (int)(me - W->fibers), base = idx & ~63;
+    const int top = (base + 64 < W->nthreads) ? base + 64 : W->nthreads;
+    int i = idx;
+    for (;;) {
+        i = (i + 1 == top) ? base : i + 1;
+        if (i == idx || !W->fibers[i].done) break;
+    }
+    Fiber* nx = &W->fibers[i];
+    if (nx == me) return;
+    cur = nx;
+    tdemu_switch(&me->sp, nx->sp);
+}
 static void fiber_entry() {
     (*W->body)();
     Fiber* me = cur;
@@ -119,7 +135,7 @@ void syncthreads() {
 static void wave_barrier(WaveCtx& w) {
     const unsigned g = w.gen;
     if (++w.count == 64) { w.count = 0; w.gen++; return; }
-    while (w.gen == g) yield();
+    while (w.gen == g) yield_in_wave();
 }
 f32x16 mfma32(float a, float b, f32x16 c) {
     Fiber* f = cur;

@@ -69,10 +69,12 @@ def test_two_ranks_one_stream_bit_identical(name, T):
     from oracle import tdnet_ref                                   # the checker: the reference's op graph on the CPU
     import test_gpu_model as tm
     oracle = tdnet_ref.TDNetRef(spec, weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0))
+    hist = np.zeros((19, 19), np.int64)
     with torch.no_grad():
         for t, x in enumerate(weights.synth_video(H, W, T, seed=9)):
             got = res[t % 2][t]
             exp = oracle.forward(torch.from_numpy(x), t % spec.path_num).numpy()
-            tm.check_frame(got, exp, ("path-parallel x2", name, t))             # two ranks vs the oracle
+            tm.check_frame(got, exp, ("path-parallel x2", name, t), hist)       # two ranks vs the oracle
             ref = m(torch.from_numpy(x).to(dev), pos_id=t % spec.path_num).cpu().numpy()
             assert np.array_equal(got, ref), (t, float(np.abs(got - ref).max()))   # and bit-identical to one handle
+    assert tm.clip_miou(hist) >= 0.9995
