@@ -859,9 +859,9 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
     if (n->P == 4) {
         const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
         TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c)) return -1;   // v2 + V[1]
+        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention != 0)) return -1;   // v2 + V[1]
         TD_TRY(run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c)) return -1;   // v3 + V[2]
+        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention != 0)) return -1;   // v3 + V[2]
         TD_TRY(run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c));                                              // (v3 + V[2]) W^T
     } else {
         TD_TRY(run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c));

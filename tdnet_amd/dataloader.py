@@ -1,8 +1,12 @@
 """Frame loader with the reference's API (Testing/dataloader.py:44-88): cityscapesLoader(img_path, in_size),
 .load_frames(), .data = [[img[1,3,H,W] fp32, img_name, folder, (W,H)], ...], .decode_segmap(labels).
 
-imageio / cv2 are not in this image; PNGs are read and resized (bilinear) with PIL.  Pixel-exact cv2.resize parity is
-not required for the measured path (synthetic tensors); normalisation follows dataloader.py:66-67 in float64.
+imageio / cv2 are not in this image.  PNGs are read with PIL; the resize is `resize_linear_u8`, a restatement of what
+`cv2.resize(img, (W, H))` (dataloader.py:64: default INTER_LINEAR on a uint8 image) computes: half-pixel centres, NO antialiasing on
+downscale (PIL's BILINEAR widens its support when shrinking, so it is not a stand-in), and OpenCV's 11-bit fixed-point arithmetic, so
+the uint8 result is meant to be the one OpenCV's generic path produces.  cv2 itself is absent here, so the function is pinned by
+hand-derived known answers, by the float bilinear formula to within one grey level and by the 2x-downscale = 2x2 box-average
+identity (tests/test_dataloader.py), not by a cv2-generated fixture.  Normalisation follows dataloader.py:66-67 in float64.
 """
 import os
 
@@ -13,6 +17,41 @@ import torch
 def recursive_glob(rootdir=".", suffix=""):
     return [os.path.join(looproot, filename) for looproot, _, filenames in os.walk(rootdir)
             for filename in filenames if filename.endswith(suffix)]
+
+
+def _linear_coeffs(n_src, n_dst):
+    """Source index and the two 11-bit weights per destination index, as OpenCV's resize builds them for INTER_LINEAR:
+    fx = (float)((d + 0.5) * scale - 0.5), s = floor(fx), fx -= s, clamped at both borders; weights = round((1 - fx, fx) * 2048)."""
+    scale = float(n_src) / float(n_dst)
+    d = np.arange(n_dst, dtype=np.float64)
+    fx = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(fx).astype(np.int64)
+    fx = (fx - s.astype(np.float32)).astype(np.float32)
+    low = s < 0
+    fx[low] = 0.0; s[low] = 0
+    high = s >= n_src - 1
+    fx[high] = 0.0; s[high] = n_src - 1
+    w1 = np.rint(fx * np.float32(2048.0)).astype(np.int64)
+    w0 = np.rint((np.float32(1.0) - fx) * np.float32(2048.0)).astype(np.int64)
+    return s, np.minimum(s + 1, n_src - 1), w0, w1
+
+
+def resize_linear_u8(img, size):
+    """uint8 [H,W,C] -> uint8 [size[1], size[0], C]; size = (W, H) like cv2.resize's dsize (dataloader.py:52,64).
+    Horizontal pass in int32 (pixel * 2048-scale weights), vertical pass with OpenCV's shifts:
+        dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3
+    Wd, Hd = int(size[0]), int(size[1])
+    Hs, Ws = img.shape[:2]
+    if (Hs, Ws) == (Hd, Wd):
+        return img.copy()
+    x0, x1, a0, a1 = _linear_coeffs(Ws, Wd)
+    y0, y1, b0, b1 = _linear_coeffs(Hs, Hd)
+    src = img.astype(np.int64)
+    rows = src[:, x0, :] * a0[None, :, None] + src[:, x1, :] * a1[None, :, None]          # [Hs, Wd, C], <= 255 * 2048
+    out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
 
 
 class cityscapesLoader():
@@ -44,8 +83,8 @@ class cityscapesLoader():
             path = path.rstrip()
             img_name = path.split('/')[-1]
             folder = path.split('/')[-2]
-            im = Image.open(path).convert("RGB").resize(self.size, Image.BILINEAR)
-            self.data.append([self.normalise(np.asarray(im)), img_name, folder, self.size])
+            im = resize_linear_u8(np.asarray(Image.open(path).convert("RGB")), self.size)      # = cv2.resize(img, self.size), dataloader.py:64
+            self.data.append([self.normalise(im), img_name, folder, self.size])
 
     def decode_segmap(self, temp):
         rgb = np.zeros((temp.shape[0], temp.shape[1], 3))
