@@ -78,12 +78,14 @@ def model_spec(name, nclass=19, backbone=None):
     """name: 'td4' (td4_psp18.py) or 'td2' (td2_psp50.py with a BasicBlock backbone)."""
     if name == "td4":
         bb = backbone or "resnet18"
-        if is_bottleneck(bb):
-            raise ValueError("td4 with a Bottleneck backbone is not a shipped configuration (td4_psp18.py:85-88 would need d_v = 2048)")
-        # td4_psp18.py:80-83 -> PyramidPooling(path_num=path_num//2, pid=0,1,0,1); :85-88 d_v = 512
+        if bb == "resnet101":
+            raise ValueError("td4 accepts resnet18 / resnet34 / resnet50 (td4_psp18.py:52)")
+        e = expansion(bb)
+        # td4_psp18.py:80-83 -> PyramidPooling(512*expansion, path_num=path_num//2, pid=0,1,0,1); :85-88 Encoding(512e, 64, 512e): d_v =
+        # d_model = 512 (BasicBlock) or 2048 (resnet50, constructible but never shipped); :112-115 FCNHead(512e, chn_down=4)
         atn = {0: ("atn1_2", "atn1_3", "atn1_4"), 1: ("atn2_3", "atn2_4", "atn2_1"),
                2: ("atn3_4", "atn3_1", "atn3_2"), 3: ("atn4_1", "atn4_2", "atn4_3")}
-        return ModelSpec("td4", 4, bb, 512, 64, 512, 2, (0, 1, 0, 1), 512 // 4, nclass, 3, atn)
+        return ModelSpec("td4", 4, bb, 512 * e, 64, 512 * e, 2, (0, 1, 0, 1), 512 * e // 4, nclass, 3, atn)
     if name == "td2":
         bb = backbone or "resnet18"
         e = expansion(bb)

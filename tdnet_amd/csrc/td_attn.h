@@ -43,6 +43,10 @@ struct AttnArgs {
     // = sum (x - mean)^2 over it -- the layout k_ln_finalize combines exactly (td_misc.h).  nullptr = off.
     float* ln_part;
     int ln_nstr;         // number of strips = gridDim.x * QW
+    // Row stride (floats) of vp / resid / out / ln_part.  A launch covers DV = 128 or 512 channels; a wider value matrix (td4 on a
+    // Bottleneck backbone: d_v = 2048) is served as chunks of 512 channels, each its own launch on pointers offset by the chunk's
+    // first channel and ldv = the full width (the scores are recomputed per chunk: 64 of 576 MACs per key).
+    int ldv;
 };
 
 template <int QW, int CW>
@@ -153,13 +157,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int cb = cw * (NT * 32) + l31 * NT;                     // this lane's first output channel
     const float* vbase = p.vp + cb;
     // V' rows of k-group G of the super-tile starting at kbase: 4 keys per lane-half, one float4 (4 channels) each
-    const TdBuf vbuf = td_make_buf(p.vp, (unsigned)p.Lk * (unsigned)DV * 4u);
-    const unsigned v_voff = (4u * (unsigned)half * (unsigned)DV + (unsigned)cb) * 4u;
+    const unsigned LDV = (unsigned)p.ldv;
+    const TdBuf vbuf = td_make_buf(p.vp, ((unsigned)(p.Lk - 1) * LDV + (unsigned)DV) * 4u);
+    const unsigned v_voff = (4u * (unsigned)half * LDV + (unsigned)cb) * 4u;
     auto load_v = [&](int kbase, int G, f32x4 (&b)[4]) {
         if (kbase + SK <= p.Lk) {                                     // wave-uniform: the whole super-tile is inside V'
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const unsigned soff = (unsigned)(kbase + 8 * G + e) * (unsigned)DV * 4u;
+                const unsigned soff = (unsigned)(kbase + 8 * G + e) * LDV * 4u;
                 if (NT == 4) b[e] = td_buf_ld4(vbuf, v_voff, soff);
                 else {
                     const f32x2 v2 = td_buf_ld2(vbuf, v_voff, soff);
@@ -172,9 +177,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int key = (key0 + e < p.Lk) ? key0 + e : key_last;     // P is exactly 0 for masked keys
-            if (NT == 4) b[e] = td_ld4(vbase + (size_t)key * DV);
+            if (NT == 4) b[e] = td_ld4(vbase + (size_t)key * LDV);
             else {
-                const f32x2 v2 = *reinterpret_cast<const f32x2*>(vbase + (size_t)key * DV);
+                const f32x2 v2 = *reinterpret_cast<const f32x2*>(vbase + (size_t)key * LDV);
                 b[e][0] = v2[0]; b[e][1] = v2[1]; b[e][2] = 0.f; b[e][3] = 0.f;
             }
         }
@@ -286,7 +291,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         for (int j = 0; j < NT; ++j) kshift[j] = acc[j][0] * inv + bv[j];
         if (p.resid) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) kshift[j] += p.resid[(size_t)q0 * DV + cb + j];
+            for (int j = 0; j < NT; ++j) kshift[j] += p.resid[(size_t)q0 * LDV + cb + j];
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -303,7 +308,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
         const float inv = 1.0f / l;
-        const size_t off = (size_t)q * DV + cb;
+        const size_t off = (size_t)q * LDV + cb;
         if (NT == 4) {
             f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[NT - 2][r] * inv, acc[NT - 1][r] * inv};
             o = o + bv;
@@ -335,8 +340,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         }
         if (half == 0) {
             const int strip = blockIdx.x * QW + qw;
-            float* pm = p.ln_part + (size_t)strip * DV + cb;
-            float* pq = p.ln_part + ((size_t)p.ln_nstr + strip) * DV + cb;
+            float* pm = p.ln_part + (size_t)strip * LDV + cb;
+            float* pq = p.ln_part + ((size_t)p.ln_nstr + strip) * LDV + cb;
             if (NT == 4) { td_st4(pm, mean); td_st4(pq, m2); }
             else { pm[0] = mean[0]; pm[1] = mean[1]; pq[0] = m2[0]; pq[1] = m2[1]; }
         }
@@ -344,14 +349,22 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 }
 
 // query tiles (= LayerNorm strips) of a launch
-static inline int attn_strips(int Lq, int DV) { return DV == 512 ? (Lq + 31) / 32 : 2 * ((Lq + 63) / 64); }
+static inline int attn_strips(int Lq, int DV) { return DV % 512 == 0 ? (Lq + 31) / 32 : 2 * ((Lq + 63) / 64); }
 
 static inline int attn_launch(AttnArgs a, int DV, bool online, hipStream_t s) {
-    if (DV == 512) {
+    a.ldv = DV;
+    if (DV >= 512 && DV % 512 == 0) {
         const int grid = (a.Lq + 31) / 32;
         a.ln_nstr = grid;
-        if (online) TD_LAUNCH((k_attention<1, 4, 4, true>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
-        else TD_LAUNCH((k_attention<1, 4, 4, false>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+        for (int c0 = 0; c0 < DV; c0 += 512) {                         // one launch per 512 channels (DV = 512: a single one)
+            AttnArgs b = a;
+            b.vp += c0; b.out += c0;
+            if (b.bias) b.bias += c0;
+            if (b.resid) b.resid += c0;
+            if (b.ln_part) b.ln_part += c0;
+            if (online) TD_LAUNCH((k_attention<1, 4, 4, true>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
+            else TD_LAUNCH((k_attention<1, 4, 4, false>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
+        }
     } else if (DV == 128) {
         // two query tiles x two channel halves: 2 waves per SIMD at Lq = 32768 (<4,1,4> -- four tiles, all channels -- runs one)
         const int grid = (a.Lq + 63) / 64;

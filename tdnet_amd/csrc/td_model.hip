@@ -367,8 +367,6 @@ extern "C" int tdnet_create_opts(const tdnet_cfg* cfg, const tdnet_opts* opts, t
         return td_fail("tdnet_create: model must be 4 (td4), 2 (td2) or 1 (single-frame PSPNet), got %d", cfg->model);
     if (cfg->backbone != 18 && cfg->backbone != 34 && cfg->backbone != 50 && cfg->backbone != 101)
         return td_fail("tdnet_create: backbone must be 18, 34, 50 or 101, got %d", cfg->backbone);
-    if (cfg->backbone == 50 && cfg->model == 4)
-        return td_fail("tdnet_create: the Bottleneck backbone is only shipped with td2 (td2_psp50.py); td4 would need d_v = 2048");
     if ((cfg->backbone == 101) != (cfg->model == 1) && !(cfg->model == 1 && cfg->backbone == 50))
         return td_fail("tdnet_create: resnet101 is the PSPNet baseline's backbone (pspnet.py:36); psp accepts 50 or 101");
     if (cfg->nclass < 1 || cfg->nclass > 32) return td_fail("tdnet_create: nclass must be in 1..32");
@@ -386,7 +384,7 @@ extern "C" int tdnet_create_opts(const tdnet_cfg* cfg, const tdnet_opts* opts, t
     n->deep = cfg->backbone >= 50;
     n->C = 512 * exp;
     n->SC = n->deep ? 128 : 64;
-    n->DV = cfg->model == 4 ? 512 : 128 * exp;                         // td4_psp18.py:85 / td2_psp50.py:79 (512*exp//4)
+    n->DV = cfg->model == 4 ? 512 * exp : 128 * exp;                   // td4_psp18.py:85 (512*expansion) / td2_psp50.py:79 (512*exp//4)
     n->MID = cfg->model == 4 ? n->DV / 4 : n->DV / 2;                  // FCNHead chn_down 4 / 2
     if (cfg->model == 1) { n->DV = 2 * n->C; n->MID = n->C / 4; }      // PSPHead: conv3x3 on the 2C-channel concat -> C/4 (pspnet.py:105-109)
     n->FIFO = cfg->model == 4 ? 3 : cfg->model == 2 ? 1 : 0;
@@ -756,7 +754,7 @@ static int run_attention(tdnet* n, const float* q, const float* k, const float* 
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
     const int rc = attn_launch(a, DV, online, s);
     prof_end(n, s);
-    if (rc) return td_fail("attention: unsupported d_v=%d (128 or 512)", DV);
+    if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);
     return 0;
 }
 
@@ -765,14 +763,14 @@ static int run_attention(tdnet* n, const float* q, const float* k, const float* 
 // head's Winograd input transform applies it on the fly, run_conv's LnFuse).
 static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* g, const float* b, float* part, float* mean,
                           float* rstd, float* y, hipStream_t s, int stats_nstr = 0) {
-    const int CV = C / 4, rows = 256 / CV;
+    const int CV = C / 4, threads = CV > 256 ? CV : 256, rows = threads / CV;                   // C = 2048 (td4 on ResNet-50): 512 threads, one row each
     int nstr = stats_nstr, per = 32;
     prof_begin(n, 2, false, 0, s);
     if (!stats_nstr) {
         nstr = (HW + rows - 1) / rows;
         if (nstr > 512) nstr = 512;
         per = (HW + nstr - 1) / nstr;                                                           // k_ln_stats' strip length
-        TD_LAUNCH(k_ln_stats, dim3(nstr), dim3(256), (rows + 1) * C * 4, s, x, part, HW, C);    // part: [2][nstr][C]
+        TD_LAUNCH(k_ln_stats, dim3(nstr), dim3(threads), (rows + 1) * C * 4, s, x, part, HW, C);   // part: [2][nstr][C]
     }
     TD_LAUNCH(k_ln_finalize, dim3((C + 3) / 4), dim3(256), (256 + 32 + 4) * 4, s, (const float*)part, nstr, per, HW, C, 1e-5f, mean, rstd);
     if (y) TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
@@ -1285,7 +1283,7 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     return 0;
 }
 extern "C" int tdnet_op_layernorm_hw(const float* x, int HW, int C, const float* g, const float* b, float* out, void* stream) {
-    if (C % 4 || 256 % (C / 4)) return td_fail("tdnet_op_layernorm_hw: C must be one of 4*{1,2,4,...,256}");
+    if (C % 4 || (C / 4 <= 256 ? 256 % (C / 4) != 0 : C / 4 > 512)) return td_fail("tdnet_op_layernorm_hw: C must be one of 4*{1,2,4,...,256} or 2048");
     float *part = nullptr, *mean = nullptr, *rstd = nullptr;
     if (dev_alloc(&part, (size_t)2 * 512 * C) || dev_alloc(&mean, C) || dev_alloc(&rstd, C)) return -1;
     run_layernorm(nullptr, x, HW, C, g, b, part, mean, rstd, out, (hipStream_t)stream);

@@ -9,7 +9,8 @@ Differences from the reference, on purpose:
   * a missing checkpoint file is an ERROR unless `synthetic_seed` is given (the reference prints and silently keeps
     random init, td4_psp18.py:239-240);
   * `reset()` empties the K/Q/V FIFO so a second clip can be fed (the reference has no reset);
-  * td4 with a ResNet-50 backbone (never shipped by the reference) -> NotImplementedError.
+  * td4 accepts all three backbones the reference's constructor accepts (td4_psp18.py:52-66), including the never-shipped
+    resnet50 (d_model = d_v = 2048): its attention runs as four 512-channel launches.
 """
 import os
 
@@ -33,8 +34,6 @@ class _TDNetBase(nn.Module):
         super().__init__()
         assert backbone == "resnet50" or backbone == "resnet34" or backbone == "resnet18"
         assert path_num == self._model_id
-        if backbone == "resnet50" and self._model_id != 2:
-            raise NotImplementedError("the Bottleneck backbone is shipped with td2 only (td2_psp50.py); td4+resnet50 would need d_v = 2048")
         if not (dilated and multi_grid):
             raise NotImplementedError("only the dilated, multi-grid backbone the reference ships is implemented")
         self.psp_path = model_path

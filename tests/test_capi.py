@@ -33,7 +33,7 @@ def test_product_fails_loudly_without_library(tmp_path):
 
 def test_create_rejects_bad_configs():
     lib = emu_util.emu_lib()
-    for cfg in [(3, 18, 19, 65, 65), (4, 50, 19, 65, 65), (4, 18, 0, 65, 65), (4, 18, 19, 4, 65)]:
+    for cfg in [(3, 18, 19, 65, 65), (4, 101, 19, 65, 65), (2, 101, 19, 65, 65), (1, 18, 19, 65, 65), (4, 18, 0, 65, 65), (4, 18, 19, 4, 65)]:
         with pytest.raises(_capi.TdnetError):
             Engine(*cfg, 0, lib=lib)
 

@@ -51,7 +51,7 @@ def clip_miou(hist):
 
 @pytest.mark.parametrize("name,bb,H,W", [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet34", 33, 65),
                                          ("td4", "resnet18", 65, 129), ("td2", "resnet18", 49, 81), ("td2", "resnet50", 33, 65),
-                                         ("td4", "resnet34", 33, 65)])
+                                         ("td4", "resnet34", 33, 65), ("td4", "resnet50", 33, 65)])
 def test_against_reference_goldens(golden_dir, name, bb, H, W):
     g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
     T = 1 + max(int(k.split("_")[0][1:]) for k in g.files if k.startswith("f"))
@@ -117,6 +117,10 @@ def test_vs_oracle_c1_512x1024():
 
 def test_vs_oracle_c2_td2_psp18_1024x2048():
     _vs_oracle("td2", "resnet18", 1024, 2048, 4)           # BASELINE.json configs[1]: warm-up frame + both paths in steady state (d_v = 128 attention at 32768 x 2048)
+
+
+def test_vs_oracle_td4_resnet50():
+    _vs_oracle("td4", "resnet50", 129, 257, 6)             # the third backbone td4_psp18.py:52-66 accepts (d_model = d_v = 2048): attention as four 512-channel launches
 
 
 def test_vs_oracle_td4_resnet34():

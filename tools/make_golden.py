@@ -125,7 +125,11 @@ def main():
     cases = [("td4", "resnet18", 33, 65, 11, True), ("td2", "resnet18", 33, 65, 5, True),
              ("td2", "resnet34", 33, 65, 5, False), ("td4", "resnet18", 65, 129, 11, False),
              ("td2", "resnet18", 49, 81, 5, False), ("td2", "resnet50", 33, 65, 5, True),
-             ("td4", "resnet34", 33, 65, 11, False)]            # td4_psp18.py:52-66 accepts resnet34 too
+             ("td4", "resnet34", 33, 65, 11, False),            # td4_psp18.py:52-66 accepts resnet34 too
+             ("td4", "resnet50", 33, 65, 7, False)]             # ... and resnet50 (d_model = d_v = 2048; constructible, never shipped)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]       # e.g. `make_golden.py td4_resnet50_33x65`: just those small cases
+    if only:
+        cases = [c for c in cases if "%s_%s_%dx%d" % c[:4] in only]
     for name, bb, H, W, T, full in cases:
         spec, m = build_reference(name, bb, H, W, seed=0)
         frames = weights.synth_video(H, W, T, seed=1)
@@ -140,6 +144,8 @@ def main():
         np.savez_compressed(fn, __meta__=np.array(meta), **arrs)
         print("wrote", fn, "%.1f MB" % (os.path.getsize(fn) / 1e6))
 
+    if only:
+        return
     # ---- full-size digests (statistics + strided samples only) --------------------------------------------
     digests = {}
     # per-frame digests (tag_f<t>_*) from the first steady-state frame on, so that every path's steady-state wiring is pinned at
