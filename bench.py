@@ -290,7 +290,7 @@ def main():
     res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
            "value": None if args.dry_run else round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": nwarm,
            "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.precision == "fp32" else "f16 (fp16 MFMA operands, fp32 accumulate)",
+           "dtype": "f32" if args.precision == "fp32" else "f16 (fp16 MFMA convs + attention, fp16 activation maps in the backbone, fp32 accumulate / softmax / LayerNorm)",
            "data": "synthetic",
            "world_size_seen": world_seen, "backend": backend, "rccl_bcast_ms": round(bcast_ms, 3),
            "bcast_bytes": 4 * nparam if world > 1 else 0, "per_rank_fps": [round(v, 3) for v in per_rank],
@@ -330,7 +330,7 @@ def main():
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             if opts["precision"]:
-                kname, dom_regex = "k_conv_igemm_h<128,128,2,2,3> (3x3 dilated conv, fp16 MFMA, fp32 accumulate)", r"k_conv_igemm_h<128, 128, 2, 2, 3"
+                kname, dom_regex = "k_conv_igemm_h<128,128,2,2,3,IN16,OUT16> (3x3 dilated conv, fp16 MFMA, fp16 maps in HBM, fp32 accumulate)", r"k_conv_igemm_h<128, 128, 2, 2, 3"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:

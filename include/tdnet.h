@@ -141,11 +141,16 @@ int tdnet_op_conv2d(const float* in_dev, int H, int W, int Cin, const float* w_h
                     const tdnet_opts* opts /* NULL = defaults */,
                     int tile /* -1 = heuristic; 0: 128x128, 1: 64x128, 2: 128x64, 3..5: the same on the two-stage pipeline */,
                     float* out_dev, void* stream);
+/* the same conv with the fp16 activation STORAGE of tdnet_opts.precision = 1: in / resid are rounded to fp16 maps in HBM, the kernel
+ * reads and writes fp16 (fp16 MFMA, fp32 accumulate), the fp16 result is widened into out_dev.  Cin % 64 == 0.                    */
+int tdnet_op_conv2d_f16io(const float* in_dev, int H, int W, int Cin, const float* w_host, const float* bias_host,
+                          int Cout, int KS, int stride, int dil, const float* resid_dev, int act, int tile, float* out_dev, void* stream);
 /* stem: NCHW image [3,H,W] -> conv7x7 s2 p3 (+bias) -> ReLU -> maxpool3x3 s2 p1 -> NHWC [H2,W2,64] (resnet.py:205-208) */
 int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const float* bias_host,
                   const tdnet_opts* opts /* NULL = defaults */, float* out_dev, void* stream);
 /* softmax(q k^T / sqrt(dk)) v' + bias + resid: q [Lq,64], k [Lk,64], vp [Lk,DV], bias dev [DV]|NULL, resid [Lq,DV]|NULL.
- * online: 0 = exact two-pass softmax, 1 = single pass with a lazily moved reference (tdnet_opts.attention).
+ * online: 0 = exact two-pass softmax, 1 = single pass with a lazily moved reference (tdnet_opts.attention), 2 = the fp16-MFMA
+ * kernel of tdnet_opts.precision = 1 (single pass; operands and P rounded to fp16, softmax and accumulation fp32).
  * ln_out != NULL: also the plane LayerNorm (affine ln_g, ln_b [Lq]) of the result, from the strip statistics the kernel's epilogue
  * writes (tdnet_opts.fusion bit 2) -> ln_out [Lq,DV].                                                                          */
 int tdnet_op_attention(const float* q_dev, const float* k_dev, const float* vp_dev, const float* bias_dev,

@@ -68,6 +68,9 @@ SYMBOLS = {
     "tdnet_op_conv2d": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, c_opts_p, ctypes.c_int,
                                        c_void_p, c_void_p]),
+    "tdnet_op_conv2d_f16io": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int,
+                                             c_void_p, c_void_p]),
     "tdnet_op_stem": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_opts_p, c_void_p, c_void_p]),
     "tdnet_op_attention": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

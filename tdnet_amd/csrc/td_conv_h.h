@@ -1,6 +1,11 @@
 // td_conv_h.h -- the same NHWC implicit-GEMM convolution on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate):
-// the "fp16 MFMA" mode of BASELINE.json config 5.  Activations stay fp32 in HBM (every other kernel is unchanged); the
-// gather converts them to fp16 (round-to-nearest-even) on the way into LDS, weights are packed as fp16 on the host.
+// the "fp16 MFMA" mode of BASELINE.json config 5.  Weights are packed as fp16 on the host.  Activations (template IN16 / OUT16):
+//   IN16 = false: the input map is fp32 in HBM; the gather converts it to fp16 (round-to-nearest-even) on the way into LDS;
+//   IN16 = true : the input map (and the residual) is fp16 NHWC in HBM -- half the gather bytes, one 16-byte load per LDS slot, no
+//                 converts in the loop;
+//   OUT16       : the epilogue rounds act(acc + bias + resid) to fp16 and stores 8 bytes per lane instead of 16.
+// Inside the backbone every map between two convs is fp16 (IN16 = OUT16 = true); the convs at its rim read or write fp32 (the stem's
+// output, c4 for the pyramid / Encoding / head, which keep fp32 storage).
 //
 // Per K step (BK = 64 channels of one tap) a 128x128 block issues 64 MFMAs of 32 cycles each instead of 256 of 64 cycles:
 // 16x the matrix rate, so the kernel lives or dies by how little else it does per step -- one ds_read_b128 per operand per
@@ -31,8 +36,80 @@ TD_DEV f16x8 td_cvt8(f32x4 lo, f32x4 hi) {
     return r;
 }
 
-// ConvArgs as td_conv.h, except: wp = packed fp16 weights [nsteps][8][CoutPad][8 halfs], nsteps = (Cin/64)*KS*KS.
-template <int BM, int BN, int WGM, int WGN, int KS>
+// Epilogue of the fp16-MFMA kernels: out[m][n] = act(acc + bias[n] (+ resid[m][n])), resid fp16 when RES16, out fp16 when OUT16.
+// Same lane-pair exchange as td_store_acc (NT == 2): a lane ends up with 4 consecutive channels of one row.
+template <int MT, int NT, bool OUT16, bool RES16>
+TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float* bias, const void* residv, int M, int N, int act,
+                           int m_base, int n_base, int lane) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int half = lane >> 5, l31 = lane & 31;
+    auto activate = [&](float v) { return act == 1 ? (v > 0.f ? v : 0.f) : act == 2 ? (v > 0.f ? v : 0.01f * v) : v; };
+    float* outf = reinterpret_cast<float*>(outv);
+    _Float16* outh = reinterpret_cast<_Float16*>(outv);
+    const float* resf = reinterpret_cast<const float*>(residv);
+    const _Float16* resh = reinterpret_cast<const _Float16*>(residv);
+    if (NT == 2 && (N & 3) == 0 && ((((size_t)outv) | ((size_t)residv)) & 15) == 0) {       // wave-uniform
+        const int odd = l31 & 1;
+        const int chan = n_base + 4 * (l31 >> 1);
+        const bool cok = chan < N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (cok) { bv[0] = bias[chan]; bv[1] = bias[chan + 1]; bv[2] = bias[chan + 2]; bv[3] = bias[chan + 3]; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int r = 2 * rp;
+                const float a0 = acc[i][0][r], a1 = acc[i][NT - 1][r], c0 = acc[i][0][r + 1], c1 = acc[i][NT - 1][r + 1];
+                const float x = td_swap1(odd ? a0 : c0), y = td_swap1(odd ? a1 : c1);
+                f32x4 v;
+                if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
+                else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
+                const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
+                if (m >= M || !cok) continue;
+                const size_t o = (size_t)m * N + chan;
+                v = v + bv;
+                if (residv) {
+                    if (RES16) {
+                        const f16x4 rh = *reinterpret_cast<const f16x4*>(resh + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rh[e];
+                    } else v = v + td_ld4(resf + o);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = activate(v[e]);
+                if (OUT16) {
+                    f16x4 oh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) oh[e] = (_Float16)v[e];
+                    *reinterpret_cast<f16x4*>(outh + o) = oh;
+                } else td_st4(outf + o, v);
+            }
+        }
+        return;
+    }
+    const int nb = n_base + l31 * NT;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= M) continue;
+            const size_t o = (size_t)m * N + nb;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (nb + j >= N) continue;
+                float v = acc[i][j][r] + bias[nb + j];
+                if (residv) v += RES16 ? (float)resh[o + j] : resf[o + j];
+                v = activate(v);
+                if (OUT16) outh[o + j] = (_Float16)v; else outf[o + j] = v;
+            }
+        }
+    }
+}
+
+// ConvArgs as td_conv.h, except: wp = packed fp16 weights [nsteps][8][CoutPad][8 halfs], nsteps = (Cin/64)*KS*KS; with IN16 `in` and
+// `resid` point at fp16 maps, with OUT16 `out` does.
+template <int BM, int BN, int WGM, int WGN, int KS, bool IN16, bool OUT16>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
@@ -40,6 +117,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     static_assert((AL == 2 || AL == 4) && (BL == 2 || BL == 4), "staging slots are spread over the 4 k-groups");
     using L = ConvLdsH<BM, BN>;
     constexpr int NTAPS = KS * KS;
+    constexpr int AR = IN16 ? AL : 2 * AL;              // staging registers (16 bytes each) per A tile
+    constexpr unsigned EB = IN16 ? 2u : 4u;             // bytes per input element
     TD_DYN_LDS(smem);
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
 
@@ -61,9 +140,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         const int oy = m / p.Wo, ox = m - oy * p.Wo;
         a_by[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 28);
         a_bx[i] = ox * p.stride - p.pad;
-        a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (unsigned)a_kq * 8u) * 4u;
+        a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (unsigned)a_kq * 8u) * EB;
     }
-    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 4u);
+    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * EB);
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
     unsigned b_off[BL];
 #pragma unroll
@@ -74,17 +153,20 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
 
     int l_step = 0, l_chunk = 0, l_tap = 0;
-    auto load_tile = [&](f32x4 (&ra)[2 * AL], f32x4 (&rb)[BL]) {
+    auto load_tile = [&](f32x4 (&ra)[AR], f32x4 (&rb)[BL]) {
         const int ky = l_tap / KS;
         const int dy = ky * p.dil, dx = (l_tap - ky * KS) * p.dil;
-        const unsigned delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * 4u;
+        const unsigned delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * EB;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const unsigned off = ok ? a_off[i] + delta : TD_BUF_OOB;
-            ra[2 * i] = td_buf_ld4(in_buf, off, 0u);
-            ra[2 * i + 1] = td_buf_ld4(in_buf, ok ? off + 16u : TD_BUF_OOB, 0u);
+            if constexpr (IN16) ra[i] = td_buf_ld4(in_buf, off, 0u);  // 8 fp16 channels = the LDS slot as it is
+            else {
+                ra[2 * i] = td_buf_ld4(in_buf, off, 0u);
+                ra[2 * i + 1] = td_buf_ld4(in_buf, ok ? off + 16u : TD_BUF_OOB, 0u);
+            }
         }
         const unsigned wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;
 #pragma unroll
@@ -92,8 +174,10 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         ++l_step;
         if (++l_tap == NTAPS) { l_tap = 0; ++l_chunk; }
     };
-    auto store_a = [&](int buf, int i, const f32x4 (&ra)[2 * AL]) {
-        td_st8h(lds + buf * L::BUF_HALFS + a_kq * L::A_STRIDE + (a_row + 32 * i) * 8, td_cvt8(ra[2 * i], ra[2 * i + 1]));
+    auto store_a = [&](int buf, int i, const f32x4 (&ra)[AR]) {
+        _Float16* dst = lds + buf * L::BUF_HALFS + a_kq * L::A_STRIDE + (a_row + 32 * i) * 8;
+        if constexpr (IN16) *reinterpret_cast<f32x4*>(dst) = ra[i];
+        else td_st8h(dst, td_cvt8(ra[2 * i], ra[2 * i + 1]));
     };
     auto store_b = [&](int buf, int i, const f32x4 (&rb)[BL]) {
         const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
@@ -109,7 +193,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // one K step = 4 MFMA k-steps of 16; k-step g uses LDS groups 2g (lanes 0-31) and 2g+1 (lanes 32-63)
-    auto compute = [&](int buf, const f32x4 (&sa)[2 * AL], const f32x4 (&sb)[BL]) {
+    auto compute = [&](int buf, const f32x4 (&sa)[AR], const f32x4 (&sb)[BL]) {
         const _Float16* As = lds + buf * L::BUF_HALFS + (wm * WM + l31) * 8;
         const _Float16* Bs = lds + buf * L::BUF_HALFS + L::A_HALFS + (wn * WN + l31) * 8;
         f16x8 af[2][MT], bf[2][NT];
@@ -137,7 +221,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     };
 
     // two-stage pipeline, branch free (see td_conv.h): tile s+2 in flight, tile s+1 written to LDS under the MFMAs of tile s
-    f32x4 ra[2 * AL], rb[BL], ra2[2 * AL], rb2[BL];
+    f32x4 ra[AR], rb[BL], ra2[AR], rb2[BL];
     load_tile(ra, rb);
 #pragma unroll
     for (int i = 0; i < AL; ++i) store_a(0, i, ra);
@@ -155,7 +239,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         __syncthreads();
     }
 
-    td_store_acc<MT, NT>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
+    td_store_acc_h<MT, NT, OUT16, IN16>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 static inline int conv_nsteps_h(int Cin, int KS) { return (Cin / 64) * KS * KS; }
@@ -181,17 +265,25 @@ static inline void conv_pack_weights_h(const float* w, int Cout, int Cin, int KS
             }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool IN16, bool OUT16>
 static inline void conv_launch_h_t(const ConvArgs& a, int KS, hipStream_t s) {
     const int grid = ((a.M + BM - 1) / BM) * a.tiles_n;
     const int lds = ConvLdsH<BM, BN>::BYTES;
-    if (KS == 3) TD_LAUNCH((k_conv_igemm_h<BM, BN, WGM, WGN, 3>), dim3(grid), dim3(256), lds, s, a);
-    else TD_LAUNCH((k_conv_igemm_h<BM, BN, WGM, WGN, 1>), dim3(grid), dim3(256), lds, s, a);
+    if (KS == 3) TD_LAUNCH((k_conv_igemm_h<BM, BN, WGM, WGN, 3, IN16, OUT16>), dim3(grid), dim3(256), lds, s, a);
+    else TD_LAUNCH((k_conv_igemm_h<BM, BN, WGM, WGN, 1, IN16, OUT16>), dim3(grid), dim3(256), lds, s, a);
 }
-static inline void conv_launch_h(ConvArgs a, ConvTile tile, int KS, hipStream_t s) {
+template <bool IN16, bool OUT16>
+static inline void conv_launch_h_io(const ConvArgs& a, const ConvTileDims& d, int KS, hipStream_t s) {
+    if (d.BM == 128 && d.BN == 128) conv_launch_h_t<128, 128, 2, 2, IN16, OUT16>(a, KS, s);
+    else if (d.BM == 64) conv_launch_h_t<64, 128, 2, 2, IN16, OUT16>(a, KS, s);
+    else conv_launch_h_t<128, 64, 4, 1, IN16, OUT16>(a, KS, s);
+}
+// in16 / out16: storage type of the input (+ residual) / output map (see the header comment)
+static inline void conv_launch_h(ConvArgs a, ConvTile tile, int KS, bool in16, bool out16, hipStream_t s) {
     const ConvTileDims d = conv_tile_dims(tile);
     a.tiles_n = a.CoutPad / d.BN;
-    if (d.BM == 128 && d.BN == 128) conv_launch_h_t<128, 128, 2, 2>(a, KS, s);
-    else if (d.BM == 64) conv_launch_h_t<64, 128, 2, 2>(a, KS, s);
-    else conv_launch_h_t<128, 64, 4, 1>(a, KS, s);
+    if (in16 && out16) conv_launch_h_io<true, true>(a, d, KS, s);
+    else if (in16) conv_launch_h_io<true, false>(a, d, KS, s);
+    else if (out16) conv_launch_h_io<false, true>(a, d, KS, s);
+    else conv_launch_h_io<false, false>(a, d, KS, s);
 }

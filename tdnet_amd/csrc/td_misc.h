@@ -57,6 +57,41 @@ TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ ou
     }
 }
 
+// the same for the fp16-activation mode (tdnet_opts.precision = 1): the pooled map is stored as fp16 (the first map of the fp16
+// backbone); the input is the stem's fp32 output (IN16 = false) or, behind the deep stem, already fp16 (IN16 = true)
+typedef _Float16 td_f16x4 __attribute__((ext_vector_type(4)));
+template <bool IN16>
+TD_KERNEL void k_maxpool3s2_h(const void* __restrict__ inv, _Float16* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
+    const int CV = C >> 2;
+    const long total = (long)Ho * Wo * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long pix = i / CV;
+        const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const size_t o = ((size_t)iy * W + ix) * C + cv * 4;
+                f32x4 v;
+                if (IN16) {
+                    const td_f16x4 h = *reinterpret_cast<const td_f16x4*>(reinterpret_cast<const _Float16*>(inv) + o);
+                    v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
+                } else v = td_ld4(reinterpret_cast<const float*>(inv) + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        td_f16x4 oh = {(_Float16)m[0], (_Float16)m[1], (_Float16)m[2], (_Float16)m[3]};
+        *reinterpret_cast<td_f16x4*>(out + (size_t)pix * C + cv * 4) = oh;
+    }
+}
+
 // the same, two horizontally adjacent outputs per thread: they share the middle input column, 15 loads for 2 outputs instead of 18
 TD_KERNEL void k_maxpool3s2_x2(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
     const int CV = C >> 2, Wp = (Wo + 1) >> 1;
@@ -437,6 +472,13 @@ TD_KERNEL void k_subsample(const float* __restrict__ in, float* __restrict__ out
         const int ox = (int)(pix % wo), oy = (int)(pix / wo);
         td_st4(out + (size_t)pix * C + cv * 4, td_ld4(in + ((size_t)(oy * stride) * w + ox * stride) * C + cv * 4));
     }
+}
+// fp32 <-> fp16 copies (test entry tdnet_op_conv2d_f16io only: the product path never converts whole maps)
+TD_KERNEL void k_f2h(const float* __restrict__ in, _Float16* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (_Float16)in[i];
+}
+TD_KERNEL void k_h2f(const _Float16* __restrict__ in, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
 }
 // NHWC [HW][C] -> planar [C][HW] into HOST-layout staging (used only by tdnet_get_stage)
 TD_KERNEL void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, long HW, int C) {

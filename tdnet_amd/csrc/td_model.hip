@@ -13,6 +13,7 @@
 #include "td_wino.h"
 #include "td_gemm.h"
 #include "td_attn.h"
+#include "td_attn_h.h"
 #include "td_misc.h"
 
 #include <cmath>
@@ -112,6 +113,7 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
+    bool in16 = false, out16 = false;                                  // h16 only: the input (+ residual) / output map is stored as fp16 in HBM
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
     int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3)): d_wp = (m+2)^2 packed 1x1 weight sets (td_wino.h)
@@ -265,6 +267,9 @@ struct tdnet {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;                 // Encoding's q / k projections beside w_vs (fusion bit 1)
+    float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
+    bool act16 = false;                                               // precision = 1: the maps between the backbone's convs are fp16 in HBM
+    _Float16* vt16 = nullptr;                                         // fp16 attention: V' transposed [DV][LkPad]
     bool ln_pending = false;                                          // the `ln` map of the last frame was not materialised (fusion bit 4)
     int ln_path = 0;
     bool failed = false;                                              // a launch helper reported an error during the current forward
@@ -417,6 +422,7 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
         if (q) hipFree(q);
     for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
     for (auto& r : n->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    if (n->vt16) hipFree(n->vt16);
     if (n->side) hipStreamDestroy(n->side);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ev_join) hipEventDestroy(n->ev_join);
@@ -520,6 +526,8 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
     if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
+    if (n->opts.precision && hipMalloc((void**)&n->vt16, (size_t)n->DV * attn_lkpad((int)lk) * sizeof(_Float16)) != hipSuccess)
+        return td_fail("hipMalloc failed for the fp16 attention workspace");
     n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -644,6 +652,31 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         if (upload(&L.d_cls_w, T(n, hp + ".4.weight")) || upload(&L.d_cls_b, T(n, hp + ".4.bias"))) return -1;
         (void)NC;
     }
+    // precision = 1: every map between two convs of the backbone is stored as fp16 (half the conv input / output bytes; td_conv_h.h).
+    // The rim stays fp32: the stem conv's output (fp32 kernel), and c4 -- the LAST conv of the backbone writes fp32 for the pyramid,
+    // Encoding and head kernels, which keep fp32 storage.
+    n->act16 = n->opts.precision != 0;
+    if (n->act16)
+        for (auto& L : n->paths) {
+            bool all16 = true;
+            for (auto& B : L.blocks) all16 = all16 && B.c1.h16 && B.c2.h16 && (!B.bott || B.c3.h16) && (!B.has_ds || B.ds.h16);
+            if (n->deep) all16 = all16 && L.stem2.h16 && L.stem3.h16;
+            all16 = all16 && !L.blocks.empty() && !L.blocks.back().has_ds;
+            if (!all16) { n->act16 = false; break; }
+        }
+    if (n->act16)
+        for (auto& L : n->paths) {
+            if (n->deep) { L.stem2.out16 = true; L.stem3.in16 = L.stem3.out16 = true; }
+            for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
+                BlockLayers& B = L.blocks[bi];
+                const bool last = bi + 1 == L.blocks.size();
+                B.c1.in16 = B.c1.out16 = true;
+                B.c2.in16 = true;
+                if (B.bott) { B.c2.out16 = true; B.c3.in16 = true; B.c3.out16 = !last; }
+                else B.c2.out16 = !last;
+                if (B.has_ds) B.ds.in16 = B.ds.out16 = true;
+            }
+        }
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
     TD_HIP(hipDeviceSynchronize());
@@ -731,7 +764,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
-    if (L.h16) conv_launch_h(a, L.tile, L.KS, s);
+    if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
@@ -746,13 +779,15 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
 
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
-                         int Lq, int Lk, int DV, float* out, hipStream_t s, bool online = false, float* ln_part = nullptr) {
+                         int Lq, int Lk, int DV, float* out, hipStream_t s, bool online = false, float* ln_part = nullptr,
+                         _Float16* vt16 = nullptr) {
+    if (n && n->vt16) vt16 = n->vt16;
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
     a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
     a.ln_part = ln_part; a.ln_nstr = 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = attn_launch(a, DV, online, s);
+    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);
     return 0;
@@ -804,7 +839,10 @@ static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, 
 static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* out, hipStream_t s, int fusion) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     prof_begin(n, 2, false, 0, s);
-    if (fusion & 16)
+    if (fusion & (32 | 64)) {                                          // internal: fp16 backbone (32: fp32 in, 64: fp16 in) -> fp16 out
+        if (fusion & 64) TD_LAUNCH((k_maxpool3s2_h<true>), dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, (const void*)in, (_Float16*)out, H, W, C, Ho, Wo);
+        else TD_LAUNCH((k_maxpool3s2_h<false>), dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, (const void*)in, (_Float16*)out, H, W, C, Ho, Wo);
+    } else if (fusion & 16)
         TD_LAUNCH(k_maxpool3s2_x2, dim3(td_grid_for((long)Ho * ((Wo + 1) / 2) * (C / 4), 256, 256 * 16)), dim3(256), 0, s, in, out, H, W, C, Ho, Wo);
     else
     TD_LAUNCH(k_maxpool3s2, dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, in, out, H, W, C, Ho, Wo);
@@ -879,25 +917,28 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     } else {
         TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s));
     }
-    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->opts.fusion);
+    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->act16 ? (n->deep ? 64 : 32) : (n->opts.fusion & 16));
     int ch = n->H2, cw = n->W2;
     for (auto& B : L.blocks) {
         int oh, ow;
+        // fp16-activation mode: the LAST conv of the backbone writes fp32 while its residual is an fp16 map -- not in place (4-byte
+        // stores over 2-byte elements other lanes still have to read): it goes to br, free here (the last block has no downsample)
+        const bool last16 = n->act16 && &B == &L.blocks.back();
         if (B.bott) {                                                  // resnet.py:91-111
             TD_TRY(run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s));                        // 1x1, input resolution
             TD_TRY(run_conv(n, B.c2, n->bt, ch, cw, nullptr, n->bu, s, &oh, &ow));              // 3x3 (stride, dilation)
             const float* res = n->bx;
             if (B.has_ds) { TD_TRY(run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s)); res = n->br; }
-            TD_TRY(run_conv(n, B.c3, n->bu, oh, ow, res, n->bx, s));                            // 1x1 x4 + residual + ReLU (in place when res == bx)
+            TD_TRY(run_conv(n, B.c3, n->bu, oh, ow, res, last16 ? n->br : n->bx, s));         // 1x1 x4 + residual + ReLU (in place when res == bx)
         } else {
             TD_TRY(run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow));
             const float* res = n->bx;
             if (B.has_ds) { TD_TRY(run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s)); res = n->br; }
-            TD_TRY(run_conv(n, B.c2, n->bt, oh, ow, res, n->bx, s));            // in-place on bx when res == bx (same element)
+            TD_TRY(run_conv(n, B.c2, n->bt, oh, ow, res, last16 ? n->br : n->bx, s));   // in-place on bx when res == bx (same element)
         }
         ch = oh; cw = ow;
     }
-    float* c4 = n->bx;
+    float* c4 = n->c4 = n->act16 ? n->br : n->bx;
     // pyramid pooling slice (td4_psp18.py:271-284)
     if (n->cfg.model == 1) {                                           // pspnet.py:73-89: PSPHead on c4, no temporal state
         run_ppm(n, c4, n->h, n->w, n->C, n->C, n->C / 4, L.d_ppm_w, L.d_ppm_b, 0, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
@@ -1118,7 +1159,7 @@ extern "C" long tdnet_get_stage(tdnet_t* n, const char* name, float* host, size_
     const float* src = nullptr;
     long rows = n->Lq, C = 0;
     bool nhwc_map = true, planar = false;
-    if (s == "c4") { src = n->bx; C = n->C; }
+    if (s == "c4") { src = n->c4 ? n->c4 : n->bx; C = n->C; }
     else if (s == "z") { src = n->z; C = n->cfg.model == 1 ? 2 * n->C : n->C; }
     else if (s == "lowres") { src = n->lowres; C = n->cfg.nclass; planar = true; }
     else if (n->cfg.model == 1) return td_fail("tdnet_get_stage: stage \"%s\" does not exist in the single-frame PSPNet", name);
@@ -1245,6 +1286,37 @@ extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const flo
     free_conv_layer(L);
     return rc;
 }
+// Test entry for the fp16-activation storage of tdnet_opts.precision = 1: the fp32 arguments are rounded to fp16 maps in HBM, the
+// conv runs with fp16 input / residual / output (k_conv_igemm_h<.., IN16, OUT16>), and the fp16 result is widened into out.
+extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, const float* w_host, const float* bias_host, int Cout,
+                                     int KS, int stride, int dil, const float* resid, int act, int tile, float* out, void* stream) {
+    if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_f16io: KS must be 1 or 3");
+    if (Cin % 64) return td_fail("tdnet_op_conv2d_f16io: Cin must be a multiple of 64");
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d", CT_COUNT);
+    hipStream_t s = (hipStream_t)stream;
+    tdnet_opts o = opts_or_default(nullptr);
+    o.precision = 1;
+    ConvLayer L;
+    std::vector<float> w(w_host, w_host + (size_t)Cout * Cin * KS * KS), b;
+    if (bias_host) b.assign(bias_host, bias_host + Cout);
+    const int pad = dil * (KS / 2);
+    const int Ho = out_size(H, KS, stride, dil, pad), Wo = out_size(W, KS, stride, dil, pad);
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
+    L.in16 = L.out16 = true;
+    _Float16 *hin = nullptr, *hres = nullptr, *hout = nullptr;
+    const long nin = (long)H * W * Cin, nout = (long)Ho * Wo * Cout;
+    if (dev_alloc(&hin, (size_t)nin) || dev_alloc(&hout, (size_t)nout) || (resid && dev_alloc(&hres, (size_t)nout))) return -1;
+    TD_LAUNCH(k_f2h, dim3(td_grid_for(nin)), dim3(256), 0, s, in, hin, nin);
+    if (resid) TD_LAUNCH(k_f2h, dim3(td_grid_for(nout)), dim3(256), 0, s, resid, hres, nout);
+    const int rc = run_conv(nullptr, L, (const float*)hin, H, W, (const float*)hres, (float*)hout, s);
+    TD_LAUNCH(k_h2f, dim3(td_grid_for(nout)), dim3(256), 0, s, (const _Float16*)hout, out, nout);
+    TD_HIP(hipStreamSynchronize(s));
+    TD_HIP(hipGetLastError());
+    hipFree(hin); hipFree(hout);
+    if (hres) hipFree(hres);
+    free_conv_layer(L);
+    return rc;
+}
 extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host, const float* bias_host, const tdnet_opts* opts,
                              float* out, void* stream) {
     const tdnet_opts o = opts_or_default(opts);
@@ -1275,10 +1347,13 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
         if (!ln_g || !ln_b) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
         if (dev_alloc(&part, (size_t)2 * attn_strips(Lq, DV) * DV) || dev_alloc(&mean, DV) || dev_alloc(&rstd, DV)) return -1;
     }
-    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online != 0, part)) return -1;
+    _Float16* vt = nullptr;                                            // online == 2: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
+    if (online == 2 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) return -1;
+    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online != 0, part, vt)) return -1;
     if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
     TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());
+    if (vt) hipFree(vt);
     if (part) { hipFree(part); hipFree(mean); hipFree(rstd); }
     return 0;
 }

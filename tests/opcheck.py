@@ -70,6 +70,36 @@ def conv(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed
     return err
 
 
+def conv_f16io(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed=0, tol=4e-3):
+    """The fp16-storage conv of tdnet_opts.precision = 1 (input / residual / output maps fp16 in HBM, fp16 MFMA, fp32 accumulate)
+    against an fp64 evaluation on the fp16-rounded operands; what is left is fp32 summation order and the output's own rounding to
+    fp16 (2^-11 relative)."""
+    g = np.random.default_rng(seed)
+    x = g.standard_normal((H, W, Cin)).astype(np.float32)
+    w = (g.standard_normal((Cout, Cin, KS, KS)) / np.sqrt(Cin * KS * KS)).astype(np.float32)
+    b = g.standard_normal(Cout).astype(np.float32)
+    pad = dil * (KS // 2)
+    h = lambda a: torch.from_numpy(a).half().double()
+    ref = F.conv2d(h(x).permute(2, 0, 1)[None], h(w), torch.from_numpy(b).double(), stride, pad, dil)
+    Ho, Wo = ref.shape[-2:]
+    r = None
+    if resid:
+        r = g.standard_normal((Ho, Wo, Cout)).astype(np.float32)
+        ref = ref + h(r).permute(2, 0, 1)[None]
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.leaky_relu(ref, 0.01)
+    ref = ref[0].permute(1, 2, 0).float().numpy()
+    dx, dr, out = mem.put(x), (mem.put(r) if resid else None), mem.empty((Ho, Wo, Cout))
+    lib.check(lib.tdnet_op_conv2d_f16io(mem.ptr(dx), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, KS, stride, dil, mem.ptr(dr), act,
+                                        -1 if tile is None else tile, mem.ptr(out), mem.stream))
+    got = mem.get(out)
+    err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
+    assert err <= tol, ("conv_f16io", H, W, Cin, Cout, KS, stride, dil, act, resid, tile, err)
+    return err
+
+
 def stem(lib, mem, H, W, seed=0, tol=1e-4, opts=None):
     import ctypes
     g = np.random.default_rng(seed)

@@ -157,6 +157,39 @@ def test_pipeline_with_fusion_options_against_reference_goldens(lib, golden_dir,
     e.close()
 
 
+def test_fp16_storage_conv_attention_and_pipeline(lib, golden_dir):
+    """tdnet_opts.precision = 1 (BASELINE config 5, "fp16 MFMA"): fp16 activation maps between the backbone's convs (every tile
+    variant, 1x1 / 3x3, stride, dilation, ragged shapes, residual), the fp16-MFMA attention kernel (both shapes, ragged, a dominating
+    key, the LayerNorm statistics of its epilogue), then the td2 pipeline in that mode against the goldens of the real (fp32)
+    reference with the gate this mode is held to: max|dlogit| <= 3e-2 and >= 99.5 % of the labels equal."""
+    for tile in (3, 4, 5):
+        opcheck.conv_f16io(lib, MEM, 13, 21, 128, 96, 3, 1, 1, 1, True, tile)
+        opcheck.conv_f16io(lib, MEM, 7, 9, 64, 64, 1, 1, 1, 0, False, tile)
+        opcheck.conv_f16io(lib, MEM, 9, 11, 192, 130, 1, 2, 1, 2, True, tile)
+        opcheck.conv_f16io(lib, MEM, 12, 17, 64, 128, 3, 2, 1, 1, False, tile)
+        opcheck.conv_f16io(lib, MEM, 10, 14, 128, 64, 3, 1, 4, 1, True, tile)
+    for ln in (False, True):
+        opcheck.attention(lib, MEM, 45, 6, 512, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 97, 300, 512, ramp=True, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 33, 1, 128, online=2, tol=1e-2, ln=ln)
+    name, bb, H, W = "td2", "resnet18", 33, 65
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    e = Engine(2, 18, 19, H, W, 0, lib=lib, opts={"precision": 1})
+    e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    for t, x in enumerate(weights.synth_video(H, W, 3, seed=1)):
+        out = np.full((1, 19, H, W), 7e7, np.float32)
+        e.forward(x, t % 2, out)
+        ref = g["f%d_logits" % t]
+        assert np.abs(out - ref).max() <= 3e-2, (t, np.abs(out - ref).max())
+        assert (out[0].argmax(0) == ref[0].argmax(0)).mean() >= 0.995
+        assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 3e-2 * np.abs(g["f%d_c4" % t]).max()
+    e.close()
+
+
 def test_winograd_conv_and_pipeline(lib, golden_dir):
     """Winograd F(2x2,3x3) mode (td_wino.h): every dilation, ragged sizes, then the td4 pipeline with layers 3-4 on it."""
     if True:

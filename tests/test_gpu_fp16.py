@@ -1,6 +1,10 @@
-"""fp16-MFMA conv mode (BASELINE config 5, tdnet_opts.precision = 1): the kernel against a reference evaluated on
-fp16-rounded operands (tight: the only difference left is fp32 summation order), and the whole model against the fp32 CPU
-oracle with the loosened, REPORTED parity this mode has (it does not meet the 1e-3 logits gate by design)."""
+"""fp16 mode (BASELINE config 5 "fp16 MFMA", tdnet_opts.precision = 1) on the GPU: fp16 activation maps between the backbone's convs,
+fp16-MFMA convs and attention, fp32 accumulation / softmax / LayerNorm.  Kernels against fp64 evaluations on fp16-rounded operands
+(tight: what is left is summation order and the output's own rounding), then the whole model against the fp32 CPU oracle with the
+gate this mode is held to at its BASELINE size (td2-psp34, 720x960 -- the stand-in for "td2-bise34", which does not exist in the
+reference): max|dlogit| <= 3e-2, >= 99.5 % of the labels equal, mIoU(pred, ref_pred) >= 0.99."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -9,12 +13,13 @@ import torch.nn.functional as F
 import opcheck
 from oracle import tdnet_ref
 from tdnet_amd import _capi, arch, weights
-from tdnet_amd.model import td2_psp50
+from tdnet_amd.model import td2_psp50, td4_psp18
 
 pytestmark = pytest.mark.gpu
 
 
 def _conv16(lib, mem, H, W, Cin, Cout, KS, stride, dil, tile, seed=0):
+    """fp32 maps in HBM, operands rounded on the way into LDS (the convs at the rim of the fp16 backbone: Encoding, head)."""
     g = np.random.default_rng(seed)
     x = g.standard_normal((H, W, Cin)).astype(np.float32)
     w = (g.standard_normal((Cout, Cin, KS, KS)) / np.sqrt(Cin * KS * KS)).astype(np.float32)
@@ -22,7 +27,6 @@ def _conv16(lib, mem, H, W, Cin, Cout, KS, stride, dil, tile, seed=0):
     xr, wr = torch.from_numpy(x).half().double(), torch.from_numpy(w).half().double()
     ref = F.conv2d(xr.permute(2, 0, 1)[None], wr, torch.from_numpy(b).double(), stride, dil * (KS // 2), dil)[0].permute(1, 2, 0).float().numpy()
     dx, out = mem.put(x), mem.empty(ref.shape)
-    import ctypes
     o = lib.opts(precision=1)
     lib.check(lib.tdnet_op_conv2d(mem.ptr(dx), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, KS, stride, dil, None, 0,
                                   ctypes.byref(o), tile, mem.ptr(out), mem.stream))
@@ -30,29 +34,57 @@ def _conv16(lib, mem, H, W, Cin, Cout, KS, stride, dil, tile, seed=0):
     assert err <= 3e-5, ("conv fp16", H, W, Cin, Cout, KS, stride, dil, tile, err)
 
 
-def test_fp16_conv_kernel_and_model():
+def test_fp16_kernels():
     lib, mem = _capi.lib(), opcheck.TorchMem()
-    if True:
-        for tile in (3, 4, 5):
-            _conv16(lib, mem, 13, 21, 128, 96, 3, 1, 1, tile)
-            _conv16(lib, mem, 7, 9, 64, 64, 1, 1, 1, tile)              # single K step
-            _conv16(lib, mem, 7, 9, 192, 130, 1, 1, 1, tile)            # odd number of K steps, ragged Cout
-            _conv16(lib, mem, 33, 47, 256, 256, 3, 1, 4, tile)          # dilation 4
-            _conv16(lib, mem, 40, 40, 64, 128, 3, 2, 1, tile)           # stride 2
-        _conv16(lib, mem, 128, 256, 512, 512, 3, 1, 4, 3)               # the dominant layer4 shape
-        # whole model in fp16 mode vs the fp32 CPU oracle: reported parity
-        H, W, T = 180, 240, 3
-        spec = arch.model_spec("td2", 19, "resnet34")
-        ref = tdnet_ref.TDNetRef(spec, weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0))
-        m = td2_psp50.td2_psp50(nclass=19, path_num=2, model_path=None, backbone="resnet34", synthetic_seed=0, kernel_opts={"precision": 1}).eval().to("cuda")
-        tdnet_ref.tune_threads()
-        worst, agree = 0.0, []
-        with torch.no_grad():
-            for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
-                xt = torch.from_numpy(x)
-                out = m(xt.cuda(), pos_id=t % 2).cpu().numpy()
-                exp = ref.forward(xt, t % 2).numpy()
-                worst = max(worst, float(np.abs(out - exp).max()))
-                agree.append(float((out[0].argmax(0) == exp[0].argmax(0)).mean()))
-        print("fp16-MFMA td2-psp34 %dx%d: max|dlogit| %.3e, label agreement %.4f" % (H, W, worst, min(agree)))
-        assert worst <= 0.25 and min(agree) >= 0.97
+    for tile in (3, 4, 5):
+        _conv16(lib, mem, 13, 21, 128, 96, 3, 1, 1, tile)
+        _conv16(lib, mem, 7, 9, 64, 64, 1, 1, 1, tile)              # single K step
+        _conv16(lib, mem, 7, 9, 192, 130, 1, 1, 1, tile)            # odd number of K steps, ragged Cout
+        _conv16(lib, mem, 33, 47, 256, 256, 3, 1, 4, tile)          # dilation 4
+        _conv16(lib, mem, 40, 40, 64, 128, 3, 2, 1, tile)           # stride 2
+        opcheck.conv_f16io(lib, mem, 13, 21, 128, 96, 3, 1, 1, 1, True, tile)        # fp16 maps in HBM (input, residual, output)
+        opcheck.conv_f16io(lib, mem, 9, 11, 192, 130, 1, 2, 1, 2, True, tile)
+        opcheck.conv_f16io(lib, mem, 40, 40, 64, 128, 3, 2, 1, 1, False, tile)
+        opcheck.conv_f16io(lib, mem, 97, 193, 256, 256, 3, 1, 2, 1, True, tile)
+    _conv16(lib, mem, 128, 256, 512, 512, 3, 1, 4, 3)               # the dominant layer4 shape
+    opcheck.conv_f16io(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, 3)
+    opcheck.conv_f16io(lib, mem, 90, 120, 512, 512, 3, 1, 16, 1, True)             # resnet34 multi-grid 16 at 720x960
+    for ln in (False, True):                                        # the fp16-MFMA attention kernel (td_attn_h.h), incl. its LayerNorm statistics
+        opcheck.attention(lib, mem, 300, 200, 512, spike=True, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 97, 300, 512, ramp=True, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 18721, 1225, 512, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 32768, 2048, 512, spike=True, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 10800, 690, 128, qk_scale=1.5, online=2, tol=1e-2, ln=ln)     # td2-psp34 @720x960
+        opcheck.attention(lib, mem, 32768, 2048, 128, online=2, tol=1e-2, ln=ln)
+
+
+def _model_gate(name, bb, H, W, T):
+    spec = arch.model_spec(name, 19, bb)
+    ref = tdnet_ref.TDNetRef(spec, weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0))
+    cls = td4_psp18.td4_psp18 if name == "td4" else td2_psp50.td2_psp50
+    m = cls(nclass=19, path_num=spec.path_num, model_path=None, backbone=bb, synthetic_seed=0, kernel_opts={"precision": 1}).eval().to("cuda")
+    tdnet_ref.tune_threads()
+    worst, agree = 0.0, []
+    hist = np.zeros((19, 19), np.int64)
+    with torch.no_grad():
+        for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
+            xt = torch.from_numpy(x)
+            out = m(xt.cuda(), pos_id=t % spec.path_num).cpu().numpy()
+            exp = ref.forward(xt, t % spec.path_num).numpy()
+            worst = max(worst, float(np.abs(out - exp).max()))
+            lo, lr = out[0].argmax(0), exp[0].argmax(0)
+            agree.append(float((lo == lr).mean()))
+            hist += tdnet_ref.confusion_miou(lo, lr, 19)[1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        miou = float(np.nanmean(np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))))
+    assert m.engine.opts()["precision"] == 1
+    print("fp16 mode %s-%s %dx%d: max|dlogit| %.3e, label agreement %.4f, mIoU vs fp32 CPU %.4f" % (name, bb, H, W, worst, min(agree), miou))
+    assert worst <= 3e-2 and min(agree) >= 0.995 and miou >= 0.99, (worst, min(agree), miou)
+
+
+def test_fp16_model_gate_config5_720x960():
+    _model_gate("td2", "resnet34", 720, 960, 4)                     # BASELINE.json configs[4] (stand-in backbone, see module docstring)
+
+
+def test_fp16_model_gate_td4():
+    _model_gate("td4", "resnet18", 257, 513, 6)
