@@ -6,8 +6,11 @@
 // 16x the matrix rate of the fp32 kernel: 4 + 8 NT MFMAs of 32 cycles per 32 x (32 CW) key tile instead of 32 + 64 NT of 64.
 //
 // Differences from td_attn.h forced by the operand format (a lane supplies 8 CONSECUTIVE k of its row / column):
-//   * V' must be read along the key axis, so it is consumed TRANSPOSED and already in fp16: vt [DV][LkPad] (k_attn_vt_h below, a
-//     2 MB pass; LkPad = Lk rounded up to the key super-tile, zero filled, so no V' load is ever ragged);
+//   * V' must be read along the key axis (8 consecutive keys of one channel per lane), so it is consumed re-tiled and already in
+//     fp16: vt [LkPad / 8][DV][8 halfs] -- key group major, so the 32 lanes of a channel tile read 32 consecutive 16-byte pieces
+//     (k_attn_vt_h below, a 2 MB pass; LkPad = Lk rounded up to the key super-tile, zero filled: no V' load is ever ragged).  (A
+//     plain transpose [DV][LkPad] was measured first: every lane then reads from its own 4 KB-strided row, 64 cache lines per load
+//     instruction, and the kernel ran at fp32 speed.)
 //   * P goes through LDS in the natural [key group of 8][query][8 halfs] image (conflict-free 16-byte reads), written by the
 //     lanes that own the scores as four 8-byte pieces;
 //   * the accumulator of channel tile j holds channel cb0 + 32 j + (lane & 31) (not NT consecutive channels per lane): a wave's
@@ -20,7 +23,7 @@
 struct AttnArgsH {
     const float* q;          // [Lq][64]
     const float* k;          // [Lk][64]
-    const _Float16* vt;      // [DV_total][LkPad]: V' transposed, fp16, zero beyond Lk
+    const _Float16* vt;      // [LkPad / 8][ldv][8]: V' in key groups of 8, fp16, zero beyond Lk (pointer already at the launch's first channel)
     const float* bias;       // [DV] or nullptr
     const float* resid;      // [Lq][ldv] or nullptr
     float* out;              // [Lq][ldv]
@@ -31,8 +34,8 @@ struct AttnArgsH {
     int ldv;                 // row stride of resid / out / ln_part (floats)
 };
 
-// vp [Lk][ldv] fp32 (channels c0 .. c0 + DV - 1 of it) -> vt [DV][LkPad] fp16, zero padded.  grid = (LkPad/64, DV/64), block 256:
-// a 64 x 64 tile through LDS so that both the reads (along channels) and the writes (along keys) are contiguous.
+// vp [Lk][ldv] fp32 -> vt [LkPad / 8][ldv][8] fp16, zero padded.  grid = (LkPad/64, DV/64), block 256: a 64 x 64 tile through LDS
+// so that both the reads (along channels) and the writes (16 bytes per channel, channels consecutive) are contiguous.
 TD_KERNEL void k_attn_vt_h(const float* __restrict__ vp, _Float16* __restrict__ vt, int Lk, int LkPad, int ldv) {
     TD_DYN_LDS(smem);
     float* tile = reinterpret_cast<float*>(smem);                 // [64 keys][65]
@@ -43,8 +46,8 @@ TD_KERNEL void k_attn_vt_h(const float* __restrict__ vp, _Float16* __restrict__ 
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
-        const int cc = i >> 6, kk = i & 63;
-        if (k0 + kk < LkPad) vt[(size_t)(c0 + cc) * LkPad + k0 + kk] = (_Float16)tile[kk * 65 + cc];
+        const int e = i & 7, cc = (i >> 3) & 63, kg = i >> 9;
+        if (k0 + 8 * kg < LkPad) vt[((size_t)(k0 / 8 + kg) * ldv + c0 + cc) * 8 + e] = (_Float16)tile[(8 * kg + e) * 65 + cc];
     }
 }
 
@@ -111,9 +114,10 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention_h(AttnArgsH p) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float lsum = 0.f, rowmax = NEG;
     const int cb0 = cw * (NT * 32);                               // first channel of this wave; tile j, lane l31 -> channel cb0 + 32 j + l31
-    const _Float16* vrow[NT];
+    const _Float16* vch[NT];                                      // key group `half` of a k16-step, this lane's channel of tile j
 #pragma unroll
-    for (int j = 0; j < NT; ++j) vrow[j] = p.vt + (size_t)(cb0 + 32 * j + l31) * p.LkPad + 8 * half;
+    for (int j = 0; j < NT; ++j) vch[j] = p.vt + ((size_t)half * LDV + cb0 + 32 * j + l31) * 8;
+    const size_t vgroup = (size_t)LDV * 8;                        // halfs per key group
 
     f32x4 kf[8];
     load_k(cw * 32, kf);
@@ -179,7 +183,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention_h(AttnArgsH p) {
         for (int ks = 0; ks < 2 * CW; ++ks) {
             const f16x8 a8 = td_ld8h(Pw + ((2 * ks + half) * 32 + l31) * 8);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = td_mfma32_f16(a8, td_ld8h(vrow[j] + kbase + 16 * ks), acc[j]);
+            for (int j = 0; j < NT; ++j) acc[j] = td_mfma32_f16(a8, td_ld8h(vch[j] + (size_t)(kbase / 8 + 2 * ks) * vgroup), acc[j]);
         }
     }
     // ---- row sums -> 1/l, epilogue ---------------------------------------------------------------------------
@@ -265,7 +269,7 @@ static inline int attn_launch_h(const AttnArgs& a, int DV, _Float16* vt, hipStre
     h.ln_nstr = grid;
     for (int c0 = 0; c0 < DV; c0 += 512) {
         AttnArgsH b = h;
-        b.vt += (size_t)c0 * LkPad; b.out += c0;
+        b.vt += (size_t)c0 * 8; b.out += c0;
         if (b.bias) b.bias += c0;
         if (b.resid) b.resid += c0;
         if (b.ln_part) b.ln_part += c0;
