@@ -52,7 +52,7 @@ typedef struct tdnet_opts {
     int32_t gemm_persistent; /* 1 (default) = stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel,
                                 0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */
     int32_t stagger;         /* start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups                      */
-    int32_t attention;       /* 0 = exact two-pass softmax (row maxima first), 1 (default) = single pass, lazily moved reference          */
+    int32_t attention;       /* 0 = exact two-pass softmax (row maxima first), 1 (default) = single pass, lazily moved reference, 2 = the same pipelined to one barrier per key tile        */
     int32_t fusion;          /* bit mask of launch-level fusions / overlaps, each measured on its own; default 2|4 = the two
                                 that pay on MI355X (1, 8, 16 measured neutral to slightly negative and stay off):
                                 1 = Encoding's q / k projections (w_qs, w_ks: small, latency-bound) on the side stream beside w_vs,
@@ -149,8 +149,9 @@ int tdnet_op_conv2d_f16io(const float* in_dev, int H, int W, int Cin, const floa
 int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const float* bias_host,
                   const tdnet_opts* opts /* NULL = defaults */, float* out_dev, void* stream);
 /* softmax(q k^T / sqrt(dk)) v' + bias + resid: q [Lq,64], k [Lk,64], vp [Lk,DV], bias dev [DV]|NULL, resid [Lq,DV]|NULL.
- * online: 0 = exact two-pass softmax, 1 = single pass with a lazily moved reference (tdnet_opts.attention), 2 = the fp16-MFMA
- * kernel of tdnet_opts.precision = 1 (single pass; operands and P rounded to fp16, softmax and accumulation fp32).
+ * online: tdnet_opts.attention (0 = exact two-pass softmax, 1 = single pass with a lazily moved reference, 2 = 1 pipelined to one
+ * barrier per key tile), or 16 = the fp16-MFMA kernel of tdnet_opts.precision = 1 (single pass; operands and P rounded to fp16,
+ * softmax and accumulation fp32).
  * ln_out != NULL: also the plane LayerNorm (affine ln_g, ln_b [Lq]) of the result, from the strip statistics the kernel's epilogue
  * writes (tdnet_opts.fusion bit 2) -> ln_out [Lq,DV].                                                                          */
 int tdnet_op_attention(const float* q_dev, const float* k_dev, const float* vp_dev, const float* bias_dev,

@@ -15,6 +15,9 @@
 //                   moves it (rescaling the accumulators and the running sum by exp2(r_old - r_new)) only when a tile's maximum
 //                   exceeds it by more than TAU = 8, so P <= 2^8 and the rescale -- a wave-uniform branch -- runs a few times per
 //                   query tile instead of once per key tile.  Results differ from the two-pass schedule by rounding only.
+//   ONLINE = 2    : the same arithmetic, software-pipelined to ONE workgroup barrier per key super-tile (ONLINE = 1 needs two: tile
+//                   maxima, then P): the scores of tile t+1 are computed, and their maxima published, before the barrier that
+//                   publishes P of tile t, so the maxima are already visible when the next iteration needs them.
 //
 // MFMA mapping (fp32, v_mfma_f32_32x32x2_f32), one wave = 32 queries x (32*NT) output channels:
 //   scores are computed TRANSPOSED, S^T = K Q^T (A = K tile, B = Q^T): lane (q = lane&31, half) then holds, in register
@@ -56,7 +59,7 @@ struct AttnLds {
     static constexpr int BYTES = (2 * P_FLOATS + 3 * RED_FLOATS) * 4;   // P (double buffered), row-max / row-sum exchange, per-wave rescale factors
 };
 
-template <int QW, int CW, int NT, bool ONLINE>
+template <int QW, int CW, int NT, int ONLINE>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     static_assert(QW * CW == 4, "4 waves per block");
     static_assert(NT == 4 || NT == 2, "lane owns NT consecutive channels: one float4 or one float2 of V' / the output");
@@ -184,6 +187,94 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             }
         }
     };
+    if (ONLINE == 2) {
+        // ---- single pass, one barrier per super-tile -------------------------------------------------------------
+        auto tile_max = [&](const f32x16& s, int kb) -> float {
+            float lm = NEG;
+            if (kb + 32 <= p.Lk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lm = s[r] > lm ? s[r] : lm;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    lm = (key < p.Lk && s[r] > lm) ? s[r] : lm;
+                }
+            }
+            return fmaxf(lm, td_shfl_xor(lm, 32));
+        };
+        float* redb[2] = {red, red2};                             // tile maxima, double buffered (red2 is free until the epilogue)
+        f32x4 kf[8];
+        load_k(cw * 32, kf);
+        f32x16 s = score_tile(kf);
+        {
+            const float lm = tile_max(s, cw * 32);
+            if (half == 0) redb[0][(qw * CW + cw) * 32 + l31] = lm;
+        }
+        if (nsuper > 1) load_k(SK + cw * 32, kf);
+        __syncthreads();
+        for (int st = 0; st < nsuper; ++st) {
+            const int kbase = st * SK, kb = kbase + cw * 32;
+            f32x4 bb[3][4];
+            load_v(kbase, 0, bb[0]);
+            load_v(kbase, 1, bb[1]);
+            // A: maxima of tile st (published by the previous barrier) -> reference -> P of tile st
+            float tm = NEG;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) tm = fmaxf(tm, redb[st & 1][(qw * CW + c) * 32 + l31]);
+            if (td_any(tm > rowmax + 8.0f)) {
+                const float nm = fmaxf(rowmax, tm);
+                const float alpha = td_exp2(rowmax - nm);
+                lsum *= alpha;
+                rowmax = nm;
+                float* sc = scr + wave * 32;
+                if (half == 0) sc[l31] = alpha;
+                td_wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 a4 = td_ld4(sc + 8 * u + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[j][4 * u + e] *= a4[e];
+                }
+                td_wave_sync();
+            }
+            float* Pw = Ps + (st & 1) * L::P_FLOATS + qw * (8 * CW * 128);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * u + e;
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float pe = (kb + 32 <= p.Lk || key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
+                    v[e] = pe;
+                    lsum += pe;
+                }
+                td_st4(Pw + ((cw * 8 + 2 * u + half) * 32 + l31) * 4, v);
+            }
+            // B: scores of tile st+1 and their maxima, before the barrier
+            if (st + 1 < nsuper) {
+                s = score_tile(kf);
+                const float lm = tile_max(s, kb + SK);
+                if (half == 0) redb[(st + 1) & 1][(qw * CW + cw) * 32 + l31] = lm;
+                if (st + 2 < nsuper) load_k(kb + 2 * SK, kf);     // in flight under the P V' MFMAs below
+            }
+            __syncthreads();
+#pragma unroll
+            for (int G = 0; G < 4 * CW; ++G) {
+                if (G + 2 < 4 * CW) load_v(kbase, G + 2, bb[(G + 2) % 3]);
+                const f32x4 a4 = td_ld4(Pw + ((2 * G + half) * 32 + l31) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = td_mfma32(a4[e], bb[G % 3][e][j], acc[j]);
+                if (G + 2 < 4 * CW) { TD_SCHED_GROUP(0x020, 4); TD_SCHED_GROUP(0x100, 1); }
+                TD_SCHED_GROUP(0x008, 4 * NT);
+            }
+        }
+    } else {
     f32x4 kf[8];
     load_k(cw * 32, kf);
     for (int st = 0; st < nsuper; ++st) {
@@ -268,6 +359,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             TD_SCHED_GROUP(0x008, 4 * NT);
         }
     }
+    }
     // ---- row sums -> 1/l, epilogue ---------------------------------------------------------------------------
     lsum += td_shfl_xor(lsum, 32);
     if (half == 0) red2[(qw * CW + cw) * 32 + l31] = lsum;
@@ -351,7 +443,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 // query tiles (= LayerNorm strips) of a launch
 static inline int attn_strips(int Lq, int DV) { return DV % 512 == 0 ? (Lq + 31) / 32 : 2 * ((Lq + 63) / 64); }
 
-static inline int attn_launch(AttnArgs a, int DV, bool online, hipStream_t s) {
+static inline int attn_launch(AttnArgs a, int DV, int online, hipStream_t s) {
     a.ldv = DV;
     if (DV >= 512 && DV % 512 == 0) {
         const int grid = (a.Lq + 31) / 32;
@@ -362,15 +454,17 @@ static inline int attn_launch(AttnArgs a, int DV, bool online, hipStream_t s) {
             if (b.bias) b.bias += c0;
             if (b.resid) b.resid += c0;
             if (b.ln_part) b.ln_part += c0;
-            if (online) TD_LAUNCH((k_attention<1, 4, 4, true>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
-            else TD_LAUNCH((k_attention<1, 4, 4, false>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
+            if (online == 2) TD_LAUNCH((k_attention<1, 4, 4, 2>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
+            else if (online) TD_LAUNCH((k_attention<1, 4, 4, 1>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
+            else TD_LAUNCH((k_attention<1, 4, 4, 0>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
         }
     } else if (DV == 128) {
         // two query tiles x two channel halves: 2 waves per SIMD at Lq = 32768 (<4,1,4> -- four tiles, all channels -- runs one)
         const int grid = (a.Lq + 63) / 64;
         a.ln_nstr = 2 * grid;
-        if (online) TD_LAUNCH((k_attention<2, 2, 2, true>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
-        else TD_LAUNCH((k_attention<2, 2, 2, false>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
+        if (online == 2) TD_LAUNCH((k_attention<2, 2, 2, 2>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
+        else if (online) TD_LAUNCH((k_attention<2, 2, 2, 1>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
+        else TD_LAUNCH((k_attention<2, 2, 2, 0>), dim3(grid), dim3(256), (AttnLds<2, 2>::BYTES), s, a);
     } else {
         return -1;
     }

@@ -147,6 +147,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.pipeline = d.pipeline ? 1 : 0;
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.stagger = d.stagger < 0 ? 0 : d.stagger > 64 ? 64 : d.stagger;
+    d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
     return d;
 }
 
@@ -779,7 +780,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
 
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
-                         int Lq, int Lk, int DV, float* out, hipStream_t s, bool online = false, float* ln_part = nullptr,
+                         int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,
                          _Float16* vt16 = nullptr) {
     if (n && n->vt16) vt16 = n->vt16;
     AttnArgs a;
@@ -895,9 +896,9 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
     if (n->P == 4) {
         const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
         TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention != 0)) return -1;   // v2 + V[1]
+        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention)) return -1;   // v2 + V[1]
         TD_TRY(run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention != 0)) return -1;   // v3 + V[2]
+        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention)) return -1;   // v3 + V[2]
         TD_TRY(run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c));                                              // (v3 + V[2]) W^T
     } else {
         TD_TRY(run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c));
@@ -989,7 +990,7 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
         const CacheSlot& ck = n->slots[n->fifo[n->FIFO - 1]];
         const AtnLayer& A = L.atn[n->P == 4 ? 2 : 0];                   // td4_psp18.py:147 / td2_psp50.py:120
         stats_nstr = (n->opts.fusion & 2) ? attn_strips(n->Lq, DV) : 0;                                         // LayerNorm strip statistics from the epilogue
-        if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention != 0,
+        if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention,
                           stats_nstr ? n->ln_part : nullptr)) return -1;                                                  // v4 + v_cur
         feat = n->feat;
     } else {
@@ -1347,9 +1348,10 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
         if (!ln_g || !ln_b) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
         if (dev_alloc(&part, (size_t)2 * attn_strips(Lq, DV) * DV) || dev_alloc(&mean, DV) || dev_alloc(&rstd, DV)) return -1;
     }
-    _Float16* vt = nullptr;                                            // online == 2: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
-    if (online == 2 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) return -1;
-    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online != 0, part, vt)) return -1;
+    _Float16* vt = nullptr;                                            // online == 16: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
+    if (online == 16 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) return -1;
+    if (online != 16 && (online < 0 || online > 2)) return td_fail("tdnet_op_attention: online must be 0, 1, 2 or 16");
+    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt)) return -1;
     if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
     TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());

@@ -65,7 +65,7 @@ def test_attention_online_softmax_and_layernorm_statistics(lib):
     """tdnet_opts.attention = 1 (single pass, lazily moved reference) and fusion bit 2 (plane-LayerNorm strip statistics written by
     the epilogue): same gate as the two-pass kernel, on ragged shapes, with a dominating key, and with scores that keep growing
     along the key axis (the reference has to move several times per query tile)."""
-    for online in (1, 0):
+    for online in (1, 2, 0):
         opcheck.attention(lib, MEM, 45, 6, 512, online=online, ln=True)
         opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=online, ln=True)
         opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=online, ln=True)
@@ -74,6 +74,8 @@ def test_attention_online_softmax_and_layernorm_statistics(lib):
         opcheck.attention(lib, MEM, 70, 260, 128, False, True, ramp=True, online=online, ln=True)   # (without the residual the plane is nearly constant: LayerNorm of it is ill-conditioned)
     opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0, online=1)
     opcheck.attention(lib, MEM, 1, 1, 128, online=1)
+    opcheck.attention(lib, MEM, 64, 128, 512, online=2)                                  # exactly one super-tile
+    opcheck.attention(lib, MEM, 40, 129, 128, online=2)                                  # two full super-tiles + one key
 
 
 def test_layernorm_ppm_upsample(lib):
@@ -169,11 +171,11 @@ def test_fp16_storage_conv_attention_and_pipeline(lib, golden_dir):
         opcheck.conv_f16io(lib, MEM, 12, 17, 64, 128, 3, 2, 1, 1, False, tile)
         opcheck.conv_f16io(lib, MEM, 10, 14, 128, 64, 3, 1, 4, 1, True, tile)
     for ln in (False, True):
-        opcheck.attention(lib, MEM, 45, 6, 512, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, MEM, 97, 300, 512, ramp=True, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, MEM, 33, 1, 128, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 45, 6, 512, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 97, 300, 512, ramp=True, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, MEM, 33, 1, 128, online=16, tol=1e-2, ln=ln)
     name, bb, H, W = "td2", "resnet18", 33, 65
     spec = arch.model_spec(name, 19, bb)
     h, w = arch.feat_size(H), arch.feat_size(W)

@@ -50,12 +50,12 @@ def test_fp16_kernels():
     opcheck.conv_f16io(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, 3)
     opcheck.conv_f16io(lib, mem, 90, 120, 512, 512, 3, 1, 16, 1, True)             # resnet34 multi-grid 16 at 720x960
     for ln in (False, True):                                        # the fp16-MFMA attention kernel (td_attn_h.h), incl. its LayerNorm statistics
-        opcheck.attention(lib, mem, 300, 200, 512, spike=True, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, mem, 97, 300, 512, ramp=True, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, mem, 18721, 1225, 512, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, mem, 32768, 2048, 512, spike=True, online=2, tol=1e-2, ln=ln)
-        opcheck.attention(lib, mem, 10800, 690, 128, qk_scale=1.5, online=2, tol=1e-2, ln=ln)     # td2-psp34 @720x960
-        opcheck.attention(lib, mem, 32768, 2048, 128, online=2, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 300, 200, 512, spike=True, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 97, 300, 512, ramp=True, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 18721, 1225, 512, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 32768, 2048, 512, spike=True, online=16, tol=1e-2, ln=ln)
+        opcheck.attention(lib, mem, 10800, 690, 128, qk_scale=1.5, online=16, tol=1e-2, ln=ln)     # td2-psp34 @720x960
+        opcheck.attention(lib, mem, 32768, 2048, 128, online=16, tol=1e-2, ln=ln)
 
 
 def _model_gate(name, bb, H, W, T):

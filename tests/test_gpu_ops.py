@@ -77,7 +77,7 @@ def test_attention(lib, mem):
 
 
 def test_attention_online_and_layernorm_statistics(lib, mem):
-    for online in (1, 0):
+    for online in (1, 2, 0):
         opcheck.attention(lib, mem, 300, 200, 512, spike=True, online=online, ln=True)
         opcheck.attention(lib, mem, 97, 300, 512, ramp=True, online=online, ln=True)
         opcheck.attention(lib, mem, 18721, 1225, 512, online=online, ln=True)

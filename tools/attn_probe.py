@@ -20,7 +20,7 @@ def run(Lq, Lk, DV, online=0, iters=20):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / iters)
     fl = 2.0 * Lq * Lk * (64 + DV)
-    print("Lq=%6d Lk=%5d DV=%3d %s: %.4f ms  %.1f TF algorithmic" % (Lq, Lk, DV, "online  " if online else "two-pass", best, fl / best / 1e9), flush=True)
+    print("Lq=%6d Lk=%5d DV=%3d %s: %.4f ms  %.1f TF algorithmic" % (Lq, Lk, DV, {0: "two-pass", 1: "online  ", 2: "online-1b"}[online], best, fl / best / 1e9), flush=True)
 for shape in ((32768, 2048, 512), (2048, 2048, 512), (18721, 1225, 512), (32768, 2048, 128), (12288, 768, 512)):
-    for online in (0, 1):
+    for online in (0, 1, 2):
         run(*shape, online=online)
