@@ -39,7 +39,7 @@ typedef struct tdnet_cfg {
 /* Per-handle kernel configuration.  Nothing in this library is process-wide: two handles in one process may differ.
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
-#define TDNET_ATTENTION_DEFAULT 1
+#define TDNET_ATTENTION_DEFAULT 2
 #define TDNET_FUSION_DEFAULT 6
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
@@ -52,7 +52,7 @@ typedef struct tdnet_opts {
     int32_t gemm_persistent; /* 1 (default) = stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel,
                                 0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */
     int32_t stagger;         /* start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups                      */
-    int32_t attention;       /* 0 = exact two-pass softmax (row maxima first), 1 (default) = single pass, lazily moved reference, 2 = the same pipelined to one barrier per key tile        */
+    int32_t attention;       /* 0 = exact two-pass softmax (row maxima first), 1 = single pass, lazily moved reference, 2 (default) = the same pipelined to one barrier per key tile        */
     int32_t fusion;          /* bit mask of launch-level fusions / overlaps, each measured on its own; default 2|4 = the two
                                 that pay on MI355X (1, 8, 16 measured neutral to slightly negative and stay off):
                                 1 = Encoding's q / k projections (w_qs, w_ks: small, latency-bound) on the side stream beside w_vs,
