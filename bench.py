@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=2, help="steady-state frames timed on the CPU oracle")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch")
     ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4 + head, 3 F(4x4,3x3) for layers 2-4 + head (default: library default)")
-    ap.add_argument("--attention", type=int, default=None, help="0 exact two-pass softmax, 1 single-pass online softmax")
+    ap.add_argument("--attention", type=int, default=None, help="0 exact two-pass softmax, 1 single pass (lazily moved reference), 2 the same with one barrier per key tile (library default)")
     ap.add_argument("--fusion", type=int, default=None, help="bit mask of launch-level fusions (include/tdnet.h tdnet_opts.fusion)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16 MFMA, fp32 accumulate (BASELINE "

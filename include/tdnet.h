@@ -59,7 +59,9 @@ typedef struct tdnet_opts {
                                 2 = LayerNorm strip statistics written by the attention epilogue (no separate pass over the map),
                                 4 = LayerNorm normalisation applied inside the head's Winograd input transform (no `ln` map in HBM),
                                 8 = pyramid-pooling row sums split four ways per bin (shorter serial chains),
-                                16 = stem: 4-pixel vectorised layout change and 2-output max-pool                               */
+                                16 = stem: 4-pixel vectorised layout change and 2-output max-pool,
+                                32 = Cout <= 64 convs (layer1, the stems) read their A operand straight from global memory in MFMA
+                                     fragment layout instead of staging it through LDS (td_conv_ad.h)                            */
     int32_t reserved[9];     /* must be 0                                                                                        */
 } tdnet_opts;
 void tdnet_opts_default(tdnet_opts* o);

@@ -10,6 +10,7 @@
 #include "td_device.h"
 #include "td_conv.h"
 #include "td_conv_h.h"
+#include "td_conv_ad.h"
 #include "td_wino.h"
 #include "td_gemm.h"
 #include "td_attn.h"
@@ -113,6 +114,7 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
+    bool adirect = false;                                              // Cout <= 64: A operand straight from global (td_conv_ad.h, fusion bit 32)
     bool in16 = false, out16 = false;                                  // h16 only: the input (+ residual) / output map is stored as fp16 in HBM
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
@@ -205,6 +207,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(float)));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    L.adirect = (o.fusion & 32) && !L.h16 && !gemm1x1 && conv_adirect_supports(L.tile, 1);
     std::vector<float> bb(Cout, 0.f);
     if (!b.empty()) bb = b;
     TD_HIP(hipMalloc((void**)&L.d_bias, Cout * sizeof(float)));
@@ -771,7 +774,8 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
         ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0;
         gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
-    } else conv_launch(a, L.tile, L.KS, L.stem, s);
+    } else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem, s);
+    else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;
     if (Wo_out) *Wo_out = Wo;
@@ -837,11 +841,12 @@ static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, 
     TD_LAUNCH(k_nchw3_to_nhwc4, dim3(td_grid_for((long)H * W)), dim3(256), 0, s, img, img4, H * W);
     prof_end(n, s);
 }
-static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* out, hipStream_t s, int fusion) {
+// pool16: 0 = fp32 in / fp32 out; the fp16-activation mode's first map: 1 = fp32 in (the stem's output) / fp16 out, 2 = fp16 in (deep stem) / fp16 out
+static void run_maxpool(tdnet* n, const float* in, int H, int W, int C, float* out, hipStream_t s, int fusion, int pool16 = 0) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     prof_begin(n, 2, false, 0, s);
-    if (fusion & (32 | 64)) {                                          // internal: fp16 backbone (32: fp32 in, 64: fp16 in) -> fp16 out
-        if (fusion & 64) TD_LAUNCH((k_maxpool3s2_h<true>), dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, (const void*)in, (_Float16*)out, H, W, C, Ho, Wo);
+    if (pool16) {
+        if (pool16 == 2) TD_LAUNCH((k_maxpool3s2_h<true>), dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, (const void*)in, (_Float16*)out, H, W, C, Ho, Wo);
         else TD_LAUNCH((k_maxpool3s2_h<false>), dim3(td_grid_for((long)Ho * Wo * (C / 4))), dim3(256), 0, s, (const void*)in, (_Float16*)out, H, W, C, Ho, Wo);
     } else if (fusion & 16)
         TD_LAUNCH(k_maxpool3s2_x2, dim3(td_grid_for((long)Ho * ((Wo + 1) / 2) * (C / 4), 256, 256 * 16)), dim3(256), 0, s, in, out, H, W, C, Ho, Wo);
@@ -918,7 +923,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     } else {
         TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s));
     }
-    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->act16 ? (n->deep ? 64 : 32) : (n->opts.fusion & 16));
+    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->opts.fusion, n->act16 ? (n->deep ? 2 : 1) : 0);
     int ch = n->H2, cw = n->W2;
     for (auto& B : L.blocks) {
         int oh, ow;

@@ -42,6 +42,22 @@ def test_conv_auto_tile_and_edges(lib):
     opcheck.conv(lib, MEM, 1, 1, 32, 32, 3, 1, 1, 0, False, opts=DIRECT)               # single pixel
 
 
+def test_conv_a_operand_direct_from_global(lib):
+    """td_conv_ad.h (fusion bit 32): the Cout <= 64 convs with the A operand loaded straight from global memory in fragment layout:
+    3x3 with dilation / stride / padding on every side, 1x1 with stride, ragged M, 1..3 K steps, residual and activations."""
+    o = {"winograd": 0, "fusion": 32}
+    for tile in (2, 5, None):
+        opcheck.conv(lib, MEM, 13, 21, 64, 64, 3, 1, 1, 1, True, tile, opts=o)
+        opcheck.conv(lib, MEM, 13, 21, 64, 64, 3, 1, 2, 0, False, tile, opts=o)
+        opcheck.conv(lib, MEM, 12, 17, 32, 48, 3, 2, 1, 2, True, tile, opts=o)
+        opcheck.conv(lib, MEM, 17, 9, 128, 64, 1, 2, 1, 0, True, tile, opts=o)
+        opcheck.conv(lib, MEM, 7, 9, 96, 19, 1, 4, 1, 1, False, tile, opts=o)
+        opcheck.conv(lib, MEM, 40, 40, 32, 64, 3, 1, 4, 1, False, tile, opts=o)
+        opcheck.conv(lib, MEM, 1, 1, 32, 32, 3, 1, 1, 0, False, tile, opts=o)
+    for (H, W) in ((33, 65), (40, 52), (8, 10)):
+        opcheck.stem(lib, MEM, H, W, opts={"fusion": 32})
+
+
 def test_stem(lib):
     opcheck.stem(lib, MEM, 33, 65)
     opcheck.stem(lib, MEM, 40, 52)
@@ -129,8 +145,8 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
     e.close()
 
 
-@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"attention": 1, "fusion": 31}), ("td2", "resnet18", {"attention": 1, "fusion": 31}),
-                                          ("td2", "resnet18", {"fusion": 6, "winograd": 1}), ("td2", "resnet18", {"fusion": 31, "winograd": 0})])
+@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"attention": 1, "fusion": 63}), ("td2", "resnet18", {"attention": 2, "fusion": 31}),
+                                          ("td2", "resnet18", {"fusion": 6 + 32, "winograd": 1}), ("td2", "resnet18", {"fusion": 63, "winograd": 0})])
 def test_pipeline_with_fusion_options_against_reference_goldens(lib, golden_dir, name, bb, opts):
     """tdnet_opts.attention = 1 (online softmax) and every tdnet_opts.fusion bit (q/k projections on the side stream, LayerNorm
     statistics from the attention epilogue, LayerNorm applied inside the head's Winograd input transform, split pyramid row sums)
