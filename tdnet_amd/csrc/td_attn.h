@@ -50,14 +50,6 @@ struct AttnArgs {
     // Bottleneck backbone: d_v = 2048) is served as chunks of 512 channels, each its own launch on pointers offset by the chunk's
     // first channel and ldv = the full width (the scores are recomputed per chunk: 64 of 576 MACs per key).
     int ldv;
-    // Key split (ONLINE = 2 only): ksplit = S > 1 -> workgroup b serves query tile b / S and the b % S-th share of the key super-tiles,
-    // and instead of finishing the rows it writes its unnormalised accumulators to part_o[S][Lq][ldv] and (reference, row sum) to
-    // part_ml[S][Lq][2]; k_attn_combine merges the S shares (exactly: softmax is a ratio of sums) and does the epilogue.  Used when
-    // the query tiles alone do not fill the chip: the cached-frame steps (Lq = Lk: 64 tiles) and ragged frame sizes (585 tiles on
-    // 512 workgroup slots at 769x1537).
-    int ksplit;
-    float* part_o;
-    float* part_ml;
 };
 
 template <int QW, int CW>
@@ -83,9 +75,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = TD_UNIFORM(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int qw = wave / CW, cw = wave % CW;
-    const int KS_ = (ONLINE == 2 && p.ksplit > 1) ? p.ksplit : 1;  // key shares per query tile
-    const int btile = (int)blockIdx.x / KS_, bshare = (int)blockIdx.x - btile * KS_;
-    const int q0 = (btile * QW + qw) * 32;                       // first query of this wave's tile
+    const int q0 = (blockIdx.x * QW + qw) * 32;                  // first query of this wave's tile
 
     // ---- this lane's query row, pre-scaled so that exp(s/8 - max) = exp2(S - M) -------------------------------
     // Out-of-range rows/keys are CLAMPED to the last valid one instead of branched around: the loads stay
@@ -214,19 +204,16 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             return fmaxf(lm, td_shfl_xor(lm, 32));
         };
         float* redb[2] = {red, red2};                             // tile maxima, double buffered (red2 is free until the epilogue)
-        const int per_share = (nsuper + KS_ - 1) / KS_;
-        const int st0 = bshare * per_share, st1 = (st0 + per_share < nsuper) ? st0 + per_share : nsuper;   // this share's super-tiles (may be empty)
         f32x4 kf[8];
-        f32x16 s;
-        if (st0 < st1) {
-            load_k(st0 * SK + cw * 32, kf);
-            s = score_tile(kf);
-            const float lm = tile_max(s, st0 * SK + cw * 32);
-            if (half == 0) redb[st0 & 1][(qw * CW + cw) * 32 + l31] = lm;
-            if (st0 + 1 < st1) load_k((st0 + 1) * SK + cw * 32, kf);
+        load_k(cw * 32, kf);
+        f32x16 s = score_tile(kf);
+        {
+            const float lm = tile_max(s, cw * 32);
+            if (half == 0) redb[0][(qw * CW + cw) * 32 + l31] = lm;
         }
+        if (nsuper > 1) load_k(SK + cw * 32, kf);
         __syncthreads();
-        for (int st = st0; st < st1; ++st) {
+        for (int st = 0; st < nsuper; ++st) {
             const int kbase = st * SK, kb = kbase + cw * 32;
             f32x4 bb[3][4];
             load_v(kbase, 0, bb[0]);
@@ -268,11 +255,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
                 td_st4(Pw + ((cw * 8 + 2 * u + half) * 32 + l31) * 4, v);
             }
             // B: scores of tile st+1 and their maxima, before the barrier
-            if (st + 1 < st1) {
+            if (st + 1 < nsuper) {
                 s = score_tile(kf);
                 const float lm = tile_max(s, kb + SK);
                 if (half == 0) redb[(st + 1) & 1][(qw * CW + cw) * 32 + l31] = lm;
-                if (st + 2 < st1) load_k(kb + 2 * SK, kf);        // in flight under the P V' MFMAs below
+                if (st + 2 < nsuper) load_k(kb + 2 * SK, kf);     // in flight under the P V' MFMAs below
             }
             __syncthreads();
 #pragma unroll
@@ -377,26 +364,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     lsum += td_shfl_xor(lsum, 32);
     if (half == 0) red2[(qw * CW + cw) * 32 + l31] = lsum;
     __syncthreads();
-    if (KS_ > 1) {
-        // key-split share: unnormalised rows + (reference, row sum) for k_attn_combine; an empty share leaves zeros and reference NEG
-        if (cw == 0 && half == 0 && q0 + l31 < p.Lq) {
-            float l = 0.f;
-#pragma unroll
-            for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + l31];
-            float* ml = p.part_ml + ((size_t)bshare * p.Lq + q0 + l31) * 2;
-            ml[0] = rowmax; ml[1] = l;
-        }
-        float* po = p.part_o + (size_t)bshare * p.Lq * p.ldv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (q >= p.Lq) continue;
-            const size_t off = (size_t)q * p.ldv + cw * (NT * 32) + l31 * NT;
-            if (NT == 4) { f32x4 o = {acc[0][r], acc[1][r], acc[NT - 2][r], acc[NT - 1][r]}; td_st4(po + off, o); }
-            else { f32x2 o = {acc[0][r], acc[1][r]}; *reinterpret_cast<f32x2*>(po + off) = o; }
-        }
-        return;
-    }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
@@ -464,7 +431,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             }
         }
         if (half == 0) {
-            const int strip = btile * QW + qw;
+            const int strip = blockIdx.x * QW + qw;
             float* pm = p.ln_part + (size_t)strip * LDV + cb;
             float* pq = p.ln_part + ((size_t)p.ln_nstr + strip) * LDV + cb;
             if (NT == 4) { td_st4(pm, mean); td_st4(pq, m2); }
@@ -473,112 +440,20 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     }
 }
 
-// Merge of the S key shares of a split launch + the epilogue of k_attention (bias, residual, optional LayerNorm strip statistics).
-// grid = strips of 32 rows, block = 256 = (C/4 channel groups) x (rows slots); each thread finishes its rows in registers
-// (<= 32 * (C/4) / 256 float4 values), so the strip statistics are a true two-sweep (mean, then centred squares), fixed order.
-template <int CV4>                                                // CV4 = channels / 4 of the launch: 128 (d_v 512) or 32 (d_v 128)
-TD_KERNEL void k_attn_combine(AttnArgs p, int S) {
-    constexpr int RS = 256 / CV4, NR = 32 / RS;                   // row slots per block, rows per thread
-    TD_DYN_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);                  // [RS][C]
-    const int cv = threadIdx.x % CV4, rs = threadIdx.x / CV4;
-    const int q0 = blockIdx.x * 32;
-    const int C = CV4 * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = td_ld4(p.bias + cv * 4);
-    f32x4 o[NR], sum = {0.f, 0.f, 0.f, 0.f};
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int q = q0 + rs + RS * i;
-        o[i][0] = o[i][1] = o[i][2] = o[i][3] = 0.f;
-        if (q >= p.Lq) continue;
-        float m = -3.0e38f;
-        for (int sp = 0; sp < S; ++sp) m = fmaxf(m, p.part_ml[((size_t)sp * p.Lq + q) * 2]);
-        float l = 0.f;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < S; ++sp) {
-            const float* ml = p.part_ml + ((size_t)sp * p.Lq + q) * 2;
-            if (ml[1] <= 0.f) continue;                            // empty share
-            const float w = td_exp2(ml[0] - m);
-            l += w * ml[1];
-            a = a + w * td_ld4(p.part_o + ((size_t)sp * p.Lq + q) * p.ldv + cv * 4);
-        }
-        const size_t off = (size_t)q * p.ldv + cv * 4;
-        f32x4 v = a * (1.0f / l) + bv;
-        if (p.resid) v = v + td_ld4(p.resid + off);
-        td_st4(p.out + off, v);
-        o[i] = v; sum = sum + v; ++cnt;
-    }
-    if (!p.ln_part) return;
-    const int n = p.Lq - q0 < 32 ? p.Lq - q0 : 32;
-    td_st4(red + (size_t)rs * C + cv * 4, sum);
-    __syncthreads();
-    f32x4 tot = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < RS; ++k) tot = tot + td_ld4(red + (size_t)k * C + cv * 4);
-    const f32x4 mean = tot * (1.0f / (float)n);
-    f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        if (q0 + rs + RS * i >= p.Lq) continue;
-        const f32x4 d = o[i] - mean;
-        m2 = m2 + d * d;
-    }
-    __syncthreads();
-    td_st4(red + (size_t)rs * C + cv * 4, m2);
-    __syncthreads();
-    if (rs == 0) {
-        f32x4 t2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < RS; ++k) t2 = t2 + td_ld4(red + (size_t)k * C + cv * 4);
-        td_st4(p.ln_part + (size_t)blockIdx.x * p.ldv + cv * 4, mean);
-        td_st4(p.ln_part + ((size_t)p.ln_nstr + blockIdx.x) * p.ldv + cv * 4, t2);
-    }
-    (void)cnt;
-}
-
-// Key shares for a launch of `tiles` query tiles over `nsuper` key super-tiles: the launch ends when the busiest workgroup slot
-// (2 per CU) is done, i.e. after ceil(tiles S / 512) shares of 1/S of the keys each; splitting costs a pass over S partial maps.
-static inline int attn_pick_split(int tiles, int nsuper) {
-    int best = 1;
-    double best_cost = 0.0;
-    for (int S = 1; S <= 8; S *= 2) {
-        if (S > nsuper) break;
-        const double cost = (double)((tiles * S + 511) / 512) / S + (S > 1 ? 0.05 * S : 0.0);
-        if (S == 1 || cost < best_cost - 1e-9) { best_cost = cost; best = S; }
-    }
-    return best;
-}
-
 // query tiles (= LayerNorm strips) of a launch
 static inline int attn_strips(int Lq, int DV) { return DV % 512 == 0 ? (Lq + 31) / 32 : 2 * ((Lq + 63) / 64); }
 
-// part_o / part_ml: optional workspace for the key split (attn_split_floats); nullptr = never split
-static inline size_t attn_split_floats(int Lq, int Lk, int DV) {
-    if (DV % 512) return 0;
-    const int S = attn_pick_split((Lq + 31) / 32, (Lk + 127) / 128);
-    return S > 1 ? (size_t)S * Lq * DV : 0;
-}
-static inline int attn_launch(AttnArgs a, int DV, int online, hipStream_t s, float* part_o = nullptr, float* part_ml = nullptr) {
+static inline int attn_launch(AttnArgs a, int DV, int online, hipStream_t s) {
     a.ldv = DV;
-    a.ksplit = 1; a.part_o = nullptr; a.part_ml = nullptr;
     if (DV >= 512 && DV % 512 == 0) {
         const int grid = (a.Lq + 31) / 32;
         a.ln_nstr = grid;
-        const int S = (online == 2 && part_o && part_ml) ? attn_pick_split(grid, (a.Lk + 127) / 128) : 1;
         for (int c0 = 0; c0 < DV; c0 += 512) {                         // one launch per 512 channels (DV = 512: a single one)
             AttnArgs b = a;
             b.vp += c0; b.out += c0;
             if (b.bias) b.bias += c0;
             if (b.resid) b.resid += c0;
             if (b.ln_part) b.ln_part += c0;
-            if (S > 1) {
-                b.ksplit = S; b.part_o = part_o + c0; b.part_ml = part_ml;
-                TD_LAUNCH((k_attention<1, 4, 4, 2>), dim3(grid * S), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
-                TD_LAUNCH((k_attn_combine<128>), dim3(grid), dim3(256), 2 * 512 * 4, s, b, S);
-                continue;
-            }
             if (online == 2) TD_LAUNCH((k_attention<1, 4, 4, 2>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
             else if (online) TD_LAUNCH((k_attention<1, 4, 4, 1>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);
             else TD_LAUNCH((k_attention<1, 4, 4, 0>), dim3(grid), dim3(256), (AttnLds<1, 4>::BYTES), s, b);

@@ -273,8 +273,7 @@ struct tdnet {
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;                 // Encoding's q / k projections beside w_vs (fusion bit 1)
     float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
     bool act16 = false;                                               // precision = 1: the maps between the backbone's convs are fp16 in HBM
-    _Float16* vt16 = nullptr;                                         // fp16 attention: V' re-tiled [LkPad/8][DV][8]
-    float *attn_po = nullptr, *attn_pml = nullptr;                    // key-split attention: partial rows [S][Lq][DV], (reference, sum) [S][Lq][2]
+    _Float16* vt16 = nullptr;                                         // fp16 attention: V' transposed [DV][LkPad]
     bool ln_pending = false;                                          // the `ln` map of the last frame was not materialised (fusion bit 4)
     int ln_path = 0;
     bool failed = false;                                              // a launch helper reported an error during the current forward
@@ -428,8 +427,6 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
     for (auto& r : n->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     if (n->vt16) hipFree(n->vt16);
-    if (n->attn_po) hipFree(n->attn_po);
-    if (n->attn_pml) hipFree(n->attn_pml);
     if (n->side) hipStreamDestroy(n->side);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ev_join) hipEventDestroy(n->ev_join);
@@ -533,10 +530,6 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
     if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
-    {
-        const size_t po = std::max(attn_split_floats(n->Lq, (int)lk, n->DV), attn_split_floats((int)lk, (int)lk, n->DV));
-        if (po && !n->opts.precision && (dev_alloc(&n->attn_po, po) || dev_alloc(&n->attn_pml, (size_t)8 * 2 * std::max<size_t>(hw, lk)))) return -1;
-    }
     if (n->opts.precision && hipMalloc((void**)&n->vt16, (size_t)n->DV * attn_lkpad((int)lk) * sizeof(_Float16)) != hipSuccess)
         return td_fail("hipMalloc failed for the fp16 attention workspace");
     n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
@@ -792,15 +785,14 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
                          int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,
-                         _Float16* vt16 = nullptr, float* part_o = nullptr, float* part_ml = nullptr) {
+                         _Float16* vt16 = nullptr) {
     if (n && n->vt16) vt16 = n->vt16;
-    if (n && n->attn_po) { part_o = n->attn_po; part_ml = n->attn_pml; }
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
     a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
     a.ln_part = ln_part; a.ln_nstr = 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s, part_o, part_ml);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
+    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);
     return 0;
@@ -1364,15 +1356,11 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     _Float16* vt = nullptr;                                            // online == 16: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
     if (online == 16 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) return -1;
     if (online != 16 && (online < 0 || online > 2)) return td_fail("tdnet_op_attention: online must be 0, 1, 2 or 16");
-    float *po = nullptr, *pml = nullptr;                               // key-split workspace (attention = 2 decides by shape whether it is used)
-    const size_t pon = online == 2 ? attn_split_floats(Lq, Lk, DV) : 0;
-    if (pon && (dev_alloc(&po, pon) || dev_alloc(&pml, (size_t)16 * Lq))) return -1;
-    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt, po, pml)) return -1;
+    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt)) return -1;
     if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
     TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());
     if (vt) hipFree(vt);
-    if (po) { hipFree(po); hipFree(pml); }
     if (part) { hipFree(part); hipFree(mean); hipFree(rstd); }
     return 0;
 }

@@ -90,13 +90,6 @@ def test_attention_online_softmax_and_layernorm_statistics(lib):
         opcheck.attention(lib, MEM, 70, 260, 128, False, True, ramp=True, online=online, ln=True)   # (without the residual the plane is nearly constant: LayerNorm of it is ill-conditioned)
     opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0, online=1)
     opcheck.attention(lib, MEM, 1, 1, 128, online=1)
-    # key split (attention = 2, few query tiles, several key super-tiles): shares with different references, an empty last share
-    # (5 super-tiles over 4 shares of 2), ragged keys and queries, the LayerNorm statistics of the combine kernel
-    for ln in (False, True):
-        opcheck.attention(lib, MEM, 70, 600, 512, online=2, ln=ln)
-        opcheck.attention(lib, MEM, 45, 1000, 512, spike=True, online=2, ln=ln)
-        opcheck.attention(lib, MEM, 33, 513, 512, False, True, ramp=True, online=2, ln=ln)
-        opcheck.attention(lib, MEM, 64, 300, 512, False, True, online=2, ln=ln)
     opcheck.attention(lib, MEM, 64, 128, 512, online=2)                                  # exactly one super-tile
     opcheck.attention(lib, MEM, 40, 129, 128, online=2)                                  # two full super-tiles + one key
 

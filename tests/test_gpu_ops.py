@@ -86,17 +86,6 @@ def test_attention_online_and_layernorm_statistics(lib, mem):
         opcheck.attention(lib, mem, 18721, 1225, 128, spike=True, ramp=True, online=online, ln=True)
 
 
-def test_attention_key_split(lib, mem):
-    """attention = 2 splits the keys over several workgroups when the query tiles alone do not fill the chip (the cached-frame steps,
-    ragged frame sizes) and merges the shares in k_attn_combine."""
-    for ln in (False, True):
-        opcheck.attention(lib, mem, 2048, 2048, 512, online=2, ln=ln)                  # cached-frame step @1024x2048: 64 tiles x 8 shares
-        opcheck.attention(lib, mem, 1225, 1225, 512, spike=True, online=2, ln=ln)      # ... @769x1537
-        opcheck.attention(lib, mem, 18721, 1225, 512, online=2, ln=ln)                 # final step @769x1537: 586 tiles on 512 slots
-        opcheck.attention(lib, mem, 45, 1000, 512, ramp=True, online=2, ln=ln)
-        opcheck.attention(lib, mem, 10800, 690, 512, qk_scale=1.5, online=2, ln=ln)
-
-
 def test_layernorm_ppm_upsample(lib, mem):
     for hw, c in [(45, 512), (153, 128), (1000, 512), (32768, 512), (18721, 128)]:
         opcheck.layernorm(lib, mem, hw, c)
