@@ -76,6 +76,10 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT the model (CPU, gloo): rank launch, rendezvous, weight broadcast, barriers, timing "
                          "reduction and the JSON line; `value` is null.  Used by tests/test_bench_launch.py; never a measurement")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the collectives run over gloo, so the N-rank code path (launch, weight "
+                         "broadcast into N model instances, barriers, reductions) can be exercised with the real kernels on a box with "
+                         "ONE GPU; the line says shared_gpu and its value is null")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 for a counter pass
     return ap.parse_args(argv)
 
@@ -93,6 +97,8 @@ def self_spawn(args, argv):
     if not args.dry_run:
         import torch
         n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if args.share_gpu and n >= 1:
+            n = args.gpus
         if n < args.gpus:
             sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); refusing to report a smaller job under that label\n" % (args.gpus, n))
             sys.exit(2)
@@ -178,7 +184,9 @@ def main():
     H, W = (int(v) for v in args.size.lower().split("x"))
     if args.dry_run:
         H, W = 33, 65
-    rank, local_rank, world = parallel.init_distributed("gloo" if args.dry_run else None)
+    rank, local_rank, world = parallel.init_distributed("gloo" if (args.dry_run or args.share_gpu) else None)
+    if args.share_gpu:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if args.dry_run:
@@ -301,6 +309,10 @@ def main():
                       "target_fps_per_gpu": 30}}
     if pp is not None:
         res["scaling"] = "strong"
+    if args.share_gpu:
+        res["shared_gpu"] = True
+        res["value"] = None
+        res["metric"] = "SHARED GPU (N ranks on one device over gloo: code-path check, not a measurement): " + res["metric"]
     if args.dry_run:
         res["dry_run"] = True
         res["metric"] = "DRY RUN (launch plumbing only, no model): " + res["metric"]

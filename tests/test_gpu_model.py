@@ -212,6 +212,25 @@ def test_uncalibrated_reference_init(wino):
     assert e_gpu <= 1e-3 * tmax and r_gpu <= 5.0 * r_cpu, (wino, tmax, e_gpu, e_cpu, r_gpu, r_cpu)
 
 
+def test_two_models_with_different_kernel_options_in_one_process():
+    """Per-handle options: an all-direct td2 and a default (Winograd F(4x4), single-pass attention) td2 side by side, fed alternately,
+    each reproduces what it computes alone, and they differ from each other only by rounding."""
+    H, W = 129, 257
+    frames = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, 4, seed=2)]
+    with torch.no_grad():
+        alone = {}
+        for key, opts in (("direct", {"winograd": 0, "attention": 0, "fusion": 0}), ("default", None)):
+            m = make_model("td2", "resnet18", kernel_opts=opts)
+            alone[key] = [m(x, pos_id=t % 2).clone() for t, x in enumerate(frames)]
+        a, b = make_model("td2", "resnet18", kernel_opts={"winograd": 0, "attention": 0, "fusion": 0}), make_model("td2", "resnet18")
+        assert a.engine is None and b.engine is None
+        for t, x in enumerate(frames):
+            oa, ob = a(x, pos_id=t % 2), b(x, pos_id=t % 2)
+            assert torch.equal(oa, alone["direct"][t]) and torch.equal(ob, alone["default"][t])
+            assert 0 < (oa - ob).abs().max().item() < 1e-3
+        assert a.engine.opts()["winograd"] == 0 and b.engine.opts()["winograd"] == 3
+
+
 def test_properties_determinism_labels_reset():
     H, W = 129, 257
     frames = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, 6, seed=3)]
