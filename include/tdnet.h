@@ -61,7 +61,9 @@ typedef struct tdnet_opts {
                                 8 = pyramid-pooling row sums split four ways per bin (shorter serial chains),
                                 16 = stem: 4-pixel vectorised layout change and 2-output max-pool,
                                 32 = Cout <= 64 convs (layer1, the stems) read their A operand straight from global memory in MFMA
-                                     fragment layout instead of staging it through LDS (td_conv_ad.h)                            */
+                                     fragment layout instead of staging it through LDS (td_conv_ad.h),
+                                64 = the 36 planes of the Winograd workspaces V / M padded by 24 rows each (an unpadded plane is a
+                                     power of two bytes: 36 concurrent streams on the same HBM channels)                         */
     int32_t reserved[9];     /* must be 0                                                                                        */
 } tdnet_opts;
 void tdnet_opts_default(tdnet_opts* o);

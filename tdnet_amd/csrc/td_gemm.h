@@ -24,6 +24,7 @@ struct GemmArgs {
     int M, N, NPad, K;
     int nbatch, act;
     int tiles_m, tiles_n; // per batch
+    int MP;               // rows between consecutive batches of a and out (>= M; padded planes of the Winograd workspaces, td_wino.h)
 };
 
 // ROLE only names the launch for the profiler (rocprofv3 aggregates by symbol): 0 = a stride-1 1x1 convolution, 1 = the (m+2)^2
@@ -65,7 +66,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
         const int lin = xbase + q + (l_tile < my_tiles ? l_tile : my_tiles - 1) * G8;   // past the end: stay on the last tile
         const int b = lin / per_batch, r = lin - b * per_batch;
         const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
-        a_buf = td_make_buf(p.a + (size_t)b * p.M * p.K, a_bytes);
+        a_buf = td_make_buf(p.a + (size_t)b * p.MP * p.K, a_bytes);
         w_buf = td_make_buf(p.wp + (size_t)b * nsteps * 8 * p.NPad * 4, w_bytes);
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
@@ -148,7 +149,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
         ++c_tile;
         const int b = lin / per_batch, r0 = lin - b * per_batch;
         const int tm = r0 / p.tiles_n, tn = r0 - tm * p.tiles_n;
-        float* outb = p.out + (size_t)b * p.M * p.N;
+        float* outb = p.out + (size_t)b * p.MP * p.N;
         td_store_acc<MT, NT>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane);
         zero_acc();
     };

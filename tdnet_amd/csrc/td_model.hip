@@ -114,6 +114,7 @@ struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
+    int wino_pad = 0;                                                  // padding rows per Winograd plane (fusion bit 64)
     bool adirect = false;                                              // Cout <= 64: A operand straight from global (td_conv_ad.h, fusion bit 32)
     bool in16 = false, out16 = false;                                  // h16 only: the input (+ residual) / output map is stored as fp16 in HBM
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
@@ -166,6 +167,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     const bool wino_ok = o.winograd && !o.precision && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
                          (o.winograd == 2 || o.winograd == 4 || (Cin >= (o.winograd == 3 ? 128 : 256) && Cout >= 128));
     L.wino = !wino_ok ? 0 : o.winograd >= 3 ? 4 : 2;
+    L.wino_pad = (L.wino && (o.fusion & 64) && o.gemm_persistent && gemm_supports(Cin)) ? 24 : 0;   // 24 rows: 12..48 KB between plane phases
     if (L.wino) {
         // nb = (m+2)^2 batched [T x Cin] x [Cin x Cout] GEMMs, T = M / m^2 tiles: nb * T rows in total -> pick the tile for that many workgroups
         const int nb = (L.wino + 2) * (L.wino + 2);
@@ -508,7 +510,7 @@ static int alloc_workspace(tdnet* n) {
         auto upd = [&](const ConvLayer& L, int H, int W) {
             if (!L.wino) return;
             const size_t T = (size_t)wino_tiles(H, W, L.dil, L.wino), nb = (size_t)(L.wino + 2) * (L.wino + 2);
-            vmax = std::max(vmax, nb * T * L.Cin); mmax = std::max(mmax, nb * T * L.Cout);
+            vmax = std::max(vmax, nb * (T + L.wino_pad) * L.Cin); mmax = std::max(mmax, nb * (T + L.wino_pad) * L.Cout);
         };
         const PathLayers& L0 = n->paths[0];
         if (n->deep) { upd(L0.stem2, n->H1, n->W1); upd(L0.stem3, n->H1, n->W1); }
@@ -725,16 +727,17 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     if (L.wino) {
         const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
         const long T = (long)L.dil * L.dil * TY * TX;
+        const long TP = T + L.wino_pad;                                // padded plane (td_wino.h WinoArgs.TP)
         const int nb = (L.wino + 2) * (L.wino + 2);
         float *V = nullptr, *Mb = nullptr;
-        const bool own = n == nullptr || n->wino_v_floats < (size_t)nb * T * L.Cin || n->wino_m_floats < (size_t)nb * T * L.Cout;
+        const bool own = n == nullptr || n->wino_v_floats < (size_t)nb * TP * L.Cin || n->wino_m_floats < (size_t)nb * TP * L.Cout;
         if (own) {
             if (n) { n->failed = true; return td_fail("internal: Winograd workspace too small"); }
-            if (dev_alloc(&V, (size_t)nb * T * L.Cin) || dev_alloc(&Mb, (size_t)nb * T * L.Cout)) return -1;
+            if (dev_alloc(&V, (size_t)nb * TP * L.Cin) || dev_alloc(&Mb, (size_t)nb * TP * L.Cout)) return -1;
         } else { V = n->wino_v; Mb = n->wino_m; }
         WinoArgs wa;
         wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
-        wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act;
+        wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act; wa.TP = (int)TP;
         wa.ln_mean = lnf ? lnf->mean : nullptr; wa.ln_rstd = lnf ? lnf->rstd : nullptr; wa.ln_g = lnf ? lnf->g : nullptr; wa.ln_b = lnf ? lnf->b : nullptr;
         prof_begin(n, 2, false, 0, s);
         if (L.wino == 4) TD_LAUNCH(k_wino4_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
@@ -744,7 +747,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         if (L.pers && gemm_supports(L.Cin)) {
             GemmArgs ga;
             ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
-            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0;
+            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP;
             gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
         } else {
             ConvArgs g;
@@ -772,7 +775,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
-        ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0;
+        ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = a.M;
         gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
@@ -1464,7 +1467,7 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     tdnet tmp;                                                        // only carries the Winograd workspace for run_conv
     if (L.wino) {
         const size_t T = (size_t)wino_tiles(H, W, dil, L.wino), nb = (size_t)(L.wino + 2) * (L.wino + 2);
-        tmp.wino_v_floats = nb * T * Cin; tmp.wino_m_floats = nb * T * Cout;
+        tmp.wino_v_floats = nb * (T + L.wino_pad) * Cin; tmp.wino_m_floats = nb * (T + L.wino_pad) * Cout;
         if (dev_alloc(&tmp.wino_v, tmp.wino_v_floats) || dev_alloc(&tmp.wino_m, tmp.wino_m_floats)) return -1.0;
     }
     tdnet* ws = L.wino ? &tmp : nullptr;

@@ -28,6 +28,9 @@ struct WinoArgs {
     const float* resid;   // [H][W][Cout] or nullptr
     float* out;           // [H][W][Cout]
     int H, W, C, Cout, dil, TY, TX, T, act;
+    // Rows per plane of V / M INCLUDING padding rows (>= T).  T*C*4 is a power of two for the frame's layers (4 MiB at 512 channels),
+    // so 36 unpadded planes put the 36 concurrent streams of a transform on the same HBM channels; TP = T + pad de-phases them.
+    int TP;
     // Optional plane-LayerNorm fused into the INPUT transform (the FCN head reads LayerNorm(feat), td4_psp18.py:151,306-312): the
     // patch element at pixel p, channel c becomes (x - ln_mean[c]) * ln_rstd[c] * ln_g[p] + ln_b[p] -- the arithmetic of k_ln_apply,
     // same operation order, so fused and unfused results are bit-identical -- and stays 0 outside the image (the conv's zero padding
@@ -87,7 +90,7 @@ TD_KERNEL void k_wino_in(WinoArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) td_st4(p.V + ((size_t)(r * 4 + c) * p.T + tile) * p.C + cv * 4, v[r][c]);
+            for (int c = 0; c < 4; ++c) td_st4(p.V + ((size_t)(r * 4 + c) * p.TP + tile) * p.C + cv * 4, v[r][c]);
     }
 }
 
@@ -106,7 +109,7 @@ TD_KERNEL void k_wino_out(WinoArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) m[r][c] = td_ld4(p.Mb + ((size_t)(r * 4 + c) * p.T + tile) * p.Cout + cv * 4);
+            for (int c = 0; c < 4; ++c) m[r][c] = td_ld4(p.Mb + ((size_t)(r * 4 + c) * p.TP + tile) * p.Cout + cv * 4);
         f32x4 s[2][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                                // A^T m
@@ -191,7 +194,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
             f32x4 v[6];
             td_wino4_bt(tm[r], v);                                    // (.) B, one row
 #pragma unroll
-            for (int c = 0; c < 6; ++c) td_st4(p.V + ((size_t)(r * 6 + c) * p.T + tile) * p.C + cv * 4, v[c]);
+            for (int c = 0; c < 6; ++c) td_st4(p.V + ((size_t)(r * 6 + c) * p.TP + tile) * p.C + cv * 4, v[c]);
         }
     }
 }
@@ -212,7 +215,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
         for (int c = 0; c < 6; ++c) {
             f32x4 m[6], col[4];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) m[r] = td_ld4(p.Mb + ((size_t)(r * 6 + c) * p.T + tile) * p.Cout + cv * 4);
+            for (int r = 0; r < 6; ++r) m[r] = td_ld4(p.Mb + ((size_t)(r * 6 + c) * p.TP + tile) * p.Cout + cv * 4);
             td_wino4_at(m, col);                                      // A^T m, one column
 #pragma unroll
             for (int r = 0; r < 4; ++r) sm[r][c] = col[r];

@@ -145,7 +145,7 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
     e.close()
 
 
-@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"attention": 1, "fusion": 63}), ("td2", "resnet18", {"attention": 2, "fusion": 31}),
+@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"attention": 1, "fusion": 63}), ("td2", "resnet18", {"attention": 2, "fusion": 31 + 64}),
                                           ("td2", "resnet18", {"fusion": 6 + 32, "winograd": 1}), ("td2", "resnet18", {"fusion": 63, "winograd": 0})])
 def test_pipeline_with_fusion_options_against_reference_goldens(lib, golden_dir, name, bb, opts):
     """tdnet_opts.attention = 1 (online softmax) and every tdnet_opts.fusion bit (q/k projections on the side stream, LayerNorm
@@ -241,6 +241,8 @@ def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
                   (5, 9, 256, 512, 3, 1, 16, 2, False), (40, 40, 32, 128, 3, 1, 1, 1, False), (1, 1, 32, 32, 3, 1, 1, 0, False),
                   (7, 7, 32, 64, 3, 1, 3, 1, True), (16, 32, 64, 64, 3, 1, 1, 2, True)]:
             worst = max(worst, opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4}))       # F4's per-conv error is ~6x F2's; outputs are O(1)
+            opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "fusion": 64})             # padded workspace planes
+            opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 2, "fusion": 64})
         opcheck.conv(lib, MEM, 13, 21, 32, 96, 3, 2, 1, 0, False, opts={"winograd": 4})           # stride 2 is not eligible: direct path
         name, bb, H, W = "td4", "resnet18", 33, 65
         spec = arch.model_spec(name, 19, bb)
