@@ -26,11 +26,12 @@ if tr and cc:
         d = dur.get(r["Dispatch_Id"])
         if not d: continue
         agg[d[1]][r["Counter_Name"]] += float(r["Counter_Value"]); agg[d[1]]["_ns_" + r["Counter_Name"]] += d[0]
-    print("==== derived (pmc_sq pass): MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE); clock = GRBM_GUI_ACTIVE / duration")
+    print("==== derived (pmc_sq pass).  GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs:")
+    print("====   clock = GRBM_GUI_ACTIVE / 8 / duration;  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("_ns_GRBM_GUI_ACTIVE", 0)):
         g, ns = v.get("GRBM_GUI_ACTIVE", 0), v.get("_ns_GRBM_GUI_ACTIVE", 0)
         if g <= 0 or ns <= 0: continue
-        print("  %-60s mfma_busy %.3f   clock %.2f GHz   wait_any/wave %.2f" % (k, v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024.0 * g), g / ns,
+        print("  %-60s mfma_busy %.3f   clock %.2f GHz   wait_any/wave %.2f" % (k, v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024.0 * g / 8.0), g / 8.0 / ns,
               v.get("SQ_WAIT_ANY", 0) / max(1.0, v.get("SQ_WAVE_CYCLES", 0))))
 PY
 find $R -name "*.csv" -size +2M -delete
