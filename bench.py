@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch")
     ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4 + head, 3 F(4x4,3x3) for layers 2-4 + head (default: library default)")
     ap.add_argument("--attention", type=int, default=None, help="0 exact two-pass softmax, 1 single pass (lazily moved reference), 2 the same with one barrier per key tile (library default)")
+    ap.add_argument("--stagger", type=int, default=None, help="tuning: start delay of co-resident workgroups (tdnet_opts.stagger)")
     ap.add_argument("--fusion", type=int, default=None, help="bit mask of launch-level fusions (include/tdnet.h tdnet_opts.fusion)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16 MFMA, fp32 accumulate (BASELINE "
@@ -208,7 +209,7 @@ def main():
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
-    kopts = {"winograd": args.winograd, "pipeline": args.conv_pipeline, "attention": args.attention, "fusion": args.fusion,
+    kopts = {"winograd": args.winograd, "pipeline": args.conv_pipeline, "attention": args.attention, "fusion": args.fusion, "stagger": args.stagger,
              "precision": 1 if args.precision == "fp16" else None}
     kopts = {k: v for k, v in kopts.items() if v is not None}
     if args.backbone is None:
@@ -391,7 +392,7 @@ def main():
             psteps, pwarm = 4, P + 2
             child = ["--pmc-child", "--steps", str(psteps), "--warmup", str(pwarm), "--no-cpu-baseline", "--no-pmc", "--model", args.model,
                      "--backbone", args.backbone, "--size", args.size, "--precision", args.precision, "--clips-per-gpu", "1"]
-            for k_, v_ in (("--winograd", args.winograd), ("--conv-pipeline", args.conv_pipeline), ("--attention", args.attention), ("--fusion", args.fusion)):
+            for k_, v_ in (("--winograd", args.winograd), ("--conv-pipeline", args.conv_pipeline), ("--attention", args.attention), ("--fusion", args.fusion), ("--stagger", args.stagger)):
                 if v_ is not None:
                     child += [k_, str(v_)]
             per_launch, per_frame, detail = measure_traffic(child, dom_regex, psteps + pwarm)

@@ -25,6 +25,7 @@ struct GemmArgs {
     int nbatch, act;
     int tiles_m, tiles_n; // per batch
     int MP;               // rows between consecutive batches of a and out (>= M; padded planes of the Winograd workspaces, td_wino.h)
+    int stagger;          // tdnet_opts.stagger (units of 1/8 tile): start delay of the co-resident workgroups, see the kernel
 };
 
 // ROLE only names the launch for the profiler (rocprofv3 aggregates by symbol): 0 = a stride-1 1x1 convolution, 1 = the (m+2)^2
@@ -55,6 +56,17 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
     const int nsteps = p.K >> 5;
     if (my_tiles == 0) return;
+    // De-phase the workgroups that share a CU by a fraction of a TILE.  All workgroups start together and walk tiles of equal
+    // length, so their epilogues coincide: every round ends in a burst of 16-64 KB of accumulator stores per workgroup (33-50 MB
+    // per round of the grid) during which no co-resident wave has MFMAs to issue -- tools/gemm_overhead_probe.py measures ~11 us of
+    // fixed cost per 128 x 128 tile round, three K steps' worth, which is what holds the K = 128..512 launches at 50-85 % MFMA
+    // busy.  Workgroups b, b + 256, b + 512 land on the same CU; group j = b / 256 sleeps j * stagger/8 of a tile's MFMA time once,
+    // so that one group's stores fall under the others' K loops.
+    if (p.stagger > 0) {
+        const int j = (int)(blockIdx.x >> 8);
+        const int units = j * p.stagger * nsteps * (MT * NT * 16 * 64 / 8 / 64);   // (MFMA cycles of a tile per wave) / 8 per unit, in s_sleep(1) = 64 cycles
+        for (int i = 0; i < units; ++i) TD_SLEEP(1);
+    }
     const unsigned w_step_bytes = 8u * (unsigned)p.NPad * 16u;
     const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 4u, w_bytes = (unsigned)nsteps * w_step_bytes;
 

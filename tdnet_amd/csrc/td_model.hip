@@ -747,7 +747,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         if (L.pers && gemm_supports(L.Cin)) {
             GemmArgs ga;
             ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
-            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP;
+            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP; ga.stagger = L.stagger;
             gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
         } else {
             ConvArgs g;
@@ -775,7 +775,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
-        ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = a.M;
+        ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = a.M; ga.stagger = L.stagger;
         gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
