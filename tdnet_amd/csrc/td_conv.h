@@ -72,38 +72,84 @@ struct ConvLds {
 // MFMA time.  With NT == 2 adjacent lanes swap half of a row pair (one DPP move per value): the even lane then holds 4
 // consecutive channels of row r, the odd lane the same 4 channels of row r + 1, and a wave stores 16 bytes per lane, 256
 // contiguous bytes per row, with a quarter of the store instructions.
-template <int MT, int NT>
-TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* bias, const float* resid, int M, int N, int act,
-                         int m_base, int n_base, int lane) {
-    const int half = lane >> 5, l31 = lane & 31;
-    auto activate = [&](float v) { return act == 1 ? (v > 0.f ? v : 0.f) : act == 2 ? (v > 0.f ? v : 0.01f * v) : v; };
-    if (NT == 2 && (N & 3) == 0 && ((((size_t)out) | ((size_t)resid)) & 15) == 0) {       // wave-uniform
-        const int odd = l31 & 1;
-        const int chan = n_base + 4 * (l31 >> 1);
-        const bool cok = chan < N;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (cok) { bv[0] = bias[chan]; bv[1] = bias[chan + 1]; bv[2] = bias[chan + 2]; bv[3] = bias[chan + 3]; }
+// Activation without control flow: act is a kernel ARGUMENT, and `act == 1 ? .. : act == 2 ? ..` per element compiles to a chain
+// of scalar compares and branches around every value (a dozen branches per 16-byte store, ~400 per tile and wave; a branch costs
+// the wave tens of cycles during which it issues nothing).  max(v, 0) + slope * min(v, 0) with slope = 1 / 0 / 0.01 is the same
+// function -- one of the two terms is always zero, so the result is rounded exactly like v, 0 or 0.01f * v.
+TD_DEV float td_act_slope(int act) { return act == 1 ? 0.f : act == 2 ? 0.01f : 1.f; }
+TD_DEV float td_activate(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+
+// The 16-byte path of td_store_acc, ONE copy of the code (two copies selected by "has residual" make the compiler hoist the lane
+// exchanges of all 8 MT row pairs above the dispatch: 64 more live VGPRs, accumulator spills).  So the residual is read
+// unconditionally through a buffer descriptor that has ZERO records when there is none -- the loads then return 0 without touching
+// memory -- and the eight vectors of a 32-row group are requested together before the first is used (one load, one wait, one
+// store per row pair would expose the memory latency sixteen times per tile; and behind a branch the compiler waits with
+// vmcnt(0), which also waits for the previous STORE).  NORES (compile time): no residual path at all.
+template <int MT, bool NORES>
+TD_DEV void td_store_acc16(const f32x16 (&acc)[MT][2], float* out, const float* resid, int M, int N, float slope,
+                           int m_base, int chan, bool cok, int half, int odd, f32x4 bv) {
+    const TdBuf res_buf = td_make_buf(resid, (NORES || !resid) ? 0u : (unsigned)M * (unsigned)N * 4u);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i) {
+        f32x4 rv[8];
+        if (!NORES) {
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
                 const int r = 2 * rp;
-                const float a0 = acc[i][0][r], a1 = acc[i][NT - 1][r], c0 = acc[i][0][r + 1], c1 = acc[i][NT - 1][r + 1];
-                const float x = td_swap1(odd ? a0 : c0), y = td_swap1(odd ? a1 : c1);   // even sends row r+1, odd sends row r
-                f32x4 v;
-                if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
-                else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
                 const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
-                if (m >= M || !cok) continue;
-                const size_t o = (size_t)m * N + chan;
-                v = v + bv;
-                if (resid) v = v + td_ld4(resid + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = activate(v[e]);
-                td_st4(out + o, v);
+                rv[rp] = td_buf_ld4(res_buf, (m < M && cok) ? ((unsigned)m * (unsigned)N + (unsigned)chan) * 4u : TD_BUF_OOB, 0u);
             }
+            TD_SCHED_FENCE();
         }
-        return;
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp) {
+            const int r = 2 * rp;
+            const float a0 = acc[i][0][r], a1 = acc[i][1][r], c0 = acc[i][0][r + 1], c1 = acc[i][1][r + 1];
+            const float x = td_swap1(odd ? a0 : c0), y = td_swap1(odd ? a1 : c1);   // even sends row r+1, odd sends row r
+            f32x4 v;
+            if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
+            else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
+            const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
+            v = v + bv;
+            if (!NORES) v = v + rv[rp];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = td_activate(v[e], slope);
+            if (m < M && cok) td_st4(out + (size_t)m * N + chan, v);
+            TD_SCHED_FENCE();                                       // one row pair at a time (bounds the live registers)
+        }
+    }
+}
+
+template <int MT, int NT, bool NORES = false>
+TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* bias, const float* resid, int M, int N, int act,
+                         int m_base, int n_base, int lane, const f32x4* bias_pre = nullptr) {
+    // bias_pre: this lane's four bias values (channels n_base + 4 (l31 >> 1) ..), fetched by the caller long before the epilogue
+    // (vmcnt is one in-order counter: waiting for a bias load issued here also waits for every older load of the wave).
+    const int half = lane >> 5, l31 = lane & 31;
+    const float slope = td_act_slope(act);
+    auto activate = [&](float v) { return td_activate(v, slope); };
+    if constexpr (NT == 2) {
+        if ((N & 3) == 0 && ((((size_t)out) | ((size_t)resid)) & 15) == 0 && (size_t)M * N < (1u << 29)) {   // wave-uniform
+            const int odd = l31 & 1;
+            const int chan = n_base + 4 * (l31 >> 1);
+            const bool cok = chan < N;
+            f32x4 bv;
+            if (bias_pre) bv = *bias_pre;
+            else {
+                // one unconditional (range-checked) load and its wait HERE: a load under `if (cok)` leaves the compiler unsure whether
+                // it is pending, and it then waits with vmcnt(0) before every use -- i.e. for the previous store, sixteen times
+                const bool al = (((size_t)bias) & 15) == 0;
+                const TdBuf bias_buf = td_make_buf(bias, (unsigned)N * 4u);
+                if (al) bv = td_buf_ld4(bias_buf, cok ? (unsigned)chan * 4u : TD_BUF_OOB, 0u);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = td_buf_ld1(bias_buf, cok ? (unsigned)(chan + e) * 4u : TD_BUF_OOB, 0u);
+                }
+                TD_PIN(bv);
+            }
+            td_store_acc16<MT, NORES>(acc, out, resid, M, N, slope, m_base, chan, cok, half, odd, bv);
+            return;
+        }
     }
     const int nb = n_base + l31 * NT;
     float bs[NT];

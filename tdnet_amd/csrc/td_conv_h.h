@@ -43,7 +43,8 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
                            int m_base, int n_base, int lane) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int half = lane >> 5, l31 = lane & 31;
-    auto activate = [&](float v) { return act == 1 ? (v > 0.f ? v : 0.f) : act == 2 ? (v > 0.f ? v : 0.01f * v) : v; };
+    const float slope = td_act_slope(act);
+    auto activate = [&](float v) { return td_activate(v, slope); };
     float* outf = reinterpret_cast<float*>(outv);
     _Float16* outh = reinterpret_cast<_Float16*>(outv);
     const float* resf = reinterpret_cast<const float*>(residv);

@@ -41,12 +41,17 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
 TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
 }
+TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0));
+}
 
 // s_sleep: park the wave for ~64*n cycles (n <= 127); used to de-phase co-resident workgroups
 #define TD_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 
 // compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
 #define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define TD_PIN(x) asm volatile("" : "+v"(x))               // a use of x right here: the wait for a pending load of x is placed at this point, once
+#define TD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)    // the instruction scheduler moves nothing across this point
 #define TD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler a wave-uniform value is one (SGPR, usable as soffset)
 
 // fp16 inputs, fp32 accumulate: D(32x32) += A(32x16) * B(16x32); lane l supplies 8 consecutive k of row/column l&31 (k-group l>>5)

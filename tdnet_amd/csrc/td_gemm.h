@@ -156,13 +156,28 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     };
     // ---- epilogue of the c_tile-th tile of this workgroup (ONE copy in the code: the K loop below is a whole number of periods) ----
     int c_tile = 0;
+    f32x4 bias_pre = {0.f, 0.f, 0.f, 0.f};                           // the current tile's bias values of this lane (td_store_acc's 16-byte path)
+    const TdBuf bias_buf = td_make_buf(p.bias, (unsigned)p.N * 4u);
+    const bool bias_al = (((size_t)p.bias) & 15) == 0;
+    auto fetch_bias = [&]() {                                        // at the START of a tile: the values are needed a whole K loop later,
+        if (ROLE == 1 || NT != 2 || c_tile >= my_tiles) return;      // and a load issued in the epilogue would make it wait for the prefetch
+        const int lin = xbase + q + c_tile * G8;                     // of the next tile.  ROLE 1 (Winograd GEMMs): the bias belongs to
+        const int r0 = lin % per_batch, tn = r0 % p.tiles_n;         // the output transform.
+        const int chan = tn * BN + wn * WN + 4 * (l31 >> 1);
+        if (bias_al) bias_pre = td_buf_ld4(bias_buf, chan < p.N ? (unsigned)chan * 4u : TD_BUF_OOB, 0u);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias_pre[e] = td_buf_ld1(bias_buf, chan + e < p.N ? (unsigned)(chan + e) * 4u : TD_BUF_OOB, 0u);
+        }
+    };
     auto store_tile = [&]() {
         const int lin = xbase + q + c_tile * G8;
         ++c_tile;
         const int b = lin / per_batch, r0 = lin - b * per_batch;
         const int tm = r0 / p.tiles_n, tn = r0 - tm * p.tiles_n;
         float* outb = p.out + (size_t)b * p.MP * p.N;
-        td_store_acc<MT, NT>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane);
+        td_store_acc<MT, NT, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane,
+                             &bias_pre);
         zero_acc();
     };
 
@@ -180,6 +195,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     load_tile(ra, rb);                                               // global step 1
     __syncthreads();
     for (int t = 0; t < my_tiles; ++t) {
+        fetch_bias();
         for (int st = 0; st < nsteps; st += 2) {
             load_tile(ra2, rb2);
             compute(0, ra, rb);

@@ -97,6 +97,7 @@ TD_KERNEL void k_wino_in(WinoArgs p) {
 // thread = (tile, 4 output channels): Y = A^T m A, + bias (+ residual), activation, scatter to the 2x2 output pixels
 TD_KERNEL void k_wino_out(WinoArgs p) {
     const int CV = p.Cout >> 2;
+    const float slope = td_act_slope(p.act);
     const long total = (long)p.T * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -131,13 +132,8 @@ TD_KERNEL void k_wino_out(WinoArgs p) {
                 const size_t off = ((size_t)y * p.W + x) * p.Cout + cv * 4;
                 f32x4 o = o2[c] + b;
                 if (p.resid) o = o + td_ld4(p.resid + off);
-                if (p.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-                } else if (p.act == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.01f * o[e];
-                }
+                for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
                 td_st4(p.out + off, o);
             }
         }
@@ -202,6 +198,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
 // thread = (tile, 4 output channels): Y = A^T m A (4x4 pixels), + bias (+ residual), activation, scatter
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
     const int CV = p.Cout >> 2;
+    const float slope = td_act_slope(p.act);
     const long total = (long)p.T * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -234,13 +231,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
                 const size_t off = ((size_t)y * p.W + x) * p.Cout + cv * 4;
                 f32x4 o = o4[c] + b;
                 if (p.resid) o = o + td_ld4(p.resid + off);
-                if (p.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-                } else if (p.act == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.01f * o[e];
-                }
+                for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
                 td_st4(p.out + off, o);
             }
         }

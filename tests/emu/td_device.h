@@ -92,6 +92,8 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
     tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds))
 
 #define TD_SCHED_GROUP(mask, n) ((void)0)
+#define TD_SCHED_FENCE() ((void)0)
+#define TD_PIN(x) ((void)0)
 #define TD_UNIFORM(x) (x)
 #define TD_SLEEP(n) ((void)0)
 
@@ -111,6 +113,15 @@ TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     if ((unsigned long long)voff_bytes + 8 <= b.bytes) {       // the hardware range check ignores soffset ...
         if ((unsigned long long)voff_bytes + soff_bytes + 8 > b.bytes) abort();   // ... so kernels must keep the sum in range themselves
         memcpy(&v, b.p + soff_bytes + voff_bytes, 8);
+    }
+    return v;
+}
+
+TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
+    float v = 0.f;
+    if ((unsigned long long)voff_bytes + 4 <= b.bytes) {
+        if ((unsigned long long)voff_bytes + soff_bytes + 4 > b.bytes) abort();
+        memcpy(&v, b.p + soff_bytes + voff_bytes, 4);
     }
     return v;
 }
