@@ -79,16 +79,26 @@ struct ConvLds {
 TD_DEV float td_act_slope(int act) { return act == 1 ? 0.f : act == 2 ? 0.01f : 1.f; }
 TD_DEV float td_activate(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
 
-// The 16-byte path of td_store_acc, ONE copy of the code (two copies selected by "has residual" make the compiler hoist the lane
-// exchanges of all 8 MT row pairs above the dispatch: 64 more live VGPRs, accumulator spills).  So the residual is read
-// unconditionally through a buffer descriptor that has ZERO records when there is none -- the loads then return 0 without touching
-// memory -- and the eight vectors of a 32-row group are requested together before the first is used (one load, one wait, one
-// store per row pair would expose the memory latency sixteen times per tile; and behind a branch the compiler waits with
-// vmcnt(0), which also waits for the previous STORE).  NORES (compile time): no residual path at all.
-template <int MT, bool NORES>
+// The 16-byte path of td_store_acc.  Everything here is VALU work of a wave that has no MFMA to issue, and while the other resident
+// waves keep the matrix pipe busy such instructions issue slowly (tools/gemm_trace.hip: 6 us for an epilogue that takes 2 us on an
+// idle CU), so it is kept short:
+//  * addresses: one buffer descriptor over the output, a per-lane byte offset computed once, the row step added per store from an
+//    SGPR (N is uniform); rows >= M and lanes with channel >= N fall outside the descriptor and the hardware drops the store -- no
+//    64-bit address arithmetic, no predicate, no branch per store;
+//  * ONE copy of the code (two copies selected by "has residual" make the compiler hoist the lane exchanges of all 8 MT row pairs
+//    above the dispatch: 64 more live VGPRs, accumulator spills): the residual is read unconditionally through a descriptor with
+//    ZERO records when there is none -- such loads return 0 without touching memory -- and the eight vectors of a 32-row group are
+//    requested together before the first is used (one load, one wait, one store per row pair would expose the memory latency
+//    sixteen times per tile; and behind a branch the compiler waits with vmcnt(0), which also waits for the previous STORE);
+//  * NORES (compile time): no residual path at all;  PLAIN (compile time): no bias, no activation either (the Winograd GEMMs).
+template <int MT, bool NORES, bool PLAIN>
 TD_DEV void td_store_acc16(const f32x16 (&acc)[MT][2], float* out, const float* resid, int M, int N, float slope,
                            int m_base, int chan, bool cok, int half, int odd, f32x4 bv) {
-    const TdBuf res_buf = td_make_buf(resid, (NORES || !resid) ? 0u : (unsigned)M * (unsigned)N * 4u);
+    const unsigned bytes = (unsigned)M * (unsigned)N * 4u;
+    const TdBuf out_buf = td_make_buf(out, bytes);
+    const TdBuf res_buf = td_make_buf(resid, (NORES || !resid) ? 0u : bytes);
+    const unsigned base = cok ? ((unsigned)(m_base + 4 * half + odd) * (unsigned)N + (unsigned)chan) * 4u : TD_BUF_OOB;
+    const unsigned row_bytes = (unsigned)N * 4u;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         f32x4 rv[8];
@@ -96,8 +106,7 @@ TD_DEV void td_store_acc16(const f32x16 (&acc)[MT][2], float* out, const float* 
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
                 const int r = 2 * rp;
-                const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
-                rv[rp] = td_buf_ld4(res_buf, (m < M && cok) ? ((unsigned)m * (unsigned)N + (unsigned)chan) * 4u : TD_BUF_OOB, 0u);
+                rv[rp] = td_buf_ld4(res_buf, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes, 0u);
             }
             TD_SCHED_FENCE();
         }
@@ -109,18 +118,20 @@ TD_DEV void td_store_acc16(const f32x16 (&acc)[MT][2], float* out, const float* 
             f32x4 v;
             if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
             else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
-            const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
-            v = v + bv;
+            if (!PLAIN) v = v + bv;
             if (!NORES) v = v + rv[rp];
+            if (!PLAIN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = td_activate(v[e], slope);
-            if (m < M && cok) td_st4(out + (size_t)m * N + chan, v);
+                for (int e = 0; e < 4; ++e) v[e] = td_activate(v[e], slope);
+            }
+            td_buf_st4(out_buf, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes, 0u, v);
             TD_SCHED_FENCE();                                       // one row pair at a time (bounds the live registers)
         }
     }
 }
 
-template <int MT, int NT, bool NORES = false>
+// PLAIN: the caller guarantees bias == 0, act == 0, resid == nullptr (they are not looked at on the 16-byte path)
+template <int MT, int NT, bool NORES = false, bool PLAIN = false>
 TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* bias, const float* resid, int M, int N, int act,
                          int m_base, int n_base, int lane, const f32x4* bias_pre = nullptr) {
     // bias_pre: this lane's four bias values (channels n_base + 4 (l31 >> 1) ..), fetched by the caller long before the epilogue
@@ -129,12 +140,13 @@ TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* b
     const float slope = td_act_slope(act);
     auto activate = [&](float v) { return td_activate(v, slope); };
     if constexpr (NT == 2) {
-        if ((N & 3) == 0 && ((((size_t)out) | ((size_t)resid)) & 15) == 0 && (size_t)M * N < (1u << 29)) {   // wave-uniform
+        if ((N & 3) == 0 && ((((size_t)out) | ((size_t)resid)) & 15) == 0 && (size_t)(M + 128) * N < (1u << 29)) {   // wave-uniform
             const int odd = l31 & 1;
             const int chan = n_base + 4 * (l31 >> 1);
             const bool cok = chan < N;
-            f32x4 bv;
-            if (bias_pre) bv = *bias_pre;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (PLAIN) {}
+            else if (bias_pre) bv = *bias_pre;
             else {
                 // one unconditional (range-checked) load and its wait HERE: a load under `if (cok)` leaves the compiler unsure whether
                 // it is pending, and it then waits with vmcnt(0) before every use -- i.e. for the previous store, sixteen times
@@ -147,7 +159,7 @@ TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* b
                 }
                 TD_PIN(bv);
             }
-            td_store_acc16<MT, NORES>(acc, out, resid, M, N, slope, m_base, chan, cok, half, odd, bv);
+            td_store_acc16<MT, NORES || PLAIN, PLAIN>(acc, out, resid, M, N, slope, m_base, chan, cok, half, odd, bv);
             return;
         }
     }

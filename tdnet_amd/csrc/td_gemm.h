@@ -26,10 +26,21 @@ struct GemmArgs {
     int tiles_m, tiles_n; // per batch
     int MP;               // rows between consecutive batches of a and out (>= M; padded planes of the Winograd workspaces, td_wino.h)
     int stagger;          // tdnet_opts.stagger (units of 1/8 tile): start delay of the co-resident workgroups, see the kernel
+#ifdef TD_GEMM_TRACE      // tools/gemm_trace.hip only: per workgroup 64 x u64 -- HW_ID, XCC_ID, start, then (end of K loop, end of epilogue) per tile
+    unsigned long long* trace;   // in s_memrealtime ticks (100 MHz); TD_GEMM_TRACE == 2: the end of every two-step period as well
+#endif
 };
+#ifdef TD_GEMM_TRACE
+#define TD_TRACE(slot, val) do { if (threadIdx.x == 0 && (slot) < 64) p.trace[(size_t)blockIdx.x * 64 + (slot)] = (val); } while (0)
+#define TD_NOW() __builtin_amdgcn_s_memrealtime()
+#else
+#define TD_TRACE(slot, val) ((void)0)
+#define TD_NOW() 0ull
+#endif
 
-// ROLE only names the launch for the profiler (rocprofv3 aggregates by symbol): 0 = a stride-1 1x1 convolution, 1 = the (m+2)^2
-// batched GEMMs of a Winograd conv -- the frame's dominant kernel, whose roofline bench.py reports.  Same code either way.
+// ROLE names the launch for the profiler (rocprofv3 aggregates by symbol): 0 = a stride-1 1x1 convolution, 1 = the (m+2)^2
+// batched GEMMs of a Winograd conv -- the frame's dominant kernel, whose roofline bench.py reports.  Same K loop; ROLE 1 has the
+// plain epilogue (bias, activation and residual belong to the Winograd output transform: GemmArgs.bias / act / resid are ignored).
 template <int BM, int BN, int WGM, int WGN, int ROLE>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
@@ -176,13 +187,19 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
         const int b = lin / per_batch, r0 = lin - b * per_batch;
         const int tm = r0 / p.tiles_n, tn = r0 - tm * p.tiles_n;
         float* outb = p.out + (size_t)b * p.MP * p.N;
-        td_store_acc<MT, NT, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane,
+        td_store_acc<MT, NT, ROLE == 1, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane,
                              &bias_pre);
         zero_acc();
     };
 
     zero_acc();
     loader_enter_tile();
+#ifdef TD_GEMM_TRACE
+    int tslot = 3;
+    TD_TRACE(0, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID
+    TD_TRACE(1, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));     // HW_REG_XCC_ID
+    TD_TRACE(2, TD_NOW());
+#endif
     // Two register sets: while global step g is multiplied, step g+1 moves registers -> LDS and step g+2 is in flight.  (A
     // third set -- three steps of lookahead -- was measured: no gain, 256 VGPRs and spills.)  K/32 is even (host check), so a
     // tile is a whole number of two-step periods and the epilogue appears once.
@@ -196,15 +213,25 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     __syncthreads();
     for (int t = 0; t < my_tiles; ++t) {
         fetch_bias();
-        for (int st = 0; st < nsteps; st += 2) {
-            load_tile(ra2, rb2);
+        int st = 0;
+        do {                                                         // at least one period (nsteps >= 2): with a zero-trip path into the
+            load_tile(ra2, rb2);                                     // epilogue the compiler waits there for ALL loads in flight
             compute(0, ra, rb);
             __syncthreads();
             load_tile(ra, rb);                                       // past the last tile: clamped to it, never consumed
             compute(1, ra2, rb2);
             __syncthreads();
-        }
+#if defined(TD_GEMM_TRACE) && TD_GEMM_TRACE == 2
+            if (st + 2 < nsteps) { TD_TRACE(tslot, TD_NOW()); ++tslot; }
+#endif
+        } while ((st += 2) < nsteps);
+#ifdef TD_GEMM_TRACE
+        TD_TRACE(tslot, TD_NOW()); ++tslot;
         store_tile();
+        TD_TRACE(tslot, TD_NOW()); ++tslot;
+#else
+        store_tile();
+#endif
     }
 }
 

@@ -117,6 +117,12 @@ TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return v;
 }
 
+TD_DEV void td_buf_st4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x4 v) {
+    if ((unsigned long long)voff_bytes + 16 <= b.bytes) {
+        if ((unsigned long long)voff_bytes + soff_bytes + 16 > b.bytes) abort();
+        memcpy(const_cast<char*>(b.p) + soff_bytes + voff_bytes, &v, 16);
+    }
+}
 TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     float v = 0.f;
     if ((unsigned long long)voff_bytes + 4 <= b.bytes) {
