@@ -82,24 +82,38 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 4u, w_bytes = (unsigned)nsteps * w_step_bytes;
 
     // ---- loader state (runs two global steps ahead of the MFMAs) -------------------------------------------------
+    // Tile coordinates are advanced INCREMENTALLY (tile list = every G8-th position: add G8's (batch, tile_m, tile_n) digits with
+    // carries) -- two integer divisions per tile are ~80 dependent scalar instructions, and instructions other than MFMAs issue slowly
+    // while the co-resident waves keep the matrix pipe busy (tools/gemm_trace.hip: the period that enters a tile takes 1.5x).
+    struct TilePos { int b, tm, tn; };
+    const int lin0 = xbase + q, r00 = lin0 % per_batch;
+    const TilePos pos0 = {lin0 / per_batch, r00 / p.tiles_n, r00 % p.tiles_n};
+    const int dB = G8 / per_batch, dR = G8 % per_batch, dTm = dR / p.tiles_n, dTn = dR % p.tiles_n;
+    auto advance = [&](TilePos& t) {
+        t.tn += dTn;
+        const int c = t.tn >= p.tiles_n ? 1 : 0;
+        t.tn -= c ? p.tiles_n : 0;
+        t.tm += dTm + c;
+        const int c2 = t.tm >= p.tiles_m ? 1 : 0;
+        t.tm -= c2 ? p.tiles_m : 0;
+        t.b += dB + c2;
+    };
     int l_tile = 0, l_step = 0;                                      // index into my tile list / K step inside it
+    TilePos lpos = pos0;
     TdBuf a_buf, w_buf;
     unsigned a_off[AL], b_off[BL];
     auto loader_enter_tile = [&]() {
-        const int lin = xbase + q + (l_tile < my_tiles ? l_tile : my_tiles - 1) * G8;   // past the end: stay on the last tile
-        const int b = lin / per_batch, r = lin - b * per_batch;
-        const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
-        a_buf = td_make_buf(p.a + (size_t)b * p.MP * p.K, a_bytes);
-        w_buf = td_make_buf(p.wp + (size_t)b * nsteps * 8 * p.NPad * 4, w_bytes);
+        a_buf = td_make_buf(p.a + (size_t)lpos.b * p.MP * p.K, a_bytes);
+        w_buf = td_make_buf(p.wp + (size_t)lpos.b * nsteps * 8 * p.NPad * 4, w_bytes);
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            const int m = tm * BM + a_row + 32 * i;
+            const int m = lpos.tm * BM + a_row + 32 * i;
             a_off[i] = m < p.M ? ((unsigned)m * (unsigned)p.K + (unsigned)a_kq * 4u) * 4u : TD_BUF_OOB;
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) {
             const int idx = tid + 256 * i, kq = idx / BN, n = idx % BN;
-            b_off[i] = (unsigned)(kq * p.NPad + tn * BN + n) * 16u;
+            b_off[i] = (unsigned)(kq * p.NPad + lpos.tn * BN + n) * 16u;
         }
     };
     auto load_tile = [&](f32x4 (&ra)[AL], f32x4 (&rb)[BL]) {
@@ -109,7 +123,10 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
         const unsigned wsoff = (unsigned)l_step * w_step_bytes;
 #pragma unroll
         for (int i = 0; i < BL; ++i) rb[i] = td_buf_ld4(w_buf, b_off[i], wsoff);
-        if (++l_step == nsteps) { l_step = 0; ++l_tile; loader_enter_tile(); }
+        if (++l_step == nsteps) {
+            l_step = 0;
+            if (++l_tile < my_tiles) { advance(lpos); loader_enter_tile(); }   // past the end: stay on the last tile (never consumed)
+        }
     };
     auto store_a = [&](int buf, int i, const f32x4 (&ra)[AL]) {
         td_st4(lds + buf * L::BUF_FLOATS + a_kq * L::A_STRIDE + (a_row + 32 * i) * 4, ra[i]);
@@ -165,16 +182,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
             }
         }
     };
-    // ---- epilogue of the c_tile-th tile of this workgroup (ONE copy in the code: the K loop below is a whole number of periods) ----
-    int c_tile = 0;
+    // ---- epilogue (ONE copy in the code: the K loop below is a whole number of periods) ----------------------------
     f32x4 bias_pre = {0.f, 0.f, 0.f, 0.f};                           // the current tile's bias values of this lane (td_store_acc's 16-byte path)
     const TdBuf bias_buf = td_make_buf(p.bias, (unsigned)p.N * 4u);
     const bool bias_al = (((size_t)p.bias) & 15) == 0;
+    TilePos spos = pos0;                                             // the tile being multiplied
     auto fetch_bias = [&]() {                                        // at the START of a tile: the values are needed a whole K loop later,
-        if (ROLE == 1 || NT != 2 || c_tile >= my_tiles) return;      // and a load issued in the epilogue would make it wait for the prefetch
-        const int lin = xbase + q + c_tile * G8;                     // of the next tile.  ROLE 1 (Winograd GEMMs): the bias belongs to
-        const int r0 = lin % per_batch, tn = r0 % p.tiles_n;         // the output transform.
-        const int chan = tn * BN + wn * WN + 4 * (l31 >> 1);
+        if (ROLE == 1 || NT != 2) return;                            // and a load issued in the epilogue would make it wait for the prefetch
+        const int chan = spos.tn * BN + wn * WN + 4 * (l31 >> 1);    // of the next tile.  ROLE 1: no bias (plain epilogue).
         if (bias_al) bias_pre = td_buf_ld4(bias_buf, chan < p.N ? (unsigned)chan * 4u : TD_BUF_OOB, 0u);
         else {
 #pragma unroll
@@ -182,14 +197,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
         }
     };
     auto store_tile = [&]() {
-        const int lin = xbase + q + c_tile * G8;
-        ++c_tile;
-        const int b = lin / per_batch, r0 = lin - b * per_batch;
-        const int tm = r0 / p.tiles_n, tn = r0 - tm * p.tiles_n;
-        float* outb = p.out + (size_t)b * p.MP * p.N;
-        td_store_acc<MT, NT, ROLE == 1, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, tm * BM + wm * WM, tn * BN + wn * WN, lane,
+        float* outb = p.out + (size_t)spos.b * p.MP * p.N;
+        td_store_acc<MT, NT, ROLE == 1, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, spos.tm * BM + wm * WM, spos.tn * BN + wn * WN, lane,
                              &bias_pre);
         zero_acc();
+        advance(spos);
     };
 
     zero_acc();
