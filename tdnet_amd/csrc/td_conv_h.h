@@ -49,14 +49,39 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
     _Float16* outh = reinterpret_cast<_Float16*>(outv);
     const float* resf = reinterpret_cast<const float*>(residv);
     const _Float16* resh = reinterpret_cast<const _Float16*>(residv);
-    if (NT == 2 && (N & 3) == 0 && ((((size_t)outv) | ((size_t)residv)) & 15) == 0) {       // wave-uniform
+    if (NT == 2 && (N & 3) == 0 && ((((size_t)outv) | ((size_t)residv)) & 15) == 0 && (size_t)(M + 128) * N < (1u << 29)) {   // wave-uniform
+        // as td_store_acc16 (td_conv.h): buffer-addressed, the 8 residual vectors of a 32-row group requested together, no predicates
         const int odd = l31 & 1;
         const int chan = n_base + 4 * (l31 >> 1);
         const bool cok = chan < N;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (cok) { bv[0] = bias[chan]; bv[1] = bias[chan + 1]; bv[2] = bias[chan + 2]; bv[3] = bias[chan + 3]; }
+        constexpr unsigned EO = OUT16 ? 2u : 4u, ER = RES16 ? 2u : 4u;
+        const unsigned elems = (unsigned)M * (unsigned)N;
+        const TdBuf out_buf = td_make_buf(outf, elems * EO);
+        const TdBuf res_buf = td_make_buf(resf, residv ? elems * ER : 0u);
+        const TdBuf bias_buf = td_make_buf(bias, (unsigned)N * 4u);
+        f32x4 bv;
+        if ((((size_t)bias) & 15) == 0) bv = td_buf_ld4(bias_buf, cok ? (unsigned)chan * 4u : TD_BUF_OOB, 0u);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = td_buf_ld1(bias_buf, cok ? (unsigned)(chan + e) * 4u : TD_BUF_OOB, 0u);
+        }
+        TD_PIN(bv);
+        const unsigned e0 = (unsigned)(m_base + 4 * half + odd) * (unsigned)N + (unsigned)chan;
+        const unsigned base_o = cok ? e0 * EO : TD_BUF_OOB, base_r = cok ? e0 * ER : TD_BUF_OOB;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            f32x4 rv[8];
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int r = 2 * rp;
+                const unsigned rows = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)N;
+                if (RES16) {
+                    const f16x4 rh = __builtin_bit_cast(f16x4, td_buf_ld2(res_buf, base_r + rows * ER, 0u));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[rp][e] = (float)rh[e];
+                } else rv[rp] = td_buf_ld4(res_buf, base_r + rows * ER, 0u);
+            }
+            TD_SCHED_FENCE();
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
                 const int r = 2 * rp;
@@ -65,25 +90,17 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
                 f32x4 v;
                 if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
                 else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
-                const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half + odd;
-                if (m >= M || !cok) continue;
-                const size_t o = (size_t)m * N + chan;
-                v = v + bv;
-                if (residv) {
-                    if (RES16) {
-                        const f16x4 rh = *reinterpret_cast<const f16x4*>(resh + o);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rh[e];
-                    } else v = v + td_ld4(resf + o);
-                }
+                v = v + bv + rv[rp];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = activate(v[e]);
+                const unsigned rows = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)N;
                 if (OUT16) {
                     f16x4 oh;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) oh[e] = (_Float16)v[e];
-                    *reinterpret_cast<f16x4*>(outh + o) = oh;
-                } else td_st4(outf + o, v);
+                    td_buf_st2(out_buf, base_o + rows * EO, 0u, __builtin_bit_cast(f32x2, oh));
+                } else td_buf_st4(out_buf, base_o + rows * EO, 0u, v);
+                TD_SCHED_FENCE();
             }
         }
         return;

@@ -123,6 +123,12 @@ TD_DEV void td_buf_st4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x4 
         memcpy(const_cast<char*>(b.p) + soff_bytes + voff_bytes, &v, 16);
     }
 }
+TD_DEV void td_buf_st2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x2 v) {
+    if ((unsigned long long)voff_bytes + 8 <= b.bytes) {
+        if ((unsigned long long)voff_bytes + soff_bytes + 8 > b.bytes) abort();
+        memcpy(const_cast<char*>(b.p) + soff_bytes + voff_bytes, &v, 8);
+    }
+}
 TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     float v = 0.f;
     if ((unsigned long long)voff_bytes + 4 <= b.bytes) {
