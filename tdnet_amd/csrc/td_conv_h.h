@@ -127,8 +127,13 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
 
 // ConvArgs as td_conv.h, except: wp = packed fp16 weights [nsteps][8][CoutPad][8 halfs], nsteps = (Cin/64)*KS*KS; with IN16 `in` and
 // `resid` point at fp16 maps, with OUT16 `out` does.
-template <int BM, int BN, int WGM, int WGN, int KS, bool IN16, bool OUT16>
+//
+// STEM (the 7x7 stride-2 conv on the 4-channel padded image, fp32 in HBM): a 16-byte LDS slot = 8 halfs = the 4 channels of TWO
+// horizontally adjacent taps, a K step = 8 slots x 2 = 16 taps = two kernel rows of 8 (7 + one zero-weight column), 4 steps = rows
+// 0..7 (row 7: zero weights).  K = 256 for 147 products -- 57 % useful, on a pipe 16x faster than the fp32 one.
+template <int BM, int BN, int WGM, int WGN, int KS, bool IN16, bool OUT16, bool STEM = false>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
+    static_assert(!STEM || (!IN16 && KS == 7), "the stem reads the fp32 image");
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
     constexpr int AL = BM / 32, BL = BN / 32;          // 16-byte LDS slots per thread per step (A: 8 channels of one pixel)
@@ -158,6 +163,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         const int oy = m / p.Wo, ox = m - oy * p.Wo;
         a_by[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 28);
         a_bx[i] = ox * p.stride - p.pad;
+        if constexpr (STEM) {                           // slot a_kq = taps (ky, kx), (ky, kx + 1) with ky = a_kq / 4 (+ 2 per step), kx = 2 (a_kq % 4)
+            a_by[i] += a_kq >> 2;
+            a_bx[i] += 2 * (a_kq & 3);
+            a_off[i] = ((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * 16u;
+        } else
         a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (unsigned)a_kq * 8u) * EB;
     }
     const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * EB);
@@ -172,6 +182,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
 
     int l_step = 0, l_chunk = 0, l_tap = 0;
     auto load_tile = [&](f32x4 (&ra)[AR], f32x4 (&rb)[BL]) {
+        if constexpr (STEM) {
+            const unsigned delta = (unsigned)(2 * l_step * p.W) * 16u;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int iy = a_by[i] + 2 * l_step, ix = a_bx[i];
+                const bool oky = (unsigned)iy < (unsigned)p.H;
+                ra[2 * i] = td_buf_ld4(in_buf, oky && (unsigned)ix < (unsigned)p.W ? a_off[i] + delta : TD_BUF_OOB, 0u);
+                ra[2 * i + 1] = td_buf_ld4(in_buf, oky && (unsigned)(ix + 1) < (unsigned)p.W ? a_off[i] + delta + 16u : TD_BUF_OOB, 0u);
+            }
+            const unsigned wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;
+#pragma unroll
+            for (int i = 0; i < BL; ++i) rb[i] = td_buf_ld4(w_buf, b_off[i], wsoff);
+            ++l_step;
+            return;
+        }
         const int ky = l_tap / KS;
         const int dy = ky * p.dil, dx = (l_tap - ky * KS) * p.dil;
         const unsigned delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * EB;
@@ -281,6 +306,35 @@ static inline void conv_pack_weights_h(const float* w, int Cout, int Cin, int KS
                     o[e] = (_Float16)(n < Cout ? w[((size_t)n * Cin + ci) * ntaps + tap] : 0.f);
                 }
             }
+}
+
+// the 7x7 stem (kernel comment): [4 steps][8 slots kq][CoutPad][8 halfs], e = (tap of the pair) * 4 + channel
+static inline int conv_nsteps_stem_h() { return 4; }
+static inline void conv_pack_weights_stem_h(const float* w, int Cout, ConvTile tile, _Float16* dst) {
+    const ConvTileDims d = conv_tile_dims(tile);
+    const int WN = d.BN / d.WGN, NT = WN / 32;
+    const int CoutPad = conv_cout_pad(Cout, tile);
+    for (int step = 0; step < 4; ++step)
+        for (int kq = 0; kq < 8; ++kq)
+            for (int slot = 0; slot < CoutPad; ++slot) {
+                const int tn = slot / d.BN, within = slot % d.BN, wn = within / WN, w2 = within % WN;
+                const int nt = w2 / 32, j = w2 % 32;
+                const int n = tn * d.BN + wn * WN + j * NT + nt;
+                _Float16* o = dst + (((size_t)step * 8 + kq) * CoutPad + slot) * 8;
+                for (int e = 0; e < 8; ++e) {
+                    const int ky = (kq >> 2) + 2 * step, kx = 2 * (kq & 3) + (e >> 2), c = e & 3;
+                    o[e] = (_Float16)((n < Cout && c < 3 && ky < 7 && kx < 7) ? w[(((size_t)n * 3 + c) * 7 + ky) * 7 + kx] : 0.f);
+                }
+            }
+}
+// 64 output channels: the 128 x 64 block (weights packed for CT_128x64 / CT_128x64_DEEP)
+static inline bool conv_stem_h_supports(ConvTile tile) { return tile == CT_128x64 || tile == CT_128x64_DEEP; }
+static inline void conv_launch_stem_h(ConvArgs a, bool out16, hipStream_t s) {
+    a.tiles_n = a.CoutPad / 64;
+    const int grid = ((a.M + 127) / 128) * a.tiles_n;
+    const int lds = ConvLdsH<128, 64>::BYTES;
+    if (out16) TD_LAUNCH((k_conv_igemm_h<128, 64, 4, 1, 7, false, true, true>), dim3(grid), dim3(256), lds, s, a);
+    else TD_LAUNCH((k_conv_igemm_h<128, 64, 4, 1, 7, false, false, true>), dim3(grid), dim3(256), lds, s, a);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool IN16, bool OUT16>

@@ -193,10 +193,18 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         return 0;
     }
     L.h16 = o.precision && !stem && Cin % 64 == 0;
+    const bool stem16 = o.precision && stem && KS == 7 && stride == 2 && Cout <= 64;    // fp16-MFMA stem (td_conv_h.h)
     const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && o.gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
     L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout, deep) : conv_pick_tile((int)M, Cout, deep);
     L.CoutPad = conv_cout_pad(Cout, L.tile);
-    if (L.h16) {
+    if (stem16 && conv_stem_h_supports(L.tile)) {
+        L.h16 = true;
+        L.nsteps = conv_nsteps_stem_h();
+        std::vector<_Float16> packed((size_t)L.nsteps * 8 * L.CoutPad * 8);
+        conv_pack_weights_stem_h(w.data(), Cout, L.tile, packed.data());
+        TD_HIP(hipMalloc((void**)&L.d_wp, packed.size() * sizeof(_Float16)));
+        TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    } else if (L.h16) {
         L.nsteps = conv_nsteps_h(Cin, KS);
         std::vector<_Float16> packed((size_t)L.nsteps * 8 * L.CoutPad * 8);
         conv_pack_weights_h(w.data(), Cout, Cin, KS, L.tile, packed.data());
@@ -659,8 +667,9 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         (void)NC;
     }
     // precision = 1: every map between two convs of the backbone is stored as fp16 (half the conv input / output bytes; td_conv_h.h).
-    // The rim stays fp32: the stem conv's output (fp32 kernel), and c4 -- the LAST conv of the backbone writes fp32 for the pyramid,
-    // Encoding and head kernels, which keep fp32 storage.
+    // The rim: the 7x7 stem runs on the fp16 MFMA from the fp32 image and writes an fp16 map (the 3x3 deep stem's first conv stays an
+    // fp32 kernel with an fp32 map), and c4 -- the LAST conv of the backbone -- writes fp32 for the pyramid, Encoding and head
+    // kernels, which keep fp32 storage.
     n->act16 = n->opts.precision != 0;
     if (n->act16)
         for (auto& L : n->paths) {
@@ -673,6 +682,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     if (n->act16)
         for (auto& L : n->paths) {
             if (n->deep) { L.stem2.out16 = true; L.stem3.in16 = L.stem3.out16 = true; }
+            else if (L.stem.h16) L.stem.out16 = true;                  // fp16-MFMA 7x7 stem: its map is fp16 too (max-pool reads fp16)
             for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
                 BlockLayers& B = L.blocks[bi];
                 const bool last = bi + 1 == L.blocks.size();
@@ -771,7 +781,8 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
-    if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
+    if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
+    else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
@@ -926,7 +937,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     } else {
         TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1, s));
     }
-    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->opts.fusion, n->act16 ? (n->deep ? 2 : 1) : 0);
+    run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->opts.fusion, n->act16 ? ((n->deep || L.stem.out16) ? 2 : 1) : 0);
     int ch = n->H2, cw = n->W2;
     for (auto& B : L.blocks) {
         int oh, ow;

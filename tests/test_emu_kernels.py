@@ -180,6 +180,8 @@ def test_fp16_storage_conv_attention_and_pipeline(lib, golden_dir):
     variant, 1x1 / 3x3, stride, dilation, ragged shapes, residual), the fp16-MFMA attention kernel (both shapes, ragged, a dominating
     key, the LayerNorm statistics of its epilogue), then the td2 pipeline in that mode against the goldens of the real (fp32)
     reference with the gate this mode is held to: max|dlogit| <= 3e-2 and >= 99.5 % of the labels equal."""
+    for H, W in ((33, 65), (18, 23), (7, 9)):           # the 7x7 stem on the fp16 MFMA (two taps per LDS slot, borders on all sides)
+        opcheck.stem(lib, MEM, H, W, tol=1e-2, opts={"precision": 1})
     for tile in (3, 4, 5):
         opcheck.conv_f16io(lib, MEM, 13, 21, 128, 96, 3, 1, 1, 1, True, tile)
         opcheck.conv_f16io(lib, MEM, 7, 9, 64, 64, 1, 1, 1, 0, False, tile)
