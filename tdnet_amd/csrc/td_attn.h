@@ -391,29 +391,48 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             kshift[j] = half ? other : kshift[j];
         }
     }
+    // Stores and residual loads go through buffer descriptors (32-bit offsets, rows >= Lq get the out-of-range offset and are dropped /
+    // read as zero); the residual rows are requested eight at a time BEFORE the first is used -- a load, a wait and a store per row
+    // exposes the memory latency sixteen times.  No residual: a descriptor with zero records (loads return 0, no memory access).
+    const TdBuf out_buf = td_make_buf(p.out, 0x80000000u);
+    const TdBuf res_buf = td_make_buf(p.resid, p.resid ? 0x80000000u : 0u);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int q = q0 + row;
-        if (q >= p.Lq) continue;
-        float l = 0.f;
+    for (int rg = 0; rg < 2; ++rg) {
+        f32x4 rv[8];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
-        const float inv = 1.0f / l;
-        const size_t off = (size_t)q * LDV + cb;
-        if (NT == 4) {
-            f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[NT - 2][r] * inv, acc[NT - 1][r] * inv};
-            o = o + bv;
-            if (p.resid) o = o + td_ld4(p.resid + off);
-            td_st4(p.out + off, o);
-            if (ln) { const f32x4 d = o - kshift; s1 = s1 + d; s2 = s2 + d * d; }
-        } else {
-            f32x2 o = {acc[0][r] * inv + bv[0], acc[1][r] * inv + bv[1]};
-            if (p.resid) o = o + *reinterpret_cast<const f32x2*>(p.resid + off);
-            *reinterpret_cast<f32x2*>(p.out + off) = o;
-            if (ln) {
-                const float d0 = o[0] - kshift[0], d1 = o[1] - kshift[1];
-                s1[0] += d0; s1[1] += d1; s2[0] += d0 * d0; s2[1] += d1 * d1;
+        for (int i = 0; i < 8; ++i) {
+            const int r = rg * 8 + i;
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const unsigned off = q < p.Lq ? ((unsigned)q * (unsigned)LDV + (unsigned)cb) * 4u : TD_BUF_OOB;
+            if (NT == 4) rv[i] = td_buf_ld4(res_buf, off, 0u);
+            else { const f32x2 t = td_buf_ld2(res_buf, off, 0u); rv[i] = f32x4{t[0], t[1], 0.f, 0.f}; }
+        }
+        TD_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = rg * 8 + i;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int q = q0 + row;
+            const bool live = q < p.Lq;
+            const unsigned off = live ? ((unsigned)q * (unsigned)LDV + (unsigned)cb) * 4u : TD_BUF_OOB;
+            float l = 0.f;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
+            const float inv = 1.0f / l;
+            if (NT == 4) {
+                f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[NT - 2][r] * inv, acc[NT - 1][r] * inv};
+                o = o + bv;
+                o = o + rv[i];
+                td_buf_st4(out_buf, off, 0u, o);
+                if (ln && live) { const f32x4 d = o - kshift; s1 = s1 + d; s2 = s2 + d * d; }
+            } else {
+                f32x2 o = {acc[0][r] * inv + bv[0], acc[1][r] * inv + bv[1]};
+                o[0] += rv[i][0]; o[1] += rv[i][1];
+                td_buf_st2(out_buf, off, 0u, o);
+                if (ln && live) {
+                    const float d0 = o[0] - kshift[0], d1 = o[1] - kshift[1];
+                    s1[0] += d0; s1[1] += d1; s2[0] += d0 * d0; s2[1] += d1 * d1;
+                }
             }
         }
     }

@@ -210,22 +210,39 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention_h(AttnArgsH p) {
             kshift[j] = half ? other : v;
         }
     }
+    // buffer-addressed (32-bit offsets; rows >= Lq fall outside the descriptor), residual rows requested four at a time before the first
+    // is used (td_attn.h); no residual: a descriptor with zero records
+    const TdBuf out_buf = td_make_buf(p.out, 0x80000000u);
+    const TdBuf res_buf = td_make_buf(p.resid, p.resid ? 0x80000000u : 0u);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int q = q0 + row;
-        if (q >= p.Lq) continue;
-        float l = 0.f;
+    for (int rg = 0; rg < 4; ++rg) {
+        float rv[4][NT];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
-        const float inv = 1.0f / l;
+        for (int i = 0; i < 4; ++i) {
+            const int r = rg * 4 + i;
+            const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const unsigned off = q < p.Lq ? ((unsigned)q * (unsigned)LDV + (unsigned)(cb0 + l31)) * 4u : TD_BUF_OOB;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const size_t off = (size_t)q * LDV + cb0 + 32 * j + l31;
-            float o = acc[j][r] * inv + bv[j];
-            if (p.resid) o += p.resid[off];
-            p.out[off] = o;
-            if (ln) { const float d = o - kshift[j]; s1[j] += d; s2[j] += d * d; }
+            for (int j = 0; j < NT; ++j) rv[i][j] = td_buf_ld1(res_buf, off, (unsigned)(128 * j));
+        }
+        TD_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rg * 4 + i;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int q = q0 + row;
+            const bool live = q < p.Lq;
+            const unsigned off = live ? ((unsigned)q * (unsigned)LDV + (unsigned)(cb0 + l31)) * 4u : TD_BUF_OOB;
+            float l = 0.f;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) l += red2[(qw * CW + c) * 32 + row];
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float o = acc[j][r] * inv + bv[j] + rv[i][j];
+                td_buf_st1(out_buf, off, (unsigned)(128 * j), o);
+                if (ln && live) { const float d = o - kshift[j]; s1[j] += d; s2[j] += d * d; }
+            }
         }
     }
     if (ln) {

@@ -50,6 +50,9 @@ TD_DEV void td_buf_st2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x2 
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b.r, voff_bytes, soff_bytes, 0);
 }
+TD_DEV void td_buf_st1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voff_bytes, soff_bytes, 0);
+}
 TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0));
 }

@@ -129,6 +129,12 @@ TD_DEV void td_buf_st2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x2 
         memcpy(const_cast<char*>(b.p) + soff_bytes + voff_bytes, &v, 8);
     }
 }
+TD_DEV void td_buf_st1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, float v) {
+    if ((unsigned long long)voff_bytes + 4 <= b.bytes) {
+        if ((unsigned long long)voff_bytes + soff_bytes + 4 > b.bytes) abort();
+        memcpy(const_cast<char*>(b.p) + soff_bytes + voff_bytes, &v, 4);
+    }
+}
 TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     float v = 0.f;
     if ((unsigned long long)voff_bytes + 4 <= b.bytes) {
