@@ -37,12 +37,29 @@ struct WinoArgs {
     // applies to the normalised map).  ln_mean == nullptr: off.
     const float* ln_mean; const float* ln_rstd; const float* ln_g; const float* ln_b;
 };
-TD_DEV f32x4 td_wino_ld(const WinoArgs& p, int y, int x, int cv, const f32x4& m4, const f32x4& r4) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-        const size_t pix = (size_t)y * p.W + x;
-        z = td_ld4(p.in + pix * p.C + cv * 4);
-        if (p.ln_mean) z = (z - m4) * r4 * p.ln_g[pix] + p.ln_b[pix];
+// Buffer descriptors of a transform: every access is an UNCONDITIONAL range-checked buffer access (a tap outside the image, an output
+// pixel outside the map or a missing residual turn into an out-of-range offset / a zero-record descriptor) -- no branch around any
+// load or store, so all loads of a thread are in flight together and the waits are exact counts.  With `if (inside) load` /
+// `if (resid) load ... store` the residual of the output transform was one load, one wait and one store sixteen times over.
+struct WinoBufs { TdBuf in, g, b, resid, out; };
+TD_DEV WinoBufs td_wino_bufs(const WinoArgs& p) {
+    WinoBufs w;
+    const unsigned pix = (unsigned)p.H * (unsigned)p.W;
+    w.in = td_make_buf(p.in, pix * (unsigned)p.C * 4u);
+    w.g = td_make_buf(p.ln_g, p.ln_mean ? pix * 4u : 0u);
+    w.b = td_make_buf(p.ln_b, p.ln_mean ? pix * 4u : 0u);
+    w.resid = td_make_buf(p.resid, p.resid ? pix * (unsigned)p.Cout * 4u : 0u);
+    w.out = td_make_buf(p.out, pix * (unsigned)p.Cout * 4u);
+    return w;
+}
+// one patch element (4 channels); outside the image: zeros (also under the fused LayerNorm: gamma and beta read as 0 there)
+TD_DEV f32x4 td_wino_ld(const WinoArgs& p, const WinoBufs& w, int y, int x, int cv, const f32x4& m4, const f32x4& r4) {
+    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    const unsigned pix = (unsigned)y * (unsigned)p.W + (unsigned)x;
+    f32x4 z = td_buf_ld4(w.in, ok ? (pix * (unsigned)p.C + (unsigned)cv * 4u) * 4u : TD_BUF_OOB, 0u);
+    if (p.ln_mean) {                                                 // uniform
+        const float g = td_buf_ld1(w.g, ok ? pix * 4u : TD_BUF_OOB, 0u), b = td_buf_ld1(w.b, ok ? pix * 4u : TD_BUF_OOB, 0u);
+        z = (z - m4) * r4 * g + b;
     }
     return z;
 }
@@ -69,6 +86,7 @@ TD_DEV void td_wino_bt_d_b(const f32x4 (&d)[4][4], f32x4 (&v)[4][4]) {
 // thread = (tile, 4 channels); lanes run over channels (coalesced float4)
 TD_KERNEL void k_wino_in(WinoArgs p) {
     const int CV = p.C >> 2;
+    const WinoBufs wb = td_wino_bufs(p);
     const long total = (long)p.T * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -83,7 +101,7 @@ TD_KERNEL void k_wino_in(WinoArgs p) {
         for (int r = 0; r < 4; ++r) {
             const int y = py + p.dil * (2 * ty - 1 + r);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) d[r][c] = td_wino_ld(p, y, px + p.dil * (2 * tx - 1 + c), cv, m4, r4);
+            for (int c = 0; c < 4; ++c) d[r][c] = td_wino_ld(p, wb, y, px + p.dil * (2 * tx - 1 + c), cv, m4, r4);
         }
         td_wino_bt_d_b(d, v);
         const size_t tile = (size_t)(i / CV);
@@ -97,6 +115,7 @@ TD_KERNEL void k_wino_in(WinoArgs p) {
 // thread = (tile, 4 output channels): Y = A^T m A, + bias (+ residual), activation, scatter to the 2x2 output pixels
 TD_KERNEL void k_wino_out(WinoArgs p) {
     const int CV = p.Cout >> 2;
+    const WinoBufs wb = td_wino_bufs(p);
     const float slope = td_act_slope(p.act);
     const long total = (long)p.T * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -106,6 +125,16 @@ TD_KERNEL void k_wino_out(WinoArgs p) {
         const int tx = t % p.TX; t /= p.TX;
         const int ty = t % p.TY; t /= p.TY;
         const int px = t % p.dil, py = t / p.dil;
+        unsigned off[2][2];                                           // byte offsets of the 2x2 output pixels (out-of-range: dropped / zeros)
+        f32x4 rs[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int y = py + p.dil * (2 * ty + r), x = px + p.dil * (2 * tx + c);
+                off[r][c] = (y < p.H && x < p.W) ? (((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.Cout + (unsigned)cv * 4u) * 4u : TD_BUF_OOB;
+                rs[r][c] = td_buf_ld4(wb.resid, off[r][c], 0u);      // requested before the 16 planes: everything in flight together
+            }
         f32x4 m[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -120,21 +149,16 @@ TD_KERNEL void k_wino_out(WinoArgs p) {
         const f32x4 b = td_ld4(p.bias + cv * 4);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int y = py + p.dil * (2 * ty + r);
-            if (y >= p.H) continue;
             f32x4 o2[2];
             o2[0] = s[r][0] + s[r][1] + s[r][2];                      // (.) A
             o2[1] = s[r][1] - s[r][2] - s[r][3];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int x = px + p.dil * (2 * tx + c);
-                if (x >= p.W) continue;
-                const size_t off = ((size_t)y * p.W + x) * p.Cout + cv * 4;
                 f32x4 o = o2[c] + b;
-                if (p.resid) o = o + td_ld4(p.resid + off);
+                o = o + rs[r][c];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
-                td_st4(p.out + off, o);
+                td_buf_st4(wb.out, off[r][c], 0u, o);
             }
         }
     }
@@ -164,6 +188,7 @@ TD_DEV void td_wino4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
 // and kept), then each row of the intermediate is transformed and stored: 144 VGPRs of live state instead of 288.
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
     const int CV = p.C >> 2;
+    const WinoBufs wb = td_wino_bufs(p);
     const long total = (long)p.T * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -179,7 +204,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
             const int x = px + p.dil * (4 * tx - 1 + c);
             f32x4 d[6], col[6];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = td_wino_ld(p, py + p.dil * (4 * ty - 1 + r), x, cv, m4, r4);
+            for (int r = 0; r < 6; ++r) d[r] = td_wino_ld(p, wb, py + p.dil * (4 * ty - 1 + r), x, cv, m4, r4);
             td_wino4_bt(d, col);                                      // B^T d, one column
 #pragma unroll
             for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
@@ -198,6 +223,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_in(WinoArgs p) {
 // thread = (tile, 4 output channels): Y = A^T m A (4x4 pixels), + bias (+ residual), activation, scatter
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
     const int CV = p.Cout >> 2;
+    const WinoBufs wb = td_wino_bufs(p);
     const float slope = td_act_slope(p.act);
     const long total = (long)p.T * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -207,6 +233,22 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
         const int tx = t % p.TX; t /= p.TX;
         const int ty = t % p.TY; t /= p.TY;
         const int px = t % p.dil, py = t / p.dil;
+        // the 16 residual vectors first: they are in flight under the 36 plane loads and the transforms (a residual load, a wait and
+        // a store per output pixel made this kernel latency-bound: 32.5 us average against 25 for the larger input transform)
+        unsigned offy[4], offx[4];
+        bool oky[4], okx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = py + p.dil * (4 * ty + r), x = px + p.dil * (4 * tx + r);
+            oky[r] = y < p.H; okx[r] = x < p.W;
+            offy[r] = (unsigned)y * (unsigned)p.W * (unsigned)p.Cout * 4u;
+            offx[r] = ((unsigned)x * (unsigned)p.Cout + (unsigned)cv * 4u) * 4u;
+        }
+        f32x4 rs[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rs[r][c] = td_buf_ld4(wb.resid, (oky[r] && okx[c]) ? offy[r] + offx[c] : TD_BUF_OOB, 0u);
         f32x4 sm[4][6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -220,20 +262,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
         const f32x4 b = td_ld4(p.bias + cv * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int y = py + p.dil * (4 * ty + r);
-            if (y >= p.H) continue;
             f32x4 o4[4];
             td_wino4_at(sm[r], o4);                                   // (.) A, one row
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int x = px + p.dil * (4 * tx + c);
-                if (x >= p.W) continue;
-                const size_t off = ((size_t)y * p.W + x) * p.Cout + cv * 4;
                 f32x4 o = o4[c] + b;
-                if (p.resid) o = o + td_ld4(p.resid + off);
+                o = o + rs[r][c];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
-                td_st4(p.out + off, o);
+                td_buf_st4(wb.out, (oky[r] && okx[c]) ? offy[r] + offx[c] : TD_BUF_OOB, 0u, o);
             }
         }
     }
