@@ -35,24 +35,33 @@ TD_KERNEL void k_nchw3_to_nhwc4_x4(const float* __restrict__ img, float* __restr
 TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
     const int CV = C >> 2;
     const long total = (long)Ho * Wo * CV;
+    // nine UNCONDITIONAL range-checked loads, all in flight, padding taps replaced by -3e38 with a select: `if (inside) load; max`
+    // is nine dependent memory round trips per output (59 us for 168 MB at 1024x2048)
+    const TdBuf in_buf = td_make_buf(in, (unsigned)H * (unsigned)W * (unsigned)C * 4u);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
         const long pix = i / CV;
         const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
-        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        f32x4 v[3][3];
+        bool ok[3][3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy - 1 + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * ox - 1 + kx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const f32x4 v = td_ld4(in + ((size_t)iy * W + ix) * C + cv * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                ok[ky][kx] = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                v[ky][kx] = td_buf_ld4(in_buf, ok[ky][kx] ? (((unsigned)iy * (unsigned)W + (unsigned)ix) * (unsigned)C + (unsigned)cv * 4u) * 4u : TD_BUF_OOB, 0u);
             }
-        }
+        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = ok[ky][kx] ? v[ky][kx][e] : -3.0e38f;
+                    m[e] = t > m[e] ? t : m[e];
+                }
         td_st4(out + (size_t)pix * C + cv * 4, m);
     }
 }
@@ -64,29 +73,35 @@ template <bool IN16>
 TD_KERNEL void k_maxpool3s2_h(const void* __restrict__ inv, _Float16* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
     const int CV = C >> 2;
     const long total = (long)Ho * Wo * CV;
+    const TdBuf in_buf = td_make_buf(reinterpret_cast<const float*>(inv), (unsigned)H * (unsigned)W * (unsigned)C * (IN16 ? 2u : 4u));
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
         const long pix = i / CV;
         const int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
-        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        f32x4 v[3][3];                                                // as k_maxpool3s2: all nine taps in flight, padding by select
+        bool ok[3][3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy - 1 + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * ox - 1 + kx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const size_t o = ((size_t)iy * W + ix) * C + cv * 4;
-                f32x4 v;
+                const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+                ok[ky][kx] = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const unsigned el = ((unsigned)iy * (unsigned)W + (unsigned)ix) * (unsigned)C + (unsigned)cv * 4u;
                 if (IN16) {
-                    const td_f16x4 h = *reinterpret_cast<const td_f16x4*>(reinterpret_cast<const _Float16*>(inv) + o);
-                    v[0] = (float)h[0]; v[1] = (float)h[1]; v[2] = (float)h[2]; v[3] = (float)h[3];
-                } else v = td_ld4(reinterpret_cast<const float*>(inv) + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+                    const td_f16x4 h = __builtin_bit_cast(td_f16x4, td_buf_ld2(in_buf, ok[ky][kx] ? el * 2u : TD_BUF_OOB, 0u));
+                    v[ky][kx] = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                } else v[ky][kx] = td_buf_ld4(in_buf, ok[ky][kx] ? el * 4u : TD_BUF_OOB, 0u);
             }
-        }
+        f32x4 m = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = ok[ky][kx] ? v[ky][kx][e] : -3.0e38f;
+                    m[e] = t > m[e] ? t : m[e];
+                }
         td_f16x4 oh = {(_Float16)m[0], (_Float16)m[1], (_Float16)m[2], (_Float16)m[3]};
         *reinterpret_cast<td_f16x4*>(out + (size_t)pix * C + cv * 4) = oh;
     }
@@ -141,9 +156,20 @@ TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ ro
     const int i = b >= 6 ? b - 6 : b >= 3 ? b - 3 : b >= 1 ? b - 1 : 0;
     const float* row = c4 + (size_t)y * w * C + cv * 4;
     const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
+    // The level-1 bin is a whole row: 256 loads per thread, and the launch lasts as long as that chain (the loads are independent,
+    // only the adds depend on each other): 32 loads in flight per thread -> 8 memory round trips instead of 32 (48 us -> see DESIGN 4.3).
+    // Same summation order as a plain loop.
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int x = lo;
+    for (; x + 32 <= hi; x += 32) {
+        f32x4 v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = td_ld4(row + (size_t)(x + k) * C);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s = s + v[k];
+    }
 #pragma unroll 8
-    for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
+    for (; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
     td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
 }
 // The same sums with every (row, bin) split SPLIT ways along x inside one workgroup (block = SPLIT * C/4 threads, LDS combine in a
