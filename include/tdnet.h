@@ -58,7 +58,7 @@ typedef struct tdnet_opts {
                                 1 = Encoding's q / k projections (w_qs, w_ks: small, latency-bound) on the side stream beside w_vs,
                                 2 = LayerNorm strip statistics written by the attention epilogue (no separate pass over the map),
                                 4 = LayerNorm normalisation applied inside the head's Winograd input transform (no `ln` map in HBM),
-                                8 = pyramid-pooling row sums split four ways per bin (shorter serial chains),
+                                8 = (retired, ignored: the pyramid row sums now read the map once, td_misc.h k_ppm_rowsum),
                                 16 = stem: 4-pixel vectorised layout change and 2-output max-pool,
                                 32 = Cout <= 64 convs (layer1, the stems) read their A operand straight from global memory in MFMA
                                      fragment layout instead of staging it through LDS (td_conv_ad.h),

@@ -149,68 +149,71 @@ TD_KERNEL void k_maxpool3s2_x2(const float* __restrict__ in, float* __restrict__
 TD_HOSTDEV int td_bin_lo(int i, int n, int o) { return (i * n) / o; }
 TD_HOSTDEV int td_bin_hi(int i, int n, int o) { return ((i + 1) * n + o - 1) / o; }
 
-// grid = h rows x 12 x-bins (one workgroup per (row, bin): 1536 groups at 128x256), block = C/4 threads; rowpart [h][12][C]
-TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C) {
-    const int y = blockIdx.x / 12, b = blockIdx.x % 12, cv = threadIdx.x;
-    const int o = b >= 6 ? 6 : b >= 3 ? 3 : b >= 1 ? 2 : 1;
-    const int i = b >= 6 ? b - 6 : b >= 3 ? b - 3 : b >= 1 ? b - 1 : 0;
-    const float* row = c4 + (size_t)y * w * C + cv * 4;
-    const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
-    // The level-1 bin is a whole row: 256 loads per thread, and the launch lasts as long as that chain (the loads are independent,
-    // only the adds depend on each other): 32 loads in flight per thread -> 8 memory round trips instead of 32 (48 us -> see DESIGN 4.3).
-    // Same summation order as a plain loop.
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int x = lo;
-    for (; x + 32 <= hi; x += 32) {
-        f32x4 v[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = td_ld4(row + (size_t)(x + k) * C);
-#pragma unroll
-        for (int k = 0; k < 32; ++k) s = s + v[k];
-    }
-#pragma unroll 8
-    for (; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
-    td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
+// Row sums of the pyramid.  The 12 x-bins of a row (levels 1, 2, 3, 6; adaptive pooling: [floor(i w / o), ceil((i + 1) w / o)), so
+// neighbours overlap by a column) cover the row four times; summing each bin on its own read the map 4x (49 us for 67 MB at
+// 1024x2048, and the level-1 bin -- a whole row -- was one 256-long chain).  The bin edges of all levels cut the row into at most 23
+// ATOMS (10 at w = 256); every atom is summed once and every bin is a run of consecutive atoms (k_ppm_bins).
+struct PpmAtoms {
+    int n;                // atoms per row
+    int edge[25];         // atom a = columns [edge[a], edge[a + 1])
+    int lo[12], hi[12];   // x-bin b (level-major: 1 | 2 | 3 | 6) = atoms lo[b] .. hi[b] - 1
+};
+static inline PpmAtoms ppm_atoms(int w) {
+    static const int lv[4] = {1, 2, 3, 6};
+    PpmAtoms a;
+    int pts[24], np = 0;
+    for (int l = 0; l < 4; ++l)
+        for (int i = 0; i < lv[l]; ++i) { pts[np++] = td_bin_lo(i, w, lv[l]); pts[np++] = td_bin_hi(i, w, lv[l]); }
+    for (int i = 1; i < np; ++i)                                     // insertion sort, then unique
+        for (int j = i; j > 0 && pts[j - 1] > pts[j]; --j) { const int t = pts[j]; pts[j] = pts[j - 1]; pts[j - 1] = t; }
+    int ne = 0;
+    for (int i = 0; i < np; ++i) if (ne == 0 || a.edge[ne - 1] != pts[i]) a.edge[ne++] = pts[i];
+    a.n = ne - 1;
+    for (int i = ne; i < 25; ++i) a.edge[i] = a.edge[ne - 1];
+    int b = 0;
+    for (int l = 0; l < 4; ++l)
+        for (int i = 0; i < lv[l]; ++i, ++b) {
+            const int lo = td_bin_lo(i, w, lv[l]), hi = td_bin_hi(i, w, lv[l]);
+            a.lo[b] = a.hi[b] = 0;
+            for (int e = 0; e < ne; ++e) { if (a.edge[e] == lo) a.lo[b] = e; if (a.edge[e] == hi) a.hi[b] = e; }
+        }
+    return a;
 }
-// The same sums with every (row, bin) split SPLIT ways along x inside one workgroup (block = SPLIT * C/4 threads, LDS combine in a
-// fixed order): the level-1 bin is a whole row, 256 serial loads per thread in the kernel above, and the launch was latency-bound
-// (48 us for 67 MB at 1024x2048).  Segment j of a bin [lo, hi) covers [lo + j*len, lo + (j+1)*len), len = ceil((hi-lo)/SPLIT).
-template <int SPLIT>
-TD_KERNEL void k_ppm_rowsum_split(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C) {
-    TD_DYN_LDS(smem);
-    float* red = reinterpret_cast<float*>(smem);               // [SPLIT][C]
-    const int CV = C >> 2;
-    const int y = blockIdx.x / 12, b = blockIdx.x % 12, cv = threadIdx.x % CV, seg = threadIdx.x / CV;
-    const int o = b >= 6 ? 6 : b >= 3 ? 3 : b >= 1 ? 2 : 1;
-    const int i = b >= 6 ? b - 6 : b >= 3 ? b - 3 : b >= 1 ? b - 1 : 0;
+// grid = h rows x at.n atoms, block = C/4 threads; rowpart [h][at.n][C]
+TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C, PpmAtoms at) {
+    const int y = blockIdx.x / at.n, a = blockIdx.x % at.n, cv = threadIdx.x;
     const float* row = c4 + (size_t)y * w * C + cv * 4;
-    const int lo = td_bin_lo(i, w, o), hi = td_bin_hi(i, w, o);
-    const int len = (hi - lo + SPLIT - 1) / SPLIT;
-    const int x0 = lo + seg * len, x1 = (x0 + len < hi) ? x0 + len : hi;
+    const int lo = at.edge[a], hi = at.edge[a + 1];
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int x = x0; x < x1; ++x) s = s + td_ld4(row + (size_t)x * C);
-    td_st4(red + (size_t)seg * C + cv * 4, s);
-    __syncthreads();
-    if (seg == 0) {
+    for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
+    td_st4(rowpart + ((size_t)y * at.n + a) * C + cv * 4, s);
+}
+// grid = h rows x 12 x-bins, block = C/4: rowbins [h][12][C] = the bin's run of atoms (at most 23 loads, all in flight together)
+TD_KERNEL void k_ppm_rowbins(const float* __restrict__ rowpart, float* __restrict__ rowbins, int C, PpmAtoms at) {
+    const int y = blockIdx.x / 12, b = blockIdx.x % 12, cv = threadIdx.x;
+    const int alo = at.lo[b], ahi = at.hi[b];
+    const TdBuf buf = td_make_buf(rowpart + (size_t)y * at.n * C, (unsigned)at.n * (unsigned)C * 4u);
+    f32x4 v[23];
 #pragma unroll
-        for (int k = 1; k < SPLIT; ++k) s = s + td_ld4(red + (size_t)k * C + cv * 4);
-        td_st4(rowpart + ((size_t)y * 12 + b) * C + cv * 4, s);
-    }
+    for (int k = 0; k < 23; ++k) v[k] = td_buf_ld4(buf, alo + k < ahi ? ((unsigned)(alo + k) * (unsigned)C + (unsigned)cv * 4u) * 4u : TD_BUF_OOB, 0u);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 23; ++k) s = s + v[k];                        // atoms past the bin read as zeros
+    td_st4(rowbins + ((size_t)y * 12 + b) * C + cv * 4, s);
 }
 // grid = 50 bins, block = C/4; pooled [50][C] = mean over the bin.  bin order: level-major, then by, then bx.
-TD_KERNEL void k_ppm_bins(const float* __restrict__ rowpart, float* __restrict__ pooled, int h, int w, int C) {
-    int bin = blockIdx.x, lvl = 0, o = 1, xoff = 0;
-    if (bin >= 14) { lvl = 3; o = 6; xoff = 6; bin -= 14; }
-    else if (bin >= 5) { lvl = 2; o = 3; xoff = 3; bin -= 5; }
-    else if (bin >= 1) { lvl = 1; o = 2; xoff = 1; bin -= 1; }
-    (void)lvl;
+TD_KERNEL void k_ppm_bins(const float* __restrict__ rowbins, float* __restrict__ pooled, int h, int w, int C) {
+    int bin = blockIdx.x, o = 1, xoff = 0;
+    if (bin >= 14) { o = 6; xoff = 6; bin -= 14; }
+    else if (bin >= 5) { o = 3; xoff = 3; bin -= 5; }
+    else if (bin >= 1) { o = 2; xoff = 1; bin -= 1; }
     const int by = bin / o, bx = bin % o, cv = threadIdx.x;
     const int ylo = td_bin_lo(by, h, o), yhi = td_bin_hi(by, h, o);
     const int cnt = (yhi - ylo) * (td_bin_hi(bx, w, o) - td_bin_lo(bx, w, o));
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-    for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowpart + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
+    for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowbins + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
     td_st4(pooled + (size_t)blockIdx.x * C + cv * 4, s * (1.0f / (float)cnt));
 }
 // pyramid 1x1 conv (BN folded) + ReLU on the 50 pooled vectors, only the FS channels this path keeps:

@@ -509,7 +509,7 @@ static int alloc_workspace(tdnet* n) {
     if (n->deep) bmax = std::max(bmax, (size_t)n->H1 * n->W1 * 128);   // br also holds the deep stem output
     if (dev_alloc(&n->bx, bmax) || dev_alloc(&n->br, bmax) || dev_alloc(&n->bt, std::max(cmax, n->bspec[0].bott ? (size_t)0 : bmax))) return -1;
     if (n->deep && dev_alloc(&n->bu, cmax)) return -1;
-    if (dev_alloc(&n->rowpart, (size_t)n->h * 12 * C) || dev_alloc(&n->pooled, 50 * C) || dev_alloc(&n->ppmfeat, 50 * FS)) return -1;
+    if (dev_alloc(&n->rowpart, (size_t)n->h * 36 * C) || dev_alloc(&n->pooled, 50 * C) || dev_alloc(&n->ppmfeat, 50 * FS)) return -1;
     if (dev_alloc(&n->z, hw * ZC)) return -1;
     n->stage_tmp_floats = hw * ZC;
     if (dev_alloc(&n->headmid, hw * n->MID) || dev_alloc(&n->lowres, hw * n->cfg.nclass) || dev_alloc(&n->stage_tmp, n->stage_tmp_floats)) return -1;
@@ -835,12 +835,11 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
 static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int FS, const float* wgt, const float* bias, int pid,
                     float* rowpart, float* pooled, float* ppmfeat, float* z, hipStream_t s) {
     prof_begin(n, 2, false, 0, s);
-    const bool split = n && (n->opts.fusion & 8);
-    if (split && C / 4 <= 128) TD_LAUNCH((k_ppm_rowsum_split<4>), dim3(h * 12), dim3(C), 4 * C * 4, s, c4, rowpart, w, C);             // 512 threads
-    else if (split && C / 4 <= 256) TD_LAUNCH((k_ppm_rowsum_split<2>), dim3(h * 12), dim3(C / 2), 2 * C * 4, s, c4, rowpart, w, C);    // 512 threads
-    else
-    TD_LAUNCH(k_ppm_rowsum, dim3(h * 12), dim3(C / 4), 0, s, c4, rowpart, w, C);
-    TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowpart, pooled, h, w, C);
+    const PpmAtoms at = ppm_atoms(w);                                 // the row is read once: atoms between the bin edges of all four levels
+    TD_LAUNCH(k_ppm_rowsum, dim3(h * at.n), dim3(C / 4), 0, s, c4, rowpart, w, C, at);
+    float* rowbins = rowpart + (size_t)h * 24 * C;                    // [h][12][C] behind the (at most 23) atoms per row
+    TD_LAUNCH(k_ppm_rowbins, dim3(h * 12), dim3(C / 4), 0, s, (const float*)rowpart, rowbins, C, at);
+    TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowbins, pooled, h, w, C);
     TD_LAUNCH(k_ppm_conv, dim3(50 * (FS / 64)), dim3(256), 256 * 4, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
     TD_LAUNCH(k_ppm_assemble, dim3(td_grid_for((long)h * w * (C / 4))), dim3(256), 0, s, c4, (const float*)ppmfeat, z, h, w, C,
               pid * XS, XS, FS);
@@ -1400,7 +1399,7 @@ extern "C" int tdnet_op_ppm(const float* c4, int h, int w, const float* w_host, 
         }
     float *dw = nullptr, *db = nullptr, *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr;
     if (upload(&dw, pw) || upload(&db, pb)) return -1;
-    if (dev_alloc(&rowpart, (size_t)h * 12 * C) || dev_alloc(&pooled, 50 * C) || dev_alloc(&ppmfeat, 50 * FS)) return -1;
+    if (dev_alloc(&rowpart, (size_t)h * 36 * C) || dev_alloc(&pooled, 50 * C) || dev_alloc(&ppmfeat, 50 * FS)) return -1;
     run_ppm(nullptr, c4, h, w, C, C / 2, FS, dw, db, pid, rowpart, pooled, ppmfeat, z, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());
