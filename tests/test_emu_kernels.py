@@ -97,7 +97,7 @@ def test_attention_online_softmax_and_layernorm_statistics(lib):
 def test_layernorm_ppm_upsample(lib):
     for hw, c in [(45, 512), (153, 128), (1000, 512), (2145, 512), (1, 128), (1300, 256)]:   # 2145: empty strips (512 strips of 5 pixels)
         opcheck.layernorm(lib, MEM, hw, c)
-    for h, w, pid in [(5, 9, 0), (9, 17, 1), (13, 25, 1), (6, 6, 0), (97 // 4, 193 // 4, 0)]:
+    for h, w, pid in [(5, 9, 0), (9, 17, 1), (13, 25, 1), (6, 6, 0), (97 // 4, 193 // 4, 0), (7, 11, 1), (4, 193, 0)]:   # row sums by atoms: odd widths
         opcheck.ppm(lib, MEM, h, w, pid)
     for c, h, w, H, W in [(19, 5, 9, 33, 65), (3, 9, 17, 65, 129), (2, 1, 1, 4, 5)]:
         opcheck.upsample(lib, MEM, c, h, w, H, W)
