@@ -1,7 +1,7 @@
 // td_gemm.h -- persistent fp32-MFMA GEMM for the short-K contractions of the path:
 //   out[b][m][n] = act( sum_k A[b][m][k] * W[b][k][n] + bias[n] (+ resid[m][n]) ),   b < nbatch, k < K = Cin
 // i.e. every stride-1 1x1 convolution (Encoding projections transformer.py:18-24, Bottleneck 1x1s resnet.py:70-78, attention fc
-// on the cached value matrix) and the 16 batched GEMMs of a Winograd conv (td_wino.h).  K is only 64..2048 here, 2..64 steps of
+// on the cached value matrix) and the 16 / 36 batched GEMMs of a Winograd conv (td_wino.h).  K is only 64..2048 here, 2..64 steps of
 // 32: a workgroup that does ONE tile spends a large part of its life in the prologue (first loads exposed) and the epilogue
 // (accumulator stores), which is why the conv kernel reaches 84 % of the MFMA roof on K = 4608 but 65 % on K = 512.
 //
@@ -67,12 +67,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
     const int nsteps = p.K >> 5;
     if (my_tiles == 0) return;
-    // De-phase the workgroups that share a CU by a fraction of a TILE.  All workgroups start together and walk tiles of equal
-    // length, so their epilogues coincide: every round ends in a burst of 16-64 KB of accumulator stores per workgroup (33-50 MB
-    // per round of the grid) during which no co-resident wave has MFMAs to issue -- tools/gemm_overhead_probe.py measures ~11 us of
-    // fixed cost per 128 x 128 tile round, three K steps' worth, which is what holds the K = 128..512 launches at 50-85 % MFMA
-    // busy.  Workgroups b, b + 256, b + 512 land on the same CU; group j = b / 256 sleeps j * stagger/8 of a tile's MFMA time once,
-    // so that one group's stores fall under the others' K loops.
+    // Optional (tdnet_opts.stagger, default 0): de-phase the workgroups that share a CU by a fraction of a TILE.  Workgroups b,
+    // b + 256, b + 512 land on the same CU; group j = b / 256 sleeps j * stagger/8 of a tile's MFMA time once.  Measured neutral:
+    // the groups drift apart on their own -- the SIMD issues the OLDER wave whenever several have an MFMA ready, so group 0 runs
+    // ~1.8x faster than group 2 -- and neither that, nor a dynamic tile list, nor s_setprio rotation changes the CU's aggregate
+    // rate (tools/gemm_trace.hip).
     if (p.stagger > 0) {
         const int j = (int)(blockIdx.x >> 8);
         const int units = j * p.stagger * nsteps * (MT * NT * 16 * 64 / 8 / 64);   // (MFMA cycles of a tile per wave) / 8 per unit, in s_sleep(1) = 64 cycles
@@ -83,8 +82,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
 
     // ---- loader state (runs two global steps ahead of the MFMAs) -------------------------------------------------
     // Tile coordinates are advanced INCREMENTALLY (tile list = every G8-th position: add G8's (batch, tile_m, tile_n) digits with
-    // carries) -- two integer divisions per tile are ~80 dependent scalar instructions, and instructions other than MFMAs issue slowly
-    // while the co-resident waves keep the matrix pipe busy (tools/gemm_trace.hip: the period that enters a tile takes 1.5x).
+    // carries) instead of by two integer divisions per tile (~80 dependent scalar instructions).  Measured neutral: the period that
+    // enters a tile takes 1.5x either way -- its operands are cold (tools/gemm_trace.hip, warm-tile experiment in profiles/r02q_*).
     struct TilePos { int b, tm, tn; };
     const int lin0 = xbase + q, r00 = lin0 % per_batch;
     const TilePos pos0 = {lin0 / per_batch, r00 / p.tiles_n, r00 % p.tiles_n};
