@@ -40,7 +40,9 @@ struct GemmArgs {
 
 // ROLE names the launch for the profiler (rocprofv3 aggregates by symbol): 0 = a stride-1 1x1 convolution, 1 = the (m+2)^2
 // batched GEMMs of a Winograd conv -- the frame's dominant kernel, whose roofline bench.py reports.  Same K loop; ROLE 1 has the
-// plain epilogue (bias, activation and residual belong to the Winograd output transform: GemmArgs.bias / act / resid are ignored).
+// plain epilogue (bias, activation and residual belong to the Winograd output transform: GemmArgs.bias / act / resid are ignored);
+// ROLE 2 = a 1x1 convolution WITHOUT residual: no residual loads in the epilogue (with ROLE 0 they are issued unconditionally --
+// zero-record descriptor when absent -- and, vmcnt being in order, waiting for them means waiting for the next tile's prefetch).
 template <int BM, int BN, int WGM, int WGN, int ROLE>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
@@ -197,7 +199,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     };
     auto store_tile = [&]() {
         float* outb = p.out + (size_t)spos.b * p.MP * p.N;
-        td_store_acc<MT, NT, ROLE == 1, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, spos.tm * BM + wm * WM, spos.tn * BN + wn * WN, lane,
+        td_store_acc<MT, NT, ROLE != 0, ROLE == 1>(acc, outb, p.bias, p.resid, p.M, p.N, p.act, spos.tm * BM + wm * WM, spos.tn * BN + wn * WN, lane,
                              &bias_pre);
         zero_acc();
         advance(spos);
@@ -281,6 +283,7 @@ static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t 
     long grid = grid_cap > 0 ? grid_cap : 256L * bpc;
     if (grid > total) grid = total;
     if (a.nbatch > 1) TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 1>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
+    else if (!a.resid) TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 2>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
     else TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 0>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
 }
 // grid_cap > 0 forces the number of workgroups (tests: several tiles per workgroup on small problems)
