@@ -32,10 +32,13 @@
 #include "td_device.h"
 #include "td_conv.h"   // td_ld4 / td_st4
 
+// rows of the value matrix V' a launch may touch: Lk rounded up to the largest super-tile (128 keys); see load_v in the kernel
+TD_HOSTDEV int attn_vp_rows(int Lk) { return (Lk + 127) / 128 * 128; }
+
 struct AttnArgs {
     const float* q;      // [Lq][64]
     const float* k;      // [Lk][64]
-    const float* vp;     // [Lk][DV]
+    const float* vp;     // [Lk][DV]; CONTRACT: attn_vp_rows(Lk) rows allocated, the rows past Lk - 1 finite (zeros)
     const float* bias;   // [DV] or nullptr
     const float* resid;  // [Lq][DV] or nullptr
     float* out;          // [Lq][DV]
@@ -158,31 +161,20 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float lsum = 0.f;
     const int cb = cw * (NT * 32) + l31 * NT;                     // this lane's first output channel
-    const float* vbase = p.vp + cb;
-    // V' rows of k-group G of the super-tile starting at kbase: 4 keys per lane-half, one float4 (4 channels) each
+    // V' rows of k-group G of the super-tile starting at kbase: 4 keys per lane-half, one float4 (4 channels) each.  CONTRACT: vp has
+    // attn_vp_rows(Lk) rows allocated (Lk rounded up to 128), the rows past Lk - 1 finite (zeros): a ragged last super-tile then
+    // reads them like any other (P is exactly 0 for masked keys) and there is no "is this tile inside V'" test -- it used to sit
+    // inside every one of the 18 calls per super-tile, a compare and two branches each in the middle of the MFMA stream.
     const unsigned LDV = (unsigned)p.ldv;
-    const TdBuf vbuf = td_make_buf(p.vp, ((unsigned)(p.Lk - 1) * LDV + (unsigned)DV) * 4u);
+    const TdBuf vbuf = td_make_buf(p.vp, ((unsigned)(attn_vp_rows(p.Lk) - 1) * LDV + (unsigned)DV) * 4u);
     const unsigned v_voff = (4u * (unsigned)half * LDV + (unsigned)cb) * 4u;
     auto load_v = [&](int kbase, int G, f32x4 (&b)[4]) {
-        if (kbase + SK <= p.Lk) {                                     // wave-uniform: the whole super-tile is inside V'
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned soff = (unsigned)(kbase + 8 * G + e) * LDV * 4u;
-                if (NT == 4) b[e] = td_buf_ld4(vbuf, v_voff, soff);
-                else {
-                    const f32x2 v2 = td_buf_ld2(vbuf, v_voff, soff);
-                    b[e][0] = v2[0]; b[e][1] = v2[1]; b[e][2] = 0.f; b[e][3] = 0.f;
-                }
-            }
-            return;
-        }
-        const int key0 = kbase + 4 * (2 * G + half);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int key = (key0 + e < p.Lk) ? key0 + e : key_last;     // P is exactly 0 for masked keys
-            if (NT == 4) b[e] = td_ld4(vbase + (size_t)key * LDV);
+            const unsigned soff = (unsigned)(kbase + 8 * G + e) * LDV * 4u;
+            if (NT == 4) b[e] = td_buf_ld4(vbuf, v_voff, soff);
             else {
-                const f32x2 v2 = *reinterpret_cast<const f32x2*>(vbase + (size_t)key * LDV);
+                const f32x2 v2 = td_buf_ld2(vbuf, v_voff, soff);
                 b[e][0] = v2[0]; b[e][1] = v2[1]; b[e][2] = 0.f; b[e][3] = 0.f;
             }
         }

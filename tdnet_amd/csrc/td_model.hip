@@ -536,7 +536,8 @@ static int alloc_workspace(tdnet* n) {
     }
     if (psp) return 0;
     if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
-    if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, lk * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
+    if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, (size_t)attn_vp_rows((int)lk) * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
+    TD_HIP(hipMemset(n->vp, 0, (size_t)attn_vp_rows((int)lk) * n->DV * sizeof(float)));   // padding rows of V' stay zero (td_attn.h load_v)
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
     if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
@@ -1361,6 +1362,8 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
                                   void* stream) {
     if (Lk < 1 || Lq < 1) return td_fail("tdnet_op_attention: empty input");
     hipStream_t s = (hipStream_t)stream;
+    const bool padded = (online & 32) != 0;                            // online | 32: the caller's vp already has the padding rows (probes that time the kernel)
+    online &= ~32;
     float *part = nullptr, *mean = nullptr, *rstd = nullptr;
     if (ln_out) {                                                      // + plane LayerNorm of the result from the epilogue's strip statistics
         if (!ln_g || !ln_b) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
@@ -1369,11 +1372,20 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     _Float16* vt = nullptr;                                            // online == 16: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
     if (online == 16 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) return -1;
     if (online != 16 && (online < 0 || online > 2)) return td_fail("tdnet_op_attention: online must be 0, 1, 2 or 16");
+    float* vpad = nullptr;                                             // the kernels' contract: V' padded to attn_vp_rows(Lk) zero rows
+    if (online != 16 && !padded && attn_vp_rows(Lk) != Lk) {
+        const size_t rows = (size_t)attn_vp_rows(Lk);
+        if (dev_alloc(&vpad, rows * DV)) return -1;
+        TD_HIP(hipMemsetAsync(vpad, 0, rows * DV * sizeof(float), s));
+        TD_HIP(hipMemcpyAsync(vpad, vp, (size_t)Lk * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
+        vp = vpad;
+    }
     if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt)) return -1;
     if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
     TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());
     if (vt) hipFree(vt);
+    if (vpad) hipFree(vpad);
     if (part) { hipFree(part); hipFree(mean); hipFree(rstd); }
     return 0;
 }

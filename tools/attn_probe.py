@@ -6,10 +6,11 @@ lib = _capi.lib(); dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(1)
 def run(Lq, Lk, DV, online=0, iters=20):
     q = (torch.randn(Lq, 64, generator=g) * 0.5).to(dev); k = (torch.randn(Lk, 64, generator=g) * 0.5).to(dev)
-    vp = torch.randn(Lk, DV, generator=g).to(dev); b = torch.randn(DV, generator=g).to(dev); r = torch.randn(Lq, DV, generator=g).to(dev)
+    vp = torch.zeros((Lk + 127) // 128 * 128, DV); vp[:Lk] = torch.randn(Lk, DV, generator=g); vp = vp.to(dev)   # padded as the kernels expect
+    b = torch.randn(DV, generator=g).to(dev); r = torch.randn(Lq, DV, generator=g).to(dev)
     out = torch.empty(Lq, DV, device=dev)
     s = torch.cuda.current_stream().cuda_stream
-    call = lambda: lib.tdnet_op_attention(q.data_ptr(), k.data_ptr(), vp.data_ptr(), b.data_ptr(), r.data_ptr(), Lq, Lk, DV, online, None, None, None, out.data_ptr(), s)
+    call = lambda: lib.check(lib.tdnet_op_attention(q.data_ptr(), k.data_ptr(), vp.data_ptr(), b.data_ptr(), r.data_ptr(), Lq, Lk, DV, online | 32, None, None, None, out.data_ptr(), s))
     for _ in range(3): call()
     torch.cuda.synchronize()
     best = 1e9
