@@ -233,17 +233,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
                 td_wave_sync();
             }
             float* Pw = Ps + (st & 1) * L::P_FLOATS + qw * (8 * CW * 128);
+            f32x16 pr;
+            if (kb + 32 <= p.Lk) {                                    // wave-uniform: no key of this tile is masked
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pr[r] = td_exp2(s[r] - rowmax); lsum += pr[r]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    pr[r] = (key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
+                    lsum += pr[r];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * u + e;
-                    const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float pe = (kb + 32 <= p.Lk || key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
-                    v[e] = pe;
-                    lsum += pe;
-                }
+                const f32x4 v = {pr[4 * u], pr[4 * u + 1], pr[4 * u + 2], pr[4 * u + 3]};
                 td_st4(Pw + ((cw * 8 + 2 * u + half) * 32 + l31) * 4, v);
             }
             // B: scores of tile st+1 and their maxima, before the barrier

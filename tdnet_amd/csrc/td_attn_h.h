@@ -162,16 +162,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention_h(AttnArgsH p) {
         }
         // P = exp2(S - reference) -> fp16 -> LDS image [key group][query][8]: this lane's registers 4g .. 4g+3 are keys 8g + 4 half + (0..3)
         _Float16* Pw = Ps + (st & 1) * L::P_HALFS + qw * (4 * CW * 256);
+        f32x16 pr;
+        if (kb + 32 <= p.Lk) {                                        // wave-uniform: no key of this tile is masked
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = td_exp2(s[r] - rowmax);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = (kb + 8 * (r >> 2) + 4 * half + (r & 3) < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             f16x4 h4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const int key = kb + 8 * g + 4 * half + e;
-                const float pe = (kb + 32 <= p.Lk || key < p.Lk) ? td_exp2(s[r] - rowmax) : 0.f;
-                const _Float16 ph = (_Float16)pe;
+                const _Float16 ph = (_Float16)pr[4 * g + e];
                 h4[e] = ph;
                 lsum += (float)ph;                                // the row sum of what is actually multiplied (fp16-rounded P)
             }

@@ -81,7 +81,10 @@ TD_DEV void td_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-TD_DEV float td_exp2(float x) { return exp2f(x); }
+// 2^x as the bare v_exp_f32 (1 ulp; results below 2^-126 flush to zero): exp2f() wraps it in a range fix-up for denormal results --
+// a compare, a select, an add and a multiply per call -- which the softmax does not need (such terms are 1e-38 of a sum >= 1) and
+// which sits in the MFMA stream of the attention kernels 16 times per key tile.
+TD_DEV float td_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 TD_DEV int td_lane() { return threadIdx.x & 63; }
 TD_DEV int td_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 #endif  // TD_DEVICE_H
