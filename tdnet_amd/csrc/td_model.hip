@@ -697,7 +697,12 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
     TD_HIP(hipDeviceSynchronize());
-    TD_HIP(hipStreamCreateWithFlags(&n->side, hipStreamNonBlocking));
+    {   // The side stream carries the cache-only attention chain (0.6 ms of work beside 2.5 ms of backbone): lowest priority, so its
+        // workgroups fill what the critical path leaves instead of taking CUs from it.
+        int least = 0, greatest = 0;
+        TD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        TD_HIP(hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, least));
+    }
     TD_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TD_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     TD_HIP(hipEventCreateWithFlags(&n->ev_fork2, hipEventDisableTiming));

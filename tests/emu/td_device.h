@@ -50,6 +50,8 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)0x1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)0x1; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
