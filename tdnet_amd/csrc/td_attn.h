@@ -134,7 +134,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             const f32x16 s = score_tile(kf);
             if (kb + 32 <= p.Lk) {                                    // wave-uniform: no key of this tile is masked
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = s[r] > mx ? s[r] : mx;
+                for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, s[r]);   // v_max(3)_f32: half the instructions of compare + select
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -185,7 +185,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             float lm = NEG;
             if (kb + 32 <= p.Lk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) lm = s[r] > lm ? s[r] : lm;
+                for (int r = 0; r < 16; ++r) lm = __builtin_fmaxf(lm, s[r]);   // v_max(3)_f32: half the instructions of compare + select
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -284,7 +284,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
             float lm = NEG;
             if (kb + 32 <= p.Lk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) lm = s[r] > lm ? s[r] : lm;
+                for (int r = 0; r < 16; ++r) lm = __builtin_fmaxf(lm, s[r]);   // v_max(3)_f32: half the instructions of compare + select
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
