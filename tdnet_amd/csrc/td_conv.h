@@ -235,6 +235,24 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         a_bx[i] = ox * p.stride - p.pad;
         a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (STEM ? 0u : (unsigned)a_kq * 4u)) * 4u;
     }
+    // Which of the KS x KS taps of slot i read inside the image: one bit per tap, computed ONCE.  The two bounds compares, the adds
+    // and the logic per slot and K step were 40-60 VALU instructions per step -- on the issue port the MFMAs use, for 16-32 MFMAs.
+    // (The 128 x 64 tile -- layer1 and the stem -- keeps the per-step compares and the loop with the break below: with the leaner loop
+    // both kernels are 3-4 % faster alone and 3-17 % SLOWER inside the frame, where they overlap the side stream's attention chain;
+    // measured three times in one visit, profiles/r02z_*, not understood.)
+    constexpr bool LEAN = BN != 64;
+    unsigned a_taps[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        a_taps[i] = 0u;
+        if (!STEM && LEAN) {
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {
+                const int iy = a_by[i] + (t / KS) * p.dil, ix = a_bx[i] + (t % KS) * p.dil;
+                a_taps[i] |= ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (1u << t) : 0u;
+            }
+        }
+    }
     const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 4u);
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
     unsigned b_off[BL];
@@ -263,8 +281,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            bool ok;
+            if (STEM || !LEAN) {
+                const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
+                ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            } else ok = ((a_taps[i] >> l_tap) & 1u) != 0u;
             // valid taps: a_off + delta is the exact non-negative byte offset (mod 2^32 arithmetic); padded taps read zeros
             ra[i] = td_buf_ld4(in_buf, ok ? a_off[i] + delta : TD_BUF_OOB, 0u);
         }
@@ -374,14 +395,29 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         for (int i = 0; i < BL; ++i) store_b(0, i, rb);
         load_tile(ra, rb);                              // tile 1 -> set 1, lands during step 0
         __syncthreads();
-        for (int step = 0; step < p.nsteps; step += 2) {
-            load_tile(ra2, rb2);                        // even step: set 1 holds tile step+1, set 2 receives tile step+2
-            compute(0, std::true_type{}, ra, rb);
-            __syncthreads();
-            if (step + 1 >= p.nsteps) break;
-            load_tile(ra, rb);                          // odd step: set 2 holds tile step+2, set 1 receives tile step+3
-            compute(1, std::true_type{}, ra2, rb2);
-            __syncthreads();
+        // Whole two-step periods, then the odd last step on its own: with `if (last) break;` in the MIDDLE of the loop the compiler
+        // keeps two copies of the accumulators and moves all of them (32 v_mov_b64 for a 128 x 128 tile) every iteration.
+        if constexpr (LEAN) {
+            int step = 0;
+            for (; step + 1 < p.nsteps; step += 2) {
+                load_tile(ra2, rb2);                    // even step: set 1 holds tile step+1, set 2 receives tile step+2
+                compute(0, std::true_type{}, ra, rb);
+                __syncthreads();
+                load_tile(ra, rb);                      // odd step: set 2 holds tile step+2, set 1 receives tile step+3
+                compute(1, std::true_type{}, ra2, rb2);
+                __syncthreads();
+            }
+            if (step < p.nsteps) compute(0, std::false_type{}, ra, rb);   // nsteps odd: the last tile is in LDS buffer 0, nothing left to stage
+        } else {
+            for (int step = 0; step < p.nsteps; step += 2) {
+                load_tile(ra2, rb2);
+                compute(0, std::true_type{}, ra, rb);
+                __syncthreads();
+                if (step + 1 >= p.nsteps) break;
+                load_tile(ra, rb);
+                compute(1, std::true_type{}, ra2, rb2);
+                __syncthreads();
+            }
         }
     }
 

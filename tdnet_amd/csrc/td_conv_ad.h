@@ -114,17 +114,18 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_conv_adirect(ConvArgs p) {
     for (int i = 0; i < 2; ++i) store_b(0, i, rb);
     load_b(rb);                                                     // weights of step 1
     __syncthreads();
-    for (int step = 0; step < p.nsteps; step += 2) {
+    int step = 0;                                                   // whole periods, then the odd last step (td_conv.h)
+    for (; step + 1 < p.nsteps; step += 2) {
         load_a(a1);                                                 // A of step+1, weights of step+2
         load_b(rb2);
         compute(0, a0, rb);
         __syncthreads();
-        if (step + 1 >= p.nsteps) break;
         load_a(a0);                                                 // A of step+2, weights of step+3
         load_b(rb);
         compute(1, a1, rb2);
         __syncthreads();
     }
+    if (step < p.nsteps) compute(0, a0, rb);
     td_store_acc<1, NT>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wave * 32, n0, lane);
 }
 

@@ -170,6 +170,18 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         } else
         a_off[i] = (((unsigned)a_by[i] * (unsigned)p.W + (unsigned)a_bx[i]) * (unsigned)p.Cin + (unsigned)a_kq * 8u) * EB;
     }
+    unsigned a_taps[AL];                                // bit t: tap t of slot i reads inside the image (td_conv.h)
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        a_taps[i] = 0u;
+        if (!STEM) {
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {
+                const int iy = a_by[i] + (t / KS) * p.dil, ix = a_bx[i] + (t % KS) * p.dil;
+                a_taps[i] |= ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (1u << t) : 0u;
+            }
+        }
+    }
     const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * EB);
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
     unsigned b_off[BL];
@@ -202,8 +214,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
         const unsigned delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * EB;
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const bool ok = ((a_taps[i] >> l_tap) & 1u) != 0u;
             const unsigned off = ok ? a_off[i] + delta : TD_BUF_OOB;
             if constexpr (IN16) ra[i] = td_buf_ld4(in_buf, off, 0u);  // 8 fp16 channels = the LDS slot as it is
             else {
@@ -272,15 +283,16 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     for (int i = 0; i < BL; ++i) store_b(0, i, rb);
     load_tile(ra, rb);
     __syncthreads();
-    for (int step = 0; step < p.nsteps; step += 2) {
+    int step = 0;                                       // whole periods, then the odd last step (no break inside the loop: td_conv.h)
+    for (; step + 1 < p.nsteps; step += 2) {
         load_tile(ra2, rb2);
         compute(0, ra, rb);
         __syncthreads();
-        if (step + 1 >= p.nsteps) break;
         load_tile(ra, rb);
         compute(1, ra2, rb2);
         __syncthreads();
     }
+    if (step < p.nsteps) compute(0, ra, rb);            // stages a surplus tile into buffer 1, never read
 
     td_store_acc_h<MT, NT, OUT16, IN16>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
 }
