@@ -237,15 +237,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     }
     // Which of the KS x KS taps of slot i read inside the image: one bit per tap, computed ONCE.  The two bounds compares, the adds
     // and the logic per slot and K step were 40-60 VALU instructions per step -- on the issue port the MFMAs use, for 16-32 MFMAs.
-    // (The 128 x 64 tile -- layer1 and the stem -- keeps the per-step compares and the loop with the break below: with the leaner loop
-    // both kernels are 3-4 % faster alone and 3-17 % SLOWER inside the frame, where they overlap the side stream's attention chain;
-    // measured three times in one visit, profiles/r02z_*, not understood.)
-    constexpr bool LEAN = BN != 64;
+    // The 128 x 64 tile -- layer1 and the stem -- keeps the loop with the break below: without it both kernels are 3-4 % faster
+    // alone and 3-17 % SLOWER inside the frame, where they overlap the side stream's attention chain (the leaner loop needs 106
+    // instead of 137 VGPRs, which presumably lets side-stream waves onto the same SIMDs); measured three times, profiles/r02z_*.
+    constexpr bool LEAN_LOOP = BN != 64;
     unsigned a_taps[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         a_taps[i] = 0u;
-        if (!STEM && LEAN) {
+        if (!STEM) {
 #pragma unroll
             for (int t = 0; t < KS * KS; ++t) {
                 const int iy = a_by[i] + (t / KS) * p.dil, ix = a_bx[i] + (t % KS) * p.dil;
@@ -282,7 +282,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             bool ok;
-            if (STEM || !LEAN) {
+            if (STEM) {
                 const int iy = a_by[i] + dy, ix = a_bx[i] + dx;
                 ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             } else ok = ((a_taps[i] >> l_tap) & 1u) != 0u;
@@ -397,7 +397,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         __syncthreads();
         // Whole two-step periods, then the odd last step on its own: with `if (last) break;` in the MIDDLE of the loop the compiler
         // keeps two copies of the accumulators and moves all of them (32 v_mov_b64 for a 128 x 128 tile) every iteration.
-        if constexpr (LEAN) {
+        if constexpr (LEAN_LOOP) {
             int step = 0;
             for (; step + 1 < p.nsteps; step += 2) {
                 load_tile(ra2, rb2);                    // even step: set 1 holds tile step+1, set 2 receives tile step+2
