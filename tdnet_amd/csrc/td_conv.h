@@ -237,10 +237,10 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     }
     // Which of the KS x KS taps of slot i read inside the image: one bit per tap, computed ONCE.  The two bounds compares, the adds
     // and the logic per slot and K step were 40-60 VALU instructions per step -- on the issue port the MFMAs use, for 16-32 MFMAs.
-    // The 128 x 64 tile -- layer1 and the stem -- keeps the loop with the break below: without it both kernels are 3-4 % faster
-    // alone and 3-17 % SLOWER inside the frame, where they overlap the side stream's attention chain (the leaner loop needs 106
-    // instead of 137 VGPRs, which presumably lets side-stream waves onto the same SIMDs); measured three times, profiles/r02z_*.
-    constexpr bool LEAN_LOOP = BN != 64;
+    // The 128 x 64 tile (layer1, the stem) overlaps the side stream's attention chain in the frame.  Its loop needs 106 VGPRs, and at
+    // 3 x 106 a SIMD has room for a fourth, side-stream wave: the kernel came out 3-4 % faster alone and 3-17 % SLOWER in the frame
+    // (profiles/r02z_*).  Claiming 144 registers keeps the SIMDs to this kernel's three waves, as the older, fatter loop did by accident.
+    if (BN == 64) TD_VGPR_FLOOR(143);
     unsigned a_taps[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
@@ -397,28 +397,16 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         __syncthreads();
         // Whole two-step periods, then the odd last step on its own: with `if (last) break;` in the MIDDLE of the loop the compiler
         // keeps two copies of the accumulators and moves all of them (32 v_mov_b64 for a 128 x 128 tile) every iteration.
-        if constexpr (LEAN_LOOP) {
-            int step = 0;
-            for (; step + 1 < p.nsteps; step += 2) {
-                load_tile(ra2, rb2);                    // even step: set 1 holds tile step+1, set 2 receives tile step+2
-                compute(0, std::true_type{}, ra, rb);
-                __syncthreads();
-                load_tile(ra, rb);                      // odd step: set 2 holds tile step+2, set 1 receives tile step+3
-                compute(1, std::true_type{}, ra2, rb2);
-                __syncthreads();
-            }
-            if (step < p.nsteps) compute(0, std::false_type{}, ra, rb);   // nsteps odd: the last tile is in LDS buffer 0, nothing left to stage
-        } else {
-            for (int step = 0; step < p.nsteps; step += 2) {
-                load_tile(ra2, rb2);
-                compute(0, std::true_type{}, ra, rb);
-                __syncthreads();
-                if (step + 1 >= p.nsteps) break;
-                load_tile(ra, rb);
-                compute(1, std::true_type{}, ra2, rb2);
-                __syncthreads();
-            }
+        int step = 0;
+        for (; step + 1 < p.nsteps; step += 2) {
+            load_tile(ra2, rb2);                        // even step: set 1 holds tile step+1, set 2 receives tile step+2
+            compute(0, std::true_type{}, ra, rb);
+            __syncthreads();
+            load_tile(ra, rb);                          // odd step: set 2 holds tile step+2, set 1 receives tile step+3
+            compute(1, std::true_type{}, ra2, rb2);
+            __syncthreads();
         }
+        if (step < p.nsteps) compute(0, std::false_type{}, ra, rb);   // nsteps odd: the last tile is in LDS buffer 0, nothing left to stage
     }
 
     td_store_acc<MT, NT>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);

@@ -63,6 +63,8 @@ TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
 // compile-time instruction interleave hint (LLVM SchedGroupMask: 0x8 MFMA, 0x100 DS read, 0x200 DS write, 0x20 VMEM read)
 #define TD_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define TD_PIN(x) asm volatile("" : "+v"(x))               // a use of x right here: the wait for a pending load of x is placed at this point, once
+#define TD_VGPR_FLOOR_STR(n) #n
+#define TD_VGPR_FLOOR(n) asm volatile("" ::: "v" TD_VGPR_FLOOR_STR(n))   // the kernel claims VGPRs 0..n: an occupancy ceiling that also holds against OTHER kernels' waves
 #define TD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)    // the instruction scheduler moves nothing across this point
 #define TD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler a wave-uniform value is one (SGPR, usable as soffset)
 

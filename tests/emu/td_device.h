@@ -97,6 +97,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
 
 #define TD_SCHED_GROUP(mask, n) ((void)0)
 #define TD_SCHED_FENCE() ((void)0)
+#define TD_VGPR_FLOOR(n) ((void)0)
 #define TD_PIN(x) ((void)0)
 #define TD_UNIFORM(x) (x)
 #define TD_SLEEP(n) ((void)0)
