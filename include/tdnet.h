@@ -41,6 +41,7 @@ typedef struct tdnet_cfg {
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
 #define TDNET_FUSION_DEFAULT 6
+#define TDNET_OVERLAP_DEFAULT 1
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
                                 convs (Cin >= 256, Cout >= 128), 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) =
@@ -64,7 +65,14 @@ typedef struct tdnet_opts {
                                      fragment layout instead of staging it through LDS (td_conv_ad.h),
                                 64 = the 36 planes of the Winograd workspaces V / M padded by 24 rows each (an unpadded plane is a
                                      power of two bytes: 36 concurrent streams on the same HBM channels)                         */
-    int32_t reserved[9];     /* must be 0                                                                                        */
+    int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
+                                1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
+                                    even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent
+                                    chains -- on two HIP streams: the HBM-bound transforms of one chain run under the MFMA-bound GEMMs of
+                                    the other (low-register transform kernels that fit beside three resident GEMM workgroups per CU),
+                                2 = the low-register transform kernels for every F(4x4) conv, chained or not,
+                                bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
+    int32_t reserved[8];     /* must be 0                                                                                        */
 } tdnet_opts;
 void tdnet_opts_default(tdnet_opts* o);
 

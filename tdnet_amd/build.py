@@ -1,24 +1,60 @@
-"""Build libtdnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libtdnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is STAMPED with a hash of the sources it was built from (every file under csrc/ + include/tdnet.h): the hash is
+compiled into tdnet_version(), build() rebuilds whenever the stamp of the existing .so differs from the sources on disk (mtimes are
+not trusted: the prebuilt .so travels to the GPU box with the tree), and smoke() / tests/test_gpu_harness.py assert that the
+library a GPU process loaded carries the hash of the shipped sources -- so a green GPU run proves it ran HEAD's kernels.
+"""
+import glob
+import hashlib
 import os
+import re
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libtdnet_hip.so")
-import glob  # noqa: E402
-SRCS = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(os.path.dirname(HERE), "include", "tdnet.h"), os.path.abspath(__file__)]
+HEADER = os.path.join(os.path.dirname(HERE), "include", "tdnet.h")
+STAMP_MARK = b"tdnet-src-hash:"
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*"))) + [HEADER]
+
+
+def source_hash():
+    """sha256 over (file name, content) of every source, 16 hex digits."""
+    h = hashlib.sha256()
+    for p in sources():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def built_hash(path=OUT):
+    """The stamp inside a built library (read from the file, without loading it); None if absent."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        m = re.search(re.escape(STAMP_MARK) + rb"([0-9a-f]{16})", f.read())
+    return m.group(1).decode() if m else None
 
 
 def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in SRCS):
+    want = source_hash()
+    if not force and built_hash() == want:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
-           os.path.join(CSRC, "td_model.hip"), "-o", OUT]
+           '-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, "td_model.hip"), "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    if built_hash() != want:
+        raise RuntimeError("libtdnet_hip.so was built but does not carry the source hash %s" % want)
     return OUT
 
 

@@ -76,8 +76,15 @@ struct ConvLds {
 // of scalar compares and branches around every value (a dozen branches per 16-byte store, ~400 per tile and wave; a branch costs
 // the wave tens of cycles during which it issues nothing).  max(v, 0) + slope * min(v, 0) with slope = 1 / 0 / 0.01 is the same
 // function -- one of the two terms is always zero, so the result is rounded exactly like v, 0 or 0.01f * v.
+// Non-finite values behave like the reference's modules: NaN propagates through every activation (a max/min formulation returns the
+// OTHER operand for NaN and would hide a corrupted accumulator as 0), ReLU(-inf) = 0, LeakyReLU(-inf) = identity(-inf) = -inf.  The
+// negative branch clamps to -FLT_MAX only when slope == 0, so that 0 * (-inf) cannot make a NaN; slope is wave-uniform, the clamp
+// bound a loop-invariant SGPR.  Negative inputs of ReLU give -0.0f (0 * v), which compares and adds like +0.
 TD_DEV float td_act_slope(int act) { return act == 1 ? 0.f : act == 2 ? 0.01f : 1.f; }
-TD_DEV float td_activate(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+TD_DEV float td_activate(float v, float slope) {
+    const float lo = slope == 0.f ? -3.402823466e+38f : -__builtin_inff();
+    return v < 0.f ? slope * fmaxf(v, lo) : v;
+}
 
 // The 16-byte path of td_store_acc.  Everything here is VALU work of a wave that has no MFMA to issue, and while the other resident
 // waves keep the matrix pipe busy such instructions issue slowly (tools/gemm_trace.hip: 6 us for an epilogue that takes 2 us on an
@@ -185,8 +192,16 @@ TD_DEV void td_store_acc(const f32x16 (&acc)[MT][NT], float* out, const float* b
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool STEM, bool DEEP>
+// FLUSH (two-stage pipeline only; a power of two, 0 = off): every FLUSH K steps the MFMA accumulators are added into a second
+// register set and cleared.  The MFMA sums its K products as ONE sequential fp32 chain per output (bit-identical to an fmaf chain);
+// at K = 9 * 512 = 4608 (layer4 on the direct path) that chain's rounding error is ~sqrt(K) ulps of the partial sums and was
+// 3.5x (rms) / 6.8x (max) what oneDNN's blocked summation leaves on the same graph with un-calibrated weights
+// (tests/test_gpu_model.py::test_uncalibrated_reference_init).  Blocks of FLUSH * 32 = 512 products summed once bring the chain to
+// sqrt(512) + sqrt(9): the direct kernel is then as accurate as the Winograd paths, whose GEMM chains are 512 long by construction.
+// Cost: MT * NT * 16 more VGPRs and that many v_add every FLUSH steps; launched only for 3x3 convs with >= 64 K steps.
+template <int BM, int BN, int WGM, int WGN, int KS, bool STEM, bool DEEP, int FLUSH = 0>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
+    static_assert(FLUSH == 0 || (DEEP && (FLUSH & (FLUSH - 1)) == 0 && FLUSH >= 2), "FLUSH: a power of two, two-stage pipeline only");
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
     constexpr int AL = BM / 32, BL = BN / 32;          // float4 slots per thread per step
@@ -397,6 +412,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
         __syncthreads();
         // Whole two-step periods, then the odd last step on its own: with `if (last) break;` in the MIDDLE of the loop the compiler
         // keeps two copies of the accumulators and moves all of them (32 v_mov_b64 for a 128 x 128 tile) every iteration.
+        f32x16 part[FLUSH ? MT : 1][FLUSH ? NT : 1];       // FLUSH: the blocks already summed
+        if constexpr (FLUSH > 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+        }
         int step = 0;
         for (; step + 1 < p.nsteps; step += 2) {
             load_tile(ra2, rb2);                        // even step: set 1 holds tile step+1, set 2 receives tile step+2
@@ -405,8 +429,26 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
             load_tile(ra, rb);                          // odd step: set 2 holds tile step+2, set 1 receives tile step+3
             compute(1, std::true_type{}, ra2, rb2);
             __syncthreads();
+            if constexpr (FLUSH > 0) {
+                if (((step + 2) & (FLUSH - 1)) == 0) {  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            part[i][j] = part[i][j] + acc[i][j];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                        }
+                }
+            }
         }
         if (step < p.nsteps) compute(0, std::false_type{}, ra, rb);   // nsteps odd: the last tile is in LDS buffer 0, nothing left to stage
+        if constexpr (FLUSH > 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = part[i][j] + acc[i][j];
+        }
     }
 
     td_store_acc<MT, NT>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
@@ -496,6 +538,7 @@ static inline void conv_launch_t(const ConvArgs& a, int KS, bool stem, hipStream
     const int lds = ConvLds<BM, BN>::BYTES;
     if (stem && KS == 7) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 7, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
     else if (stem) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, true, DEEP>), dim3(grid), dim3(256), lds, s, a);
+    else if (KS == 3 && DEEP && a.nsteps >= 64) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, false, DEEP, DEEP ? 16 : 0>), dim3(grid), dim3(256), lds, s, a);   // long K: blocked summation
     else if (KS == 3) TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 3, false, DEEP>), dim3(grid), dim3(256), lds, s, a);
     else TD_LAUNCH((k_conv_igemm<BM, BN, WGM, WGN, 1, false, DEEP>), dim3(grid), dim3(256), lds, s, a);
 }

@@ -26,6 +26,8 @@ struct GemmArgs {
     int tiles_m, tiles_n; // per batch
     int MP;               // rows between consecutive batches of a and out (>= M; padded planes of the Winograd workspaces, td_wino.h)
     int stagger;          // tdnet_opts.stagger (units of 1/8 tile): start delay of the co-resident workgroups, see the kernel
+    int wshare = 0;       // nbatch > 1 with ONE weight set and bias for all batches: a 1x1 conv over a strided set of image rows (batch = row,
+                          // M = W pixels, MP = row pitch in pixels) -- the downsample conv of one row-parity chain (td_model.hip); resid must be null
 #ifdef TD_GEMM_TRACE      // tools/gemm_trace.hip only: per workgroup 64 x u64 -- HW_ID, XCC_ID, start, then (end of K loop, end of epilogue) per tile
     unsigned long long* trace;   // in s_memrealtime ticks (100 MHz); TD_GEMM_TRACE == 2: the end of every two-step period as well
 #endif
@@ -105,7 +107,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     unsigned a_off[AL], b_off[BL];
     auto loader_enter_tile = [&]() {
         a_buf = td_make_buf(p.a + (size_t)lpos.b * p.MP * p.K, a_bytes);
-        w_buf = td_make_buf(p.wp + (size_t)lpos.b * nsteps * 8 * p.NPad * 4, w_bytes);
+        w_buf = td_make_buf(p.wp + (p.wshare ? (size_t)0 : (size_t)lpos.b * nsteps * 8 * p.NPad * 4), w_bytes);
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const int m = lpos.tm * BM + a_row + 32 * i;
@@ -282,7 +284,7 @@ static inline void gemm_launch_t(GemmArgs a, int bpc, int grid_cap, hipStream_t 
     const long total = (long)a.tiles_m * a.tiles_n * a.nbatch;
     long grid = grid_cap > 0 ? grid_cap : 256L * bpc;
     if (grid > total) grid = total;
-    if (a.nbatch > 1) TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 1>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
+    if (a.nbatch > 1 && !a.wshare) TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 1>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
     else if (!a.resid) TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 2>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
     else TD_LAUNCH((k_gemm_persistent<BM, BN, WGM, WGN, 0>), dim3((unsigned)grid), dim3(256), (ConvLds<BM, BN>::BYTES), s, a);
 }

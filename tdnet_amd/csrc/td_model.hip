@@ -62,7 +62,12 @@ struct DevGuard {
     if (!dev_guard_.ok) { td_fail("cannot select HIP device %d", (n)->cfg.device); return __VA_ARGS__; }
 
 extern "C" const char* tdnet_last_error(void) { return g_err; }
-extern "C" const char* tdnet_version(void) { return "tdnet_amd 0.1 (gfx950, fp32 MFMA)"; }
+// The build stamps the library with a hash of its sources (tdnet_amd/build.py: -DTDNET_SRC_HASH): tests and smoke() compare it with
+// the sources that were shipped, so a stale prebuilt .so cannot pass for HEAD's kernels.
+#ifndef TDNET_SRC_HASH
+#define TDNET_SRC_HASH "unstamped"
+#endif
+extern "C" const char* tdnet_version(void) { return "tdnet_amd 0.3 (gfx950, fp32 MFMA) tdnet-src-hash:" TDNET_SRC_HASH; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // architecture description (same rules as tdnet_amd/arch.py; resnet.py:114-202)
@@ -119,6 +124,8 @@ struct ConvLayer {
     bool in16 = false, out16 = false;                                  // h16 only: the input (+ residual) / output map is stored as fp16 in HBM
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
+    int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
+    int vw = 0;                                                        // != 0: the low-register F(4x4) transform kernels with vw channels per lane (td_wino.h k_wino4_*_c)
     int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3)): d_wp = (m+2)^2 packed 1x1 weight sets (td_wino.h)
     float* d_zero = nullptr;                                           // zero bias for the batched GEMM pass
     ConvTile tile = CT_128x128;
@@ -139,6 +146,7 @@ extern "C" void tdnet_opts_default(tdnet_opts* o) {
     o->stagger = 0;
     o->attention = TDNET_ATTENTION_DEFAULT;
     o->fusion = TDNET_FUSION_DEFAULT;
+    o->overlap = TDNET_OVERLAP_DEFAULT;
 }
 static tdnet_opts opts_or_default(const tdnet_opts* o) {
     tdnet_opts d;
@@ -151,6 +159,8 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.stagger = d.stagger < 0 ? 0 : d.stagger > 64 ? 64 : d.stagger;
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
+    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0x33;
+    if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
     return d;
 }
 
@@ -158,7 +168,7 @@ static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2
 
 // Upload a BN-folded OIHW weight + bias as a ConvLayer for an output of M pixels.
 static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std::vector<float>& b, int Cout, int Cin, int KS,
-                           int stride, int dil, int act, bool stem, long M, const tdnet_opts& o, int forced_tile = -1) {
+                           int stride, int dil, int act, bool stem, long M, const tdnet_opts& o, int forced_tile = -1, int chunks = 1) {
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
     L.pers = o.gemm_persistent; L.stagger = o.stagger;
@@ -169,11 +179,14 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     L.wino = !wino_ok ? 0 : o.winograd >= 3 ? 4 : 2;
     L.wino_pad = (L.wino && (o.fusion & 64) && o.gemm_persistent && gemm_supports(Cin)) ? 24 : 0;   // 24 rows: 12..48 KB between plane phases
     if (L.wino) {
+        L.chunks = (L.wino == 4 && chunks > 1 && dil % chunks == 0 && o.gemm_persistent && gemm_supports(Cin)) ? chunks : 1;
+        chunks = L.chunks;
+        L.vw = (L.wino == 4 && (L.chunks > 1 || (o.overlap & 2))) ? (1 << ((o.overlap >> 4) & 3)) : 0;
         // nb = (m+2)^2 batched [T x Cin] x [Cin x Cout] GEMMs, T = M / m^2 tiles: nb * T rows in total -> pick the tile for that many workgroups
         const int nb = (L.wino + 2) * (L.wino + 2);
         const bool pers = o.gemm_persistent && gemm_supports(Cin);
         L.tile = forced_tile >= 0 ? (ConvTile)forced_tile
-               : pers ? gemm_pick_tile(wino_tiles_estimate(M, dil, L.wino), nb, Cout, deep)
+               : pers ? gemm_pick_tile(wino_tiles_estimate(M, dil, L.wino) / chunks, nb, Cout, deep)
                       : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout, deep);
         L.CoutPad = conv_cout_pad(Cout, L.tile);
         L.nsteps = conv_nsteps(Cin, 1, false);
@@ -281,6 +294,16 @@ struct tdnet {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;                 // Encoding's q / k projections beside w_vs (fusion bit 1)
+    // Row-parity chains (tdnet_opts.overlap bit 1): the trailing run of even-dilation Winograd convs of the backbone starts at conv
+    // seg_conv (0: conv1, 1: conv2) of block seg_block (-1: off).  Chain 0 runs on the forward's stream with wino_v / wino_m, chain 1
+    // on `chain2` with wino_v2 / wino_m2.  The chains may drift apart by more than a block and the channel count changes inside the
+    // run, so no map of the run is written in place or shared between blocks: block b owns seg_t[b] (conv1 output), seg_r[b]
+    // (downsample output) and seg_x[b] (block output).
+    int seg_block = -1, seg_conv = 0;
+    hipStream_t chain2 = nullptr;
+    hipEvent_t ev_cfork = nullptr, ev_cjoin = nullptr;
+    float *wino_v2 = nullptr, *wino_m2 = nullptr;
+    std::vector<float*> seg_t, seg_r, seg_x;
     float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
     bool act16 = false;                                               // precision = 1: the maps between the backbone's convs are fp16 in HBM
     _Float16* vt16 = nullptr;                                         // fp16 attention: V' transposed [DV][LkPad]
@@ -437,6 +460,11 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
     for (auto& r : n->recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     if (n->vt16) hipFree(n->vt16);
+    for (float* q : {n->wino_v2, n->wino_m2}) if (q) hipFree(q);
+    for (auto* v : {&n->seg_t, &n->seg_r, &n->seg_x}) for (float* q : *v) if (q) hipFree(q);
+    if (n->chain2) hipStreamDestroy(n->chain2);
+    if (n->ev_cfork) hipEventDestroy(n->ev_cfork);
+    if (n->ev_cjoin) hipEventDestroy(n->ev_cjoin);
     if (n->side) hipStreamDestroy(n->side);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ev_join) hipEventDestroy(n->ev_join);
@@ -489,6 +517,32 @@ static int upload(float** d, const std::vector<float>& v) {
     return 0;
 }
 
+// Row-parity chains: which convs can run as an even-row and an odd-row half (tdnet_opts.overlap bit 1).  A stride-1 3x3 conv with an
+// EVEN dilation reads, for an output row y, only the input rows y + k * dil: rows of y's parity.  So from the first such conv to the end
+// of the backbone (ResNet-18/34: layer3.0.conv2 .. layer4.1.conv2, dilations 2,2,2,4,4,8,4 -- resnet.py:181-198) the even and the odd
+// rows are two INDEPENDENT chains of convs (residual adds and the 1x1 downsample are pixel-wise), each with half the Winograd tiles.
+static bool conv_chainable(int cin, int cout, int stride, int dil, const tdnet_opts& o) {
+    return stride == 1 && dil % 2 == 0 && cin >= 128 && cout >= 128 && gemm_supports(cin) && cout % 4 == 0;
+}
+static void plan_chains(tdnet* n) {
+    n->seg_block = -1; n->seg_conv = 0;
+    const tdnet_opts& o = n->opts;
+    if (!(o.overlap & 1) || o.winograd < 3 || o.precision || !o.gemm_persistent || n->deep) return;
+    int sb = -1, sc = 0;
+    for (int b = (int)n->bspec.size() - 1; b >= 0; --b) {
+        const BlockSpec& S = n->bspec[b];
+        if (S.bott || !conv_chainable(S.cout, S.cout, 1, S.dil2, o)) break;
+        sb = b; sc = 1;
+        if (!conv_chainable(S.cin, S.cout, S.stride, S.dil1, o)) break;
+        sb = b; sc = 0;
+        if (S.ds && !(S.stride == 1 && gemm_supports(S.cin))) break;   // an earlier start would put this block's downsample inside the chains
+    }
+    n->seg_block = sb; n->seg_conv = sc;
+}
+static bool in_chain(const tdnet* n, int block, int conv) {
+    return n->seg_block >= 0 && (block > n->seg_block || (block == n->seg_block && conv >= n->seg_conv));
+}
+
 static int alloc_workspace(tdnet* n) {
     const size_t hw = (size_t)n->Lq, lk = (size_t)n->Lk;
     const bool psp = n->cfg.model == 1;
@@ -533,6 +587,16 @@ static int alloc_workspace(tdnet* n) {
         upd(L0.head3, n->h, n->w);
         n->wino_v_floats = vmax; n->wino_m_floats = mmax;
         if (vmax && (dev_alloc(&n->wino_v, vmax) || dev_alloc(&n->wino_m, mmax))) return -1;
+        if (n->seg_block >= 0) {                                       // chain 1's own workspaces (a chunk is never larger than the conv) + the run's maps
+            if (dev_alloc(&n->wino_v2, vmax) || dev_alloc(&n->wino_m2, mmax)) return -1;
+            const size_t nb = L0.blocks.size();
+            n->seg_t.assign(nb, nullptr); n->seg_r.assign(nb, nullptr); n->seg_x.assign(nb, nullptr);
+            for (size_t b = (size_t)n->seg_block; b < nb; ++b) {
+                const size_t sz = (size_t)n->h * n->w * n->bspec[b].cout;   // the run is at the backbone's output resolution (stride-1 convs)
+                if (dev_alloc(&n->seg_t[b], sz) || dev_alloc(&n->seg_x[b], sz)) return -1;
+                if (n->bspec[b].ds && dev_alloc(&n->seg_r[b], sz)) return -1;
+            }
+        }
     }
     if (psp) return 0;
     if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
@@ -562,6 +626,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         if (!n->sd.count(k)) return td_fail("Missing key in state_dict: \"%s\"", k.c_str());
     }
     const int C = n->C, DV = n->DV, FS = C / (2 * 4), NC = n->cfg.nclass;
+    plan_chains(n);
     n->paths.resize(n->P);
     char b[160];
     for (int p = 0; p < n->P; ++p) {
@@ -581,7 +646,9 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             if (make_conv_layer(L.stem, f.w, f.b, 64, 3, 7, 2, 1, 1, true, (long)n->H1 * n->W1, n->opts)) return -1;
         }
         int ch = n->H2, cw = n->W2;
-        for (auto& s : n->bspec) {
+        for (size_t bsi = 0; bsi < n->bspec.size(); ++bsi) {
+            const BlockSpec& s = n->bspec[bsi];
+            const int k1 = in_chain(n, (int)bsi, 0) ? 2 : 1, k2 = in_chain(n, (int)bsi, 1) ? 2 : 1;   // row-parity chunks of conv1 / conv2
             BlockLayers B;
             const std::string bp = pre + "." + s.name;
             const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
@@ -596,9 +663,10 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
                 if (make_conv_layer(B.c3, f3.w, f3.b, s.cout, s.planes, 1, 1, 1, 1, false, M, n->opts)) return -1;   // ReLU after the residual add
             } else {
                 Folded f1 = fold(n, bp + ".conv1.weight", "", bp + ".bn1", s.cout);
-                if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M, n->opts)) return -1;
+                if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M, n->opts, -1, k1)) return -1;
                 Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.cout);
-                if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M, n->opts)) return -1;
+                if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M, n->opts, -1, k2)) return -1;
+                if ((k1 > 1 && B.c1.chunks != k1) || (k2 > 1 && B.c2.chunks != k2)) return td_fail("internal: chain plan and conv layers disagree");
             }
             B.has_ds = s.ds;
             if (s.ds) {
@@ -703,6 +771,11 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         TD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         TD_HIP(hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, least));
     }
+    if (n->seg_block >= 0) {
+        TD_HIP(hipStreamCreateWithFlags(&n->chain2, hipStreamNonBlocking));
+        TD_HIP(hipEventCreateWithFlags(&n->ev_cfork, hipEventDisableTiming));
+        TD_HIP(hipEventCreateWithFlags(&n->ev_cjoin, hipEventDisableTiming));
+    }
     TD_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TD_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     TD_HIP(hipEventCreateWithFlags(&n->ev_fork2, hipEventDisableTiming));
@@ -735,52 +808,89 @@ static void prof_end(tdnet* n, hipStream_t s) {
 // plane LayerNorm applied to the conv's INPUT inside a Winograd input transform (td_wino.h WinoArgs.ln_*)
 struct LnFuse { const float *mean, *rstd, *g, *b; };
 
+// One row-parity / column-parity chunk of a Winograd conv (td_wino.h WinoArgs.Tc..cx): the tiles whose phase row is ny * i + cy and
+// whose phase column is nx * j + cx.  {1, 0, 1, 0} = the whole conv.
+struct WinoChunk { int ny = 1, cy = 0, nx = 1, cx = 0; };
+
+template <int VW>
+static void launch_wino4_c(bool out_side, const WinoArgs& wa, hipStream_t s) {
+    if (out_side) TD_LAUNCH((k_wino4_out_c<VW>), dim3(wino_chunk_grid(wa.Tc, wa.Cout, VW)), dim3(256), 0, s, wa);
+    else TD_LAUNCH((k_wino4_in_c<VW>), dim3(wino_chunk_grid(wa.Tc, wa.C, VW)), dim3(256), 0, s, wa);
+}
+
+// Winograd conv (or one chunk of it): input transform -> (m+2)^2 batched GEMMs -> output transform, all on stream s.
+// V / Mb: workspaces for THIS call ([nb][Tc + pad][C]); nullptr = the handle's (n->wino_v / wino_m) or, without a handle, temporary ones.
+static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
+                    const LnFuse* lnf, const WinoChunk& ck, float* V, float* Mb) {
+    const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
+    const long T = (long)L.dil * L.dil * TY * TX;
+    const bool chunked = ck.ny != 1 || ck.nx != 1;
+    if (chunked && (!L.vw || L.dil % ck.ny || L.dil % ck.nx)) return td_fail("internal: this conv cannot run in chunks");
+    const long Tc = (long)(L.dil / ck.ny) * (L.dil / ck.nx) * TY * TX;
+    const long TP = Tc + L.wino_pad;                                   // padded plane (td_wino.h WinoArgs.TP)
+    const int nb = (L.wino + 2) * (L.wino + 2);
+    bool own = false;
+    if (!V) {
+        own = n == nullptr || n->wino_v_floats < (size_t)nb * TP * L.Cin || n->wino_m_floats < (size_t)nb * TP * L.Cout;
+        if (own) {
+            if (n) { n->failed = true; return td_fail("internal: Winograd workspace too small"); }
+            if (dev_alloc(&V, (size_t)nb * TP * L.Cin) || dev_alloc(&Mb, (size_t)nb * TP * L.Cout)) return -1;
+        } else { V = n->wino_v; Mb = n->wino_m; }
+    }
+    WinoArgs wa;
+    wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
+    wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act; wa.TP = (int)TP;
+    wa.ln_mean = lnf ? lnf->mean : nullptr; wa.ln_rstd = lnf ? lnf->rstd : nullptr; wa.ln_g = lnf ? lnf->g : nullptr; wa.ln_b = lnf ? lnf->b : nullptr;
+    wa.Tc = (int)Tc; wa.ny = ck.ny; wa.cy = ck.cy; wa.nx = ck.nx; wa.cx = ck.cx;
+    auto transform = [&](bool out_side) {
+        prof_begin(n, 2, false, 0, s);
+        const int C = out_side ? L.Cout : L.Cin;
+        if (L.vw == 1) launch_wino4_c<1>(out_side, wa, s);
+        else if (L.vw == 2 && C % 2 == 0) launch_wino4_c<2>(out_side, wa, s);
+        else if (L.vw == 4 && C % 4 == 0) launch_wino4_c<4>(out_side, wa, s);
+        else if (L.vw) launch_wino4_c<1>(out_side, wa, s);
+        else if (L.wino == 4 && out_side) TD_LAUNCH(k_wino4_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        else if (L.wino == 4) TD_LAUNCH(k_wino4_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        else if (out_side) TD_LAUNCH(k_wino_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        else TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
+        prof_end(n, s);
+    };
+    transform(false);
+    prof_begin(n, 0, 2, 2.0 * nb * Tc * (double)L.Cin * L.Cout, s);
+    if (L.pers && gemm_supports(L.Cin)) {
+        GemmArgs ga;
+        ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
+        ga.M = (int)Tc; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP; ga.stagger = L.stagger;
+        gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
+    } else {
+        ConvArgs g;
+        g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
+        g.H = 1; g.W = (int)Tc; g.Cin = L.Cin; g.Wo = (int)Tc; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
+        g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)Tc; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = nb;
+        conv_launch(g, L.tile, 1, false, s);
+    }
+    prof_end(n, s);
+    transform(true);
+    if (own) { TD_HIP(hipStreamSynchronize(s)); hipFree(V); hipFree(Mb); }
+    return 0;
+}
+
 // out[Ho*Wo][Cout] = act(conv(in[H][W][Cin]) + bias (+ resid))
 static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
                     int* Ho_out = nullptr, int* Wo_out = nullptr, const LnFuse* lnf = nullptr) {
     if (lnf && !L.wino) return td_fail("internal: LayerNorm fusion needs a Winograd input transform");
     const int Ho = out_size(H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(W, L.KS, L.stride, L.dil, L.pad);
     if (L.wino) {
-        const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
-        const long T = (long)L.dil * L.dil * TY * TX;
-        const long TP = T + L.wino_pad;                                // padded plane (td_wino.h WinoArgs.TP)
-        const int nb = (L.wino + 2) * (L.wino + 2);
-        float *V = nullptr, *Mb = nullptr;
-        const bool own = n == nullptr || n->wino_v_floats < (size_t)nb * TP * L.Cin || n->wino_m_floats < (size_t)nb * TP * L.Cout;
-        if (own) {
-            if (n) { n->failed = true; return td_fail("internal: Winograd workspace too small"); }
-            if (dev_alloc(&V, (size_t)nb * TP * L.Cin) || dev_alloc(&Mb, (size_t)nb * TP * L.Cout)) return -1;
-        } else { V = n->wino_v; Mb = n->wino_m; }
-        WinoArgs wa;
-        wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
-        wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)T; wa.act = L.act; wa.TP = (int)TP;
-        wa.ln_mean = lnf ? lnf->mean : nullptr; wa.ln_rstd = lnf ? lnf->rstd : nullptr; wa.ln_g = lnf ? lnf->g : nullptr; wa.ln_b = lnf ? lnf->b : nullptr;
-        prof_begin(n, 2, false, 0, s);
-        if (L.wino == 4) TD_LAUNCH(k_wino4_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
-        else TD_LAUNCH(k_wino_in, dim3(td_grid_for(T * (L.Cin / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
-        prof_end(n, s);
-        prof_begin(n, 0, 2, 2.0 * nb * T * (double)L.Cin * L.Cout, s);
-        if (L.pers && gemm_supports(L.Cin)) {
-            GemmArgs ga;
-            ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
-            ga.M = (int)T; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP; ga.stagger = L.stagger;
-            gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
-        } else {
-            ConvArgs g;
-            g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
-            g.H = 1; g.W = (int)T; g.Cin = L.Cin; g.Wo = (int)T; g.Cout = L.Cout; g.CoutPad = L.CoutPad;
-            g.stride = 1; g.dil = 1; g.pad = 0; g.M = (int)T; g.nsteps = L.nsteps; g.act = 0; g.tiles_n = 0; g.stagger = 0; g.nbatch = nb;
-            conv_launch(g, L.tile, 1, false, s);
-        }
-        prof_end(n, s);
-        prof_begin(n, 2, false, 0, s);
-        if (L.wino == 4) TD_LAUNCH(k_wino4_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
-        else TD_LAUNCH(k_wino_out, dim3(td_grid_for(T * (L.Cout / 4), 256, 256 * 16)), dim3(256), 0, s, wa);
-        prof_end(n, s);
-        if (own) { TD_HIP(hipStreamSynchronize(s)); hipFree(V); hipFree(Mb); }
         if (Ho_out) *Ho_out = H;
         if (Wo_out) *Wo_out = W;
-        return 0;
+        if (L.chunks > 1 && !n) {                                      // operator tests: the chunks one after the other on one stream
+            for (int c = 0; c < L.chunks; ++c) {
+                WinoChunk ck; ck.ny = L.chunks; ck.cy = c;
+                TD_TRY(run_wino(n, L, in, H, W, resid, out, s, lnf, ck, nullptr, nullptr));
+            }
+            return 0;
+        }
+        return run_wino(n, L, in, H, W, resid, out, s, lnf, WinoChunk(), nullptr, nullptr);
     }
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
@@ -931,6 +1041,57 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
     return 0;
 }
 
+// The 1x1 stride-1 downsample conv (resnet.py:172-177) on the image rows y = ny * i + cy only: a batched GEMM, batch = row, M = W pixels,
+// row pitch ny * W pixels, one weight set (td_gemm.h GemmArgs.wshare).
+static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int W, float* out, int ny, int cy, hipStream_t s) {
+    if (L.KS != 1 || L.stride != 1 || L.h16 || !L.pers || !gemm_supports(L.Cin)) return td_fail("internal: downsample conv cannot run on image rows");
+    const int rows = (H - cy + ny - 1) / ny;
+    if (rows <= 0) return 0;
+    GemmArgs ga;
+    ga.a = in + (size_t)cy * W * L.Cin; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = nullptr; ga.out = out + (size_t)cy * W * L.Cout;
+    ga.M = W; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = rows; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = ny * W;
+    ga.stagger = L.stagger; ga.wshare = 1;
+    prof_begin(n, 0, 0, 2.0 * rows * W * (double)L.Cin * L.Cout, s);
+    gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
+    prof_end(n, s);
+    return 0;
+}
+
+// The trailing run of even-dilation Winograd convs as two row-parity chains (plan_chains): chain 0 on s, chain 1 on n->chain2.
+// Each chain is an in-order sequence transform -> GEMMs -> transform -> ..., so nothing synchronises the two between fork and join;
+// while one chain's GEMM holds the matrix pipes, the other's transforms (HBM-bound, one wave per SIMD beside the GEMM's three) run
+// under it, and a chain's GEMM workgroups start as the other's retire.  Host enqueue order alternates between the chains so that
+// neither stream runs dry while the other's launches are being issued.
+static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
+    const int sb = n->seg_block, nblk = (int)L.blocks.size();
+    hipStream_t st[2] = {s, n->chain2};
+    float* Vw[2] = {n->wino_v, n->wino_v2};
+    float* Mw[2] = {n->wino_m, n->wino_m2};
+    {   // the part of the first block that precedes the run: its downsample, and conv1 when the run starts at conv2
+        BlockLayers& B = L.blocks[sb];
+        if (n->seg_conv == 1) TD_TRY(run_conv(n, B.c1, n->bx, h, w, nullptr, n->seg_t[sb], s));
+        if (B.has_ds) TD_TRY(run_conv(n, B.ds, n->bx, h, w, nullptr, n->seg_r[sb], s));
+    }
+    TD_HIP(hipEventRecord(n->ev_cfork, s));
+    TD_HIP(hipStreamWaitEvent(n->chain2, n->ev_cfork, 0));
+    for (int b = sb; b < nblk; ++b) {
+        BlockLayers& B = L.blocks[b];
+        const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
+        for (int c = 0; c < 2; ++c) {
+            WinoChunk ck; ck.ny = 2; ck.cy = c;
+            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+            if (B.has_ds && b > sb) TD_TRY(run_ds_rows(n, B.ds, xin, h, w, n->seg_r[b], 2, c, st[c]));
+        }
+        for (int c = 0; c < 2; ++c) {
+            WinoChunk ck; ck.ny = 2; ck.cy = c;
+            TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+        }
+    }
+    TD_HIP(hipEventRecord(n->ev_cjoin, n->chain2));
+    TD_HIP(hipStreamWaitEvent(s, n->ev_cjoin, 0));
+    return 0;
+}
+
 static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s) {
     const int DV = n->DV;
     // backbone (resnet.py:204-215)
@@ -944,7 +1105,13 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     }
     run_maxpool(n, n->deep ? n->br : n->s1, n->H1, n->W1, n->SC, n->bx, s, n->opts.fusion, n->act16 ? ((n->deep || L.stem.out16) ? 2 : 1) : 0);
     int ch = n->H2, cw = n->W2;
-    for (auto& B : L.blocks) {
+    for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
+        BlockLayers& B = L.blocks[bi];
+        if ((int)bi == n->seg_block) {                                 // the rest of the backbone as two row-parity chains
+            if (ch != n->h || cw != n->w) return td_fail("internal: the chained run is not at the output resolution");
+            TD_TRY(run_parity_chains(n, L, ch, cw, s));
+            break;
+        }
         int oh, ow;
         // fp16-activation mode: the LAST conv of the backbone writes fp32 while its residual is an fp16 map -- not in place (4-byte
         // stores over 2-byte elements other lanes still have to read): it goes to br, free here (the last block has no downsample)
@@ -963,7 +1130,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
         }
         ch = oh; cw = ow;
     }
-    float* c4 = n->c4 = n->act16 ? n->br : n->bx;
+    float* c4 = n->c4 = n->seg_block >= 0 ? n->seg_x.back() : n->act16 ? n->br : n->bx;
     // pyramid pooling slice (td4_psp18.py:271-284)
     if (n->cfg.model == 1) {                                           // pspnet.py:73-89: PSPHead on c4, no temporal state
         run_ppm(n, c4, n->h, n->w, n->C, n->C, n->C / 4, L.d_ppm_w, L.d_ppm_b, 0, n->rowpart, n->pooled, n->ppmfeat, n->z, s);
@@ -1304,7 +1471,8 @@ extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const flo
     if (bias_host) b.assign(bias_host, bias_host + Cout);
     const int pad = dil * (KS / 2);
     const long M = (long)out_size(H, KS, stride, dil, pad) * out_size(W, KS, stride, dil, pad);
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M, o, tile < 0 ? -1 : tile)) return -1;
+    // tdnet_opts.overlap bit 1: an even-dilation Winograd conv runs as its two row-parity chunks (here one after the other)
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M, o, tile < 0 ? -1 : tile, (o.overlap & 1) ? 2 : 1)) return -1;
     const int rc = run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
     TD_HIP(hipStreamSynchronize((hipStream_t)stream));
     TD_HIP(hipGetLastError());

@@ -36,6 +36,11 @@ struct WinoArgs {
     // same operation order, so fused and unfused results are bit-identical -- and stays 0 outside the image (the conv's zero padding
     // applies to the normalised map).  ln_mean == nullptr: off.
     const float* ln_mean; const float* ln_rstd; const float* ln_g; const float* ln_b;
+    // Chunked transforms (k_wino4_in_c / k_wino4_out_c): a launch covers the Tc tiles whose phase row is py = ny * i + cy and whose
+    // phase column is px = nx * j + cx (i < dil / ny, j < dil / nx); V / Mb then hold ONLY those tiles ([36][TP][C], TP >= Tc).  With
+    // an even dilation and ny = 2 the two chunks are the even and the odd image rows: a dilated conv maps a row parity onto itself,
+    // so through a run of even-dilation convs the two chunks are independent chains (td_model.hip run_parity_chains).
+    int Tc, ny, cy, nx, cx;
 };
 // Buffer descriptors of a transform: every access is an UNCONDITIONAL range-checked buffer access (a tap outside the image, an output
 // pixel outside the map or a missing residual turn into an out-of-range offset / a zero-record descriptor) -- no branch around any
@@ -275,6 +280,177 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
         }
     }
 }
+
+
+// ---- low-register, chunk-aware F(4x4) transforms -----------------------------------------------------------------------------
+// Same arithmetic as k_wino4_in / k_wino4_out, element for element (results are bit-identical), laid out for CO-RESIDENCY with the
+// persistent GEMM: that kernel holds 3 workgroups per CU for its whole life at 136 VGPRs per wave, which leaves 104 registers
+// per SIMD -- the float4-per-lane transforms above need 194 / 244 and could only start when a GEMM workgroup retires.  Here a
+// WAVE owns (tile, slice of 64 * VW channels) and a lane VW channels (VW = 1: 60-odd VGPRs), so one transform wave fits beside
+// three GEMM waves on every SIMD and the HBM-bound transform of one chunk runs UNDER the MFMA-bound GEMM of another.  The tile is
+// wave-uniform: its decode (divisions by TX, TY, dil) and every pixel offset are scalar work, a lane adds its channel offset.
+template <int VW> struct WinoVec;
+template <> struct WinoVec<1> {
+    typedef float T;
+    static TD_DEV T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld1(b, v, s); }
+    static TD_DEV void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st1(b, v, s, x); }
+    static TD_DEV T act(T x, float slope) { return td_activate(x, slope); }
+};
+template <> struct WinoVec<2> {
+    typedef f32x2 T;
+    static TD_DEV T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld2(b, v, s); }
+    static TD_DEV void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st2(b, v, s, x); }
+    static TD_DEV T act(T x, float slope) { x[0] = td_activate(x[0], slope); x[1] = td_activate(x[1], slope); return x; }
+};
+template <> struct WinoVec<4> {
+    typedef f32x4 T;
+    static TD_DEV T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld4(b, v, s); }
+    static TD_DEV void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st4(b, v, s, x); }
+    static TD_DEV T act(T x, float slope) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = td_activate(x[e], slope);
+        return x;
+    }
+};
+template <typename T>
+TD_DEV void td_wino4_bt_t(const T (&d)[6], T (&t)[6]) {
+    const T a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = c + e;
+    t[4] = c - e;
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+template <typename T>
+TD_DEV void td_wino4_at_t(const T (&m)[6], T (&y)[4]) {
+    const T p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = m[0] + p + r;
+    y[1] = q + 2.f * s;
+    y[2] = p + 4.f * r;
+    y[3] = q + 8.f * s + m[5];
+}
+// (wave-uniform) tile of a chunk -> phase and tile coordinates; returns false past the end
+struct WinoTile { int tl, sl, py, px, ty, tx; };
+TD_DEV bool td_wino_chunk_tile(const WinoArgs& p, int slices, WinoTile& w) {
+    const int wv = TD_UNIFORM((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wv >= p.Tc * slices) return false;
+    w.tl = wv / slices; w.sl = wv - w.tl * slices;
+    int t = w.tl;
+    w.tx = t % p.TX; t /= p.TX;
+    w.ty = t % p.TY; t /= p.TY;
+    const int pw = p.dil / p.nx;
+    w.px = p.nx * (t % pw) + p.cx;
+    w.py = p.ny * (t / pw) + p.cy;
+    return true;
+}
+
+template <int VW>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
+    typedef WinoVec<VW> X;
+    typedef typename X::T T;
+    const int slices = (p.C + 64 * VW - 1) / (64 * VW);
+    WinoTile w;
+    if (!td_wino_chunk_tile(p, slices, w)) return;
+    const WinoBufs wb = td_wino_bufs(p);
+    const int c0 = (w.sl * 64 + (int)(threadIdx.x & 63)) * VW;        // this lane's first channel
+    const unsigned coff = c0 < p.C ? (unsigned)c0 * 4u : TD_BUF_OOB;  // lanes past C (C not a multiple of 64 VW): nothing read, nothing written
+    T m4 = T(0.f), r4 = T(0.f);
+    if (p.ln_mean) {
+        const TdBuf mb = td_make_buf(p.ln_mean, (unsigned)p.C * 4u), rb = td_make_buf(p.ln_rstd, (unsigned)p.C * 4u);
+        m4 = X::ld(mb, coff, 0u); r4 = X::ld(rb, coff, 0u);
+    }
+    T tm[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int x = w.px + p.dil * (4 * w.tx - 1 + c);
+        T d[6], col[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = w.py + p.dil * (4 * w.ty - 1 + r);
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;          // wave-uniform
+            const unsigned pix = (unsigned)y * (unsigned)p.W + (unsigned)x;
+            T z = X::ld(wb.in, ok ? coff : TD_BUF_OOB, ok ? pix * (unsigned)p.C * 4u : 0u);
+            if (p.ln_mean) {                                         // the arithmetic of td_wino_ld / k_ln_apply, same order
+                const float g = td_buf_ld1(wb.g, ok ? 0u : TD_BUF_OOB, ok ? pix * 4u : 0u), b = td_buf_ld1(wb.b, ok ? 0u : TD_BUF_OOB, ok ? pix * 4u : 0u);
+                z = (z - m4) * r4 * g + b;
+            }
+            d[r] = z;
+        }
+        td_wino4_bt_t(d, col);                                        // B^T d, one column
+#pragma unroll
+        for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
+    }
+    const unsigned plane = (unsigned)p.TP * (unsigned)p.C * 4u;
+    const TdBuf vb = td_make_buf(p.V, 36u * plane);
+    const unsigned voff = (unsigned)w.tl * (unsigned)p.C * 4u;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        T v[6];
+        td_wino4_bt_t(tm[r], v);                                      // (.) B, one row
+#pragma unroll
+        for (int c = 0; c < 6; ++c) X::st(vb, coff, (unsigned)(r * 6 + c) * plane + voff, v[c]);
+    }
+}
+
+template <int VW>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_out_c(WinoArgs p) {
+    typedef WinoVec<VW> X;
+    typedef typename X::T T;
+    const int slices = (p.Cout + 64 * VW - 1) / (64 * VW);
+    WinoTile w;
+    if (!td_wino_chunk_tile(p, slices, w)) return;
+    const WinoBufs wb = td_wino_bufs(p);
+    const float slope = td_act_slope(p.act);
+    const int c0 = (w.sl * 64 + (int)(threadIdx.x & 63)) * VW;
+    const unsigned coff = c0 < p.Cout ? (unsigned)c0 * 4u : TD_BUF_OOB;
+    unsigned offy[4], offx[4];
+    bool oky[4], okx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = w.py + p.dil * (4 * w.ty + r), x = w.px + p.dil * (4 * w.tx + r);
+        oky[r] = y < p.H; okx[r] = x < p.W;
+        offy[r] = (unsigned)y * (unsigned)p.W * (unsigned)p.Cout * 4u;
+        offx[r] = (unsigned)x * (unsigned)p.Cout * 4u;
+    }
+    T rs[4][4];                                                       // residual first: in flight under the 36 plane loads
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = oky[r] && okx[c];
+            rs[r][c] = X::ld(wb.resid, ok ? coff : TD_BUF_OOB, ok ? offy[r] + offx[c] : 0u);
+        }
+    const unsigned plane = (unsigned)p.TP * (unsigned)p.Cout * 4u;
+    const TdBuf mb = td_make_buf(p.Mb, 36u * plane);
+    const unsigned moff = (unsigned)w.tl * (unsigned)p.Cout * 4u;
+    T sm[4][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        T m[6], col[4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r] = X::ld(mb, coff, (unsigned)(r * 6 + c) * plane + moff);
+        td_wino4_at_t(m, col);                                        // A^T m, one column
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[r][c] = col[r];
+    }
+    const TdBuf bb = td_make_buf(p.bias, (unsigned)p.Cout * 4u);
+    const T b = X::ld(bb, coff, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T o4[4];
+        td_wino4_at_t(sm[r], o4);                                     // (.) A, one row
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = oky[r] && okx[c];
+            T o = o4[c] + b;
+            o = o + rs[r][c];
+            X::st(wb.out, ok ? coff : TD_BUF_OOB, ok ? offy[r] + offx[c] : 0u, X::act(o, slope));
+        }
+    }
+}
+// grid of a chunked transform: one wave per (tile, channel slice)
+static inline unsigned wino_chunk_grid(int Tc, int C, int VW) { return (unsigned)(((long)Tc * ((C + 64 * VW - 1) / (64 * VW)) + 3) / 4); }
 
 
 // m = output tile edge (2 or 4)

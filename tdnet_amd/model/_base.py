@@ -79,7 +79,18 @@ class _TDNetBase(nn.Module):
     # ---- engine ----------------------------------------------------------------------------------------------
     def _get_engine(self, img):
         n, c, H, W = img.shape
-        dev = img.device.index or 0
+        return self._engine_for(H, W, img.device.index or 0, n)
+
+    def ensure_engine(self, H, W, device):
+        """Build the handle (weights, workspace, FIFO) from the stream geometry alone, before any frame is seen.  A path-parallel rank
+        that owns no frame of a short first round never calls encode(), yet it must accept its peers' cache entries
+        (parallel.PathParallelStream calls this before the first exchange)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise TdnetError("tdnet_amd runs on MI355X only: got device %s (no CPU fallback)" % device)
+        return self._engine_for(int(H), int(W), device.index or 0)
+
+    def _engine_for(self, H, W, dev, n=1):
         key = (H, W, dev)
         if self._engine is not None and self._engine_key == key:
             return self._engine
@@ -178,6 +189,8 @@ class _TDNetBase(nn.Module):
 
     def cache_push(self, q, k, v):
         """Append a peer's cache entry to the FIFO (contiguous fp32 CUDA tensors)."""
+        if self._engine is None:
+            raise RuntimeError("cache_push(): no handle yet -- call ensure_engine(H, W, device) (or encode a frame) first")
         self._engine.cache_push(q.data_ptr(), k.data_ptr(), v.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
 
     def reset(self):

@@ -96,7 +96,8 @@ class PathParallelStream:
     bit-identical to one GPU serving the stream, and W frames finish in about one frame's latency.
 
     `stage` is duck-typed (the model classes of tdnet_amd.model implement it): encode(img, pos_id), propagate(labels=) -> out,
-    cache_entry_numel_for(H, W) -> (nq, nk, nv), cache_export(q, k, v), cache_push(q, k, v).
+    cache_entry_numel_for(H, W) -> (nq, nk, nv), cache_export(q, k, v), cache_push(q, k, v), and optionally
+    ensure_engine(H, W, device), called once before the first exchange so that a rank without a frame can still push entries.
 
     `frame_size` = (H, W) of the stream.  The exchange buffers are sized from it (pure arithmetic on the architecture), NOT from a
     live engine: a rank that owns no frame of a short first round (T < world) still knows the geometry and takes part in every
@@ -124,6 +125,10 @@ class PathParallelStream:
                 self.frame_size = (int(f.shape[-2]), int(f.shape[-1]))
             nq, nk, nv = self.stage.cache_entry_numel_for(*self.frame_size)
             self._sizes = (nq, nk, nv)
+            # A rank that owns no frame of a short round (T < world) never encodes, yet it pushes its peers' entries: the stage must
+            # have its handle (FIFO) from the geometry alone, on every rank, before the first exchange.
+            if hasattr(self.stage, "ensure_engine") and self.device is not None and torch.device(self.device).type == "cuda":
+                self.stage.ensure_engine(self.frame_size[0], self.frame_size[1], self.device)
             self._buf = torch.zeros(self.world, nq + nk + nv, dtype=torch.float32, device=self.device)
         return self._buf
 

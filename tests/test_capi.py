@@ -26,6 +26,23 @@ def test_hip_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.tdnet_version()
 
 
+def test_library_is_stamped_with_the_hash_of_its_sources(tmp_path):
+    """tdnet_amd/build.py: the .so carries a hash of csrc/* + include/tdnet.h (compiled into tdnet_version()); build() rebuilds when the
+    stamp and the sources disagree instead of trusting mtimes, and the stamp is readable without loading the library."""
+    import __graft_entry__ as g
+    from tdnet_amd import build as b
+    g.build()
+    want = b.source_hash()
+    assert b.built_hash() == want
+    assert _capi.Lib(_capi.DEFAULT_LIB).tdnet_version().decode().endswith("tdnet-src-hash:" + want)
+    # a library built from other sources is recognised as stale (a copy with one stamp byte changed stands in for it)
+    blob = open(b.OUT, "rb").read()
+    i = blob.index(b.STAMP_MARK) + len(b.STAMP_MARK)
+    fake = tmp_path / "stale.so"
+    fake.write_bytes(blob[:i] + (b"0" if blob[i:i + 1] != b"0" else b"1") + blob[i + 1:])
+    assert b.built_hash(str(fake)) not in (None, want)
+
+
 def test_product_fails_loudly_without_library(tmp_path):
     with pytest.raises(_capi.TdnetError):
         _capi.Lib(str(tmp_path / "missing.so"))

@@ -261,6 +261,69 @@ def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
         e.close()
 
 
+def test_winograd_chunked_low_register_transforms(lib):
+    """td_wino.h k_wino4_in_c / k_wino4_out_c (tdnet_opts.overlap): the wave-per-(tile, channel slice) F(4x4) transforms with 1, 2 and 4
+    channels per lane, whole convs (bit 2) and as the two row-parity chunks of an even-dilation conv (bit 1, the chunks run one after the
+    other here): every dilation, images smaller than a tile, odd heights (the two parities have different row counts), channel counts
+    that are not a multiple of the 64-lane slice, residual / activation variants."""
+    shapes = [(13, 21, 64, 128, 3, 1, 2, 1, True), (12, 30, 64, 160, 3, 1, 4, 1, False), (9, 17, 128, 256, 3, 1, 8, 0, True),
+              (5, 9, 256, 512, 3, 1, 16, 2, False), (40, 40, 32, 128, 3, 1, 1, 1, False), (1, 1, 32, 32, 3, 1, 1, 0, False),
+              (7, 7, 32, 64, 3, 1, 3, 1, True), (16, 32, 64, 64, 3, 1, 1, 2, True), (3, 5, 96, 36, 3, 1, 2, 1, True)]
+    for vw in (0, 1, 2):
+        for a in shapes:
+            opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 2 | (vw << 4)})       # whole conv on the new kernels
+            opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1 | (vw << 4)})       # even dilation: two chunks
+    opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 1, "gemm_persistent": 3, "fusion": 64})
+
+
+@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 1}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
+                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td4", "resnet18", {"overlap": 1, "winograd": 4})])
+def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
+    """tdnet_opts.overlap bit 1: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows)
+    against the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd."""
+    H, W = 33, 65
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=opts)
+    assert e.opts()["overlap"] == opts["overlap"]
+    e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 1, seed=1)):
+        out = np.full((1, 19, H, W), 7e7, np.float32)
+        e.forward(x, t % spec.path_num, out)
+        if "f%d_c4" % t in g.files:
+            assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 1e-4 * np.abs(g["f%d_c4" % t]).max()
+        assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
+        assert (out[0].argmax(0) == g["f%d_logits" % t][0].argmax(0)).all()
+    e.close()
+
+
+def test_activation_propagates_non_finite_values_like_the_reference(lib):
+    """td_conv.h td_activate (shared by the conv / GEMM epilogues and the Winograd output transforms): a NaN in the input reaches the
+    output as NaN under every activation (F.relu / F.leaky_relu do the same; a max/min formulation would turn it into 0), ReLU(-inf)
+    is 0, LeakyReLU(-inf) and no-activation(-inf) stay -inf.  Direct conv, persistent 1x1 GEMM and F(4x4) Winograd."""
+    import ctypes
+    H, W, Cin, Cout = 6, 10, 64, 128
+    g = np.random.default_rng(3)
+    x = g.standard_normal((H, W, Cin)).astype(np.float32)
+    x[2, 3, 5] = np.nan
+    for KS, o in ((1, {}), (3, {"winograd": 0}), (3, {"winograd": 4, "overlap": 2})):
+        w = (g.standard_normal((Cout, Cin, KS, KS)) / np.sqrt(Cin * KS * KS)).astype(np.float32)
+        b = g.standard_normal(Cout).astype(np.float32)
+        b[7] = -np.inf
+        for act in (0, 1, 2):
+            out = MEM.empty((H, W, Cout))
+            lib.check(lib.tdnet_op_conv2d(MEM.ptr(MEM.put(x)), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, KS, 1, 1, None, act,
+                                          ctypes.byref(lib.opts(**o)), -1, MEM.ptr(out), None))
+            reach = KS // 2 if not o.get("winograd") else 5                     # a Winograd tile spreads the NaN over its 4x4 outputs
+            assert np.isnan(out[2, 3]).all(), (KS, o, act)
+            clean = np.ones((H, W), bool)
+            clean[max(0, 2 - reach):2 + reach + 1, max(0, 3 - reach):3 + reach + 1] = False
+            assert np.isfinite(np.delete(out[clean], 7, axis=1)).all(), (KS, o, act)
+            col = out[clean][:, 7]
+            assert (col == 0).all() if act == 1 else np.isneginf(col).all(), (KS, o, act, col[:4])
+
+
 def test_persistent_gemm_multi_tile(lib):
     """td_gemm.h: stride-1 1x1 convs and Winograd GEMMs on the persistent kernel, with the grid forced small so every
     workgroup walks several tiles (pipeline running across tile boundaries, odd/even tile counts, idle workgroups)."""

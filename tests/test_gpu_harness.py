@@ -55,6 +55,14 @@ def test_reference_cli_end_to_end(tmp_path):
     assert mism <= 0.002 * T * oh * ow, mism          # only numerical-tie pixels may differ
 
 
+def test_loaded_library_was_built_from_the_shipped_sources():
+    """The .so travels prebuilt to the GPU box: its stamp (tdnet_version()) must equal the hash of the csrc/ + include/tdnet.h that
+    travelled with it, or this run would be testing some other build's kernels."""
+    from tdnet_amd import _capi, build as b
+    ver = _capi.lib().tdnet_version().decode()
+    assert ver.endswith("tdnet-src-hash:" + b.source_hash()), (ver, b.source_hash())
+
+
 def test_bench_two_ranks_sharing_the_gpu():
     """The N-rank code path of bench.py with the real kernels: `--gpus 2 --share-gpu` launches two ranks itself, both on cuda:0, the
     219 MB weight blob crosses the process boundary (gloo), each rank builds its model from the broadcast copy and serves its own

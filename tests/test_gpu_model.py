@@ -179,8 +179,11 @@ def test_uncalibrated_reference_init(wino):
     meaningful (the reference's own fp32 CPU evaluation is 1.7e-3 away from an fp64 evaluation of the same graph at this size), so
     the gate is RELATIVE to what fp32 itself can deliver: against an fp64 evaluation of the oracle graph ("truth"),
         max|gpu - truth| <= 4 x max|fp32 CPU oracle - truth|   and   rms(gpu - truth) <= 3 x rms(fp32 CPU oracle - truth),
-    and a label may differ from the truth's only inside the truth's top-2 tie band.  All three conv algorithms (direct, Winograd
-    F(2x2), F(4x4)) must pass: Winograd's extra rounding error is a constant factor (measured on the CPU model of the kernels,
+    and a label may differ from the truth's only inside the truth's top-2 tie band -- asserted exactly as written here (round 2
+    asserted a looser 1e-3 max|truth| / 5x rms, which the direct kernel needed: its one sequential fp32 chain over K = 4608 was 6.8x /
+    3.5x the CPU's error; the kernel now sums blocks of 512 products, td_conv.h FLUSH).  max|gpu - cpu| is printed as well: it is
+    what "within X of the CPU path" means for logits of this magnitude.  All three conv algorithms (direct, Winograd F(2x2), F(4x4))
+    must pass: Winograd's extra rounding error is a constant factor (measured on the CPU model of the kernels,
     tests/numerics_winograd.py reference-init: rms 1.0x / 2.3x, max 1.8x / 3.0x the direct path's), not something the calibrated
     weights were hiding."""
     H, W, T = 129, 257, 5
@@ -191,7 +194,7 @@ def test_uncalibrated_reference_init(wino):
     m = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None, kernel_opts={"winograd": wino}).eval().to("cuda")
     m.load_state_dict(sd)
     tdnet_ref.tune_threads()
-    e_gpu, e_cpu, s_gpu, s_cpu, n, tmax = 0.0, 0.0, 0.0, 0.0, 0, 0.0
+    e_gpu, e_cpu, s_gpu, s_cpu, n, tmax, e_gc = 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0
     with torch.no_grad():
         for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
             xt = torch.from_numpy(x)
@@ -199,6 +202,7 @@ def test_uncalibrated_reference_init(wino):
             truth = ref64.forward(xt.double(), t % 4).numpy()
             cpu = ref32.forward(xt, t % 4).double().numpy()
             dg, dc = out - truth, cpu - truth
+            e_gc = max(e_gc, float(np.abs(out - cpu).max()))
             tmax = max(tmax, float(np.abs(truth).max()))
             e_gpu, e_cpu = max(e_gpu, float(np.abs(dg).max())), max(e_cpu, float(np.abs(dc).max()))
             s_gpu, s_cpu, n = s_gpu + float((dg ** 2).sum()), s_cpu + float((dc ** 2).sum()), n + dg.size
@@ -207,9 +211,9 @@ def test_uncalibrated_reference_init(wino):
                 top2 = np.sort(truth[0], axis=0)[-2:]
                 assert ((top2[1] - top2[0])[bad] <= 2 * float(np.abs(dg).max())).all(), (wino, t, "label flip outside the tie band")
     r_gpu, r_cpu = (s_gpu / n) ** 0.5, (s_cpu / n) ** 0.5
-    print("reference init, winograd=%d: max|truth| %.1f; max err gpu %.2e (%.1e of max|truth|) vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f)"
-          % (wino, tmax, e_gpu, e_gpu / tmax, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu))
-    assert e_gpu <= 1e-3 * tmax and r_gpu <= 5.0 * r_cpu, (wino, tmax, e_gpu, e_cpu, r_gpu, r_cpu)
+    print("reference init, winograd=%d: max|truth| %.1f; max err gpu %.2e (%.1e of max|truth|) vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f); max|gpu - cpu| %.2e"
+          % (wino, tmax, e_gpu, e_gpu / tmax, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu, e_gc))
+    assert e_gpu <= 4.0 * e_cpu and r_gpu <= 3.0 * r_cpu, (wino, tmax, e_gpu, e_cpu, r_gpu, r_cpu)
 
 
 def test_two_models_with_different_kernel_options_in_one_process():

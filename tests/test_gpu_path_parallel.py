@@ -45,12 +45,13 @@ def _worker(rank, world, port, q, name, H, W, T):
     with torch.no_grad():
         outs = parallel.PathParallelStream(m, spec.path_num, device=dev, frame_size=(H, W)).process(frames)
     torch.cuda.synchronize()
+    assert m.engine is not None and m.engine.fifo_len() == min(T, spec.fifo), (rank, m.engine.fifo_len())   # every rank saw every entry
     q.put((rank, {t: o.cpu().numpy() for t, o in outs.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,T", [("td4", 9), ("td2", 5)])
+@pytest.mark.parametrize("name,T", [("td4", 9), ("td2", 5), ("td4", 1)])   # T = 1 < world: rank 1 owns no frame, never encodes, still pushes
 def test_two_ranks_one_stream_bit_identical(name, T):
     H, W = 129, 257
     ctx = mp.get_context("spawn")
