@@ -59,7 +59,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-direct-line", action="store_true", help="skip timing the all-direct-conv configuration beside the headline")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="steady-state frames timed on the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="steady-state frames timed on the CPU oracle (SURVEY 8d: >= 5)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short legs for BASELINE configs[1] (td2-psp18 1024x2048 fp32) and configs[4] (td2-psp34 720x960 fp16, the "
+                         "stand-in for the BiSeNet-34 the reference does not contain) that the default N = 1 run appends as `other_configs`")
+    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-pmc --no-direct-line --no-other-configs (A/B runs)")
+    ap.add_argument("--perturb-rank", type=int, default=-1,
+                    help="TEST ONLY: this rank scales one weight tensor by 1.001 after the broadcast; the N-rank line must then say "
+                         "ranks_agree false and the run must exit non-zero (tests/test_bench_launch.py)")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch")
     ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4 + head, 3 F(4x4,3x3) for layers 2-4 + head (default: library default)")
     ap.add_argument("--attention", type=int, default=None, help="0 exact two-pass softmax, 1 single pass (lazily moved reference), 2 the same with one barrier per key tile (library default)")
@@ -84,7 +91,10 @@ def parse_args(argv=None):
                          "broadcast into N model instances, barriers, reductions) can be exercised with the real kernels on a box with "
                          "ONE GPU; the line says shared_gpu and its value is null")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 for a counter pass
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.quick:
+        a.no_cpu_baseline = a.no_pmc = a.no_direct_line = a.no_other_configs = True
+    return a
 
 
 def free_port():
@@ -173,7 +183,128 @@ def measure_traffic(child_args, dom_regex, frames):
     return per_launch, total / frames, detail
 
 
+# ---- parity of a model against the CPU oracle on a bounded sample (the rule of tests/test_gpu_model.py::check_frame) ---------------
+def parity_sample(model, ref, clip, P, nw, nsteady, fp32, torch, np, tdnet_ref, keep_labels=None):
+    """Runs frames 0 .. nw + nsteady - 1 of `clip` through the GPU model (after reset) and the oracle.  Returns (parity dict, CPU
+    seconds spent on the nsteady steady-state frames, 19x19 confusion matrix GPU labels vs oracle labels)."""
+    import time as _t
+    model.reset()
+    cpu_t, worst, flips, outside, npx = 0.0, 0.0, 0, 0, 0
+    hist = np.zeros((19, 19), np.int64)
+    with torch.no_grad():
+        for t in range(nw + nsteady):
+            x = clip[t % len(clip)]
+            out = model(x, pos_id=t % P).cpu()
+            xc = x.cpu()
+            c0 = _t.perf_counter()
+            exp = ref.forward(xc, t % P)
+            c1 = _t.perf_counter()
+            if t >= nw:
+                cpu_t += c1 - c0
+            err = (out - exp).abs().max().item()
+            worst = max(worst, err)
+            lo, lr = out[0].argmax(0).numpy(), exp[0].argmax(0).numpy()
+            if keep_labels is not None:
+                keep_labels.append(lr.astype(np.uint8))
+            bad = lo != lr
+            flips += int(bad.sum()); npx += lo.size
+            if bad.any():
+                top2 = np.sort(exp[0].numpy(), axis=0)[-2:]
+                outside += int(((top2[1] - top2[0])[bad] > 2 * err).sum())
+            hist += tdnet_ref.confusion_miou(lo, lr, 19)[1]
+    iu = np.diag(hist) / np.maximum(1, hist.sum(1) + hist.sum(0) - np.diag(hist))
+    par = {"frames": nw + nsteady, "max_abs_dlogit": float("%.3e" % worst), "label_mismatches": flips,
+           "flips_outside_tie_band": outside, "pixels": npx, "miou_vs_cpu": round(float(iu[hist.sum(1) > 0].mean()), 6),
+           "labels_equal_frac": round(1.0 - flips / max(1, npx), 6),
+           "gate": "max|dlogit| <= 1e-3 and every label flip inside the reference's top-2 tie band (gap <= 2 max|dlogit|)"
+                   if fp32 else "reported, not gated (fp16 mode; tests/test_gpu_fp16.py gates it at 3e-2 / 99.5 % / mIoU 0.99)"}
+    if fp32 and (outside > 0 or worst > 1e-3):
+        par["FAILED"] = True
+    return par, cpu_t, hist
+
+
+def logits_digest(out, torch):
+    """Two 64-bit integers of a logits tensor's BIT pattern (plain sum and a position-weighted sum, int64 wrap-around): equal on two
+    ranks iff -- up to a 2^-64-ish accident -- the tensors are bit-identical."""
+    v = out.contiguous().view(torch.int32).flatten().to(torch.int64)
+    idx = (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 65521) + 1
+    return [int(v.sum().item()), int((v * idx).sum().item())]
+
+
+def profile_dominant(eng, step_one, nprof, sync, torch):
+    """Profiled replay (HIP events around every launch on the forward's own streams): per-family [ms, FLOP, launches] sums."""
+    eng.set_profiling(True)
+    acc = {k: [0.0, 0.0, 0.0] for k in (0, 1, 2, 3)}
+    sync()
+    with torch.no_grad():
+        for _ in range(nprof):
+            step_one()
+            sync()
+            for k in acc:
+                ms_, fl, n = eng.last(k)
+                acc[k][0] += ms_; acc[k][1] += fl; acc[k][2] += n
+    eng.set_profiling(False)
+    return acc
+
+
+def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite):
+    """One short leg for another BASELINE.json config on this GPU: frames/s over `steps` steady frames, the dominant kernel's roofline
+    fraction (profiled replay) and parity against the CPU oracle on `cpu_frames` steady frames.  Own model, own clip, own oracle."""
+    import numpy as np
+    import torch
+    from oracle import tdnet_ref                                          # checker only
+    from tdnet_amd import arch, weights
+    from tdnet_amd.model import td2_psp50, td4_psp18
+    H, W = size
+    spec = arch.model_spec(model_name, 19, backbone)
+    P = spec.path_num
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
+    cls = td4_psp18.td4_psp18 if model_name == "td4" else td2_psp50.td2_psp50
+    opts = {"precision": 1} if precision == "fp16" else {}
+    m = cls(nclass=19, path_num=P, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
+    m.load_state_dict(sd)
+    NF = 6
+    clip = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=200)]
+    st = {"t": 0}
+
+    def step():
+        t = st["t"]
+        m(clip[t % NF], pos_id=t % P)
+        st["t"] = t + 1
+    with torch.no_grad():
+        for _ in range(P + 2):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+    eng = m.engine
+    peak = PEAK_FP16_MFMA_TFLOPS if precision == "fp16" else PEAK_FP32_MFMA_TFLOPS
+    acc = profile_dominant(eng, step, 2 * P, sync, torch)
+    dom_ms, dom_fl, dom_n = acc[3]
+    leg = {"config": tag, "workload": "%s-psp%s, %dx%d, %s" % (model_name, backbone[6:], H, W, precision), "reference": cite,
+           "value": round(steps / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+           "dtype": "f32" if precision == "fp32" else "f16 (fp16 MFMA, fp32 accumulate)", "kernel_opts": eng.opts(),
+           "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1)}
+    if dom_n > 0 and dom_ms > 0:
+        ach = dom_fl / (dom_ms * 1e-3) / 1e12
+        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_igemm_h<128,128,2,2,3,IN16,OUT16> (3x3 convs, fp16 MFMA)" if precision == "fp16"
+                           else "k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
+                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / (2 * P)}
+    if cpu_frames > 0:
+        ref = tdnet_ref.TDNetRef(spec, sd)
+        par, cpu_t, _ = parity_sample(m, ref, clip, P, P, cpu_frames, precision == "fp32", torch, np, tdnet_ref)
+        leg["parity"] = par
+        leg["cpu_baseline"] = {"value": round(cpu_frames / cpu_t, 4), "unit": "frames/s", "kind": "port", "sample": "%d steady-state frames" % cpu_frames}
+    del m
+    return leg
+
+
 def main():
+    t_proc0 = time.perf_counter()
     argv = sys.argv[1:]
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -226,6 +357,10 @@ def main():
     sync(); parallel.barrier()
     bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
     nparam = sum(int(np.asarray(v).size) for v in sd.values())
+    if args.perturb_rank == rank:                                                 # TEST ONLY: this rank now holds different weights
+        k0 = sorted(k for k in sd if k.endswith("conv1.weight"))[0]
+        sd = dict(sd)
+        sd[k0] = np.asarray(sd[k0], np.float32) * np.float32(1.001)
 
     def make_model(opts):
         from tdnet_amd.model import pspnet, td2_psp50, td4_psp18
@@ -288,6 +423,8 @@ def main():
     with torch.no_grad():
         for _ in range(nwarm):
             step()
+        sync()
+        init_s = time.perf_counter() - t_proc0                        # process start -> first steady frame done (import, weights, handle, warm-up)
         dt = timed(args.steps)
     if args.pmc_child:                                                # counter pass under rocprofv3: the steps above are all it needs
         return 0
@@ -295,6 +432,9 @@ def main():
     per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
     per_rank[rank] = C * args.steps / dt
     per_rank = parallel.allreduce_sum(per_rank).tolist()
+    init_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+    init_rank[rank] = init_s
+    init_rank = parallel.allreduce_sum(init_rank).tolist()
     fps = world * C * args.steps / tmax
 
     mname = ("psp%s" if args.model == "psp" else args.model + "-psp%s") % args.backbone[6:]
@@ -305,6 +445,7 @@ def main():
            "data": "synthetic",
            "world_size_seen": world_seen, "backend": backend, "rccl_bcast_ms": round(bcast_ms, 3),
            "bcast_bytes": 4 * nparam if world > 1 else 0, "per_rank_fps": [round(v, 3) for v in per_rank],
+           "init_s_per_rank": [round(v, 2) for v in init_rank],
            "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, %d clip%s per GPU"
                                   % (mname, H, W, spec.fifo, C, "" if C == 1 else "s (concurrent HIP streams)"),
                       "parallelism": ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else
@@ -321,6 +462,68 @@ def main():
         res["metric"] = "DRY RUN (launch plumbing only, no model): " + res["metric"]
 
     exit_code = 0
+    # ---- N > 1: the line must be able to FAIL.  Every rank replays RANK 0's clip for P + 2 frames and contributes a 64-bit digest of each
+    # frame's logits bits plus its label histogram; MIN and MAX all-reduces must coincide (every rank bit-identical to rank 0, whose
+    # output is held to the CPU oracle below), and the 19x19 confusion matrices (each rank's labels vs the oracle's) are
+    # summed over the ranks into the line.  --dry-run does the same over the broadcast weight bytes (there is no model on the CPU).
+    ref_labels = None
+    if world > 1 and pp is None:
+        nchk = P + 2
+        my_labels = []
+        if args.dry_run:
+            blob = np.concatenate([np.asarray(sd[k], np.float32).reshape(-1) for k in sorted(sd)])
+            vec = logits_digest(torch.from_numpy(blob), torch)
+        else:
+            clip0 = clip if rank == 0 else [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, nchk, seed=100)]
+            vec = []
+            model.reset()
+            with torch.no_grad():
+                for t in range(nchk):
+                    out = model(clip0[t % len(clip0)], pos_id=t % P)
+                    lab = out[0].argmax(0)
+                    my_labels.append(lab.to(torch.uint8))
+                    vec += logits_digest(out, torch) + torch.bincount(lab.flatten(), minlength=19)[:19].tolist()
+            model.reset()
+        v = torch.tensor(vec, dtype=torch.int64, device=dev)
+        vmin, vmax = v.clone(), v.clone()
+        dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        agree = bool(torch.equal(vmin, vmax))
+        res["rank_check"] = {"ranks_agree": agree, "frames": 0 if args.dry_run else nchk, "digest_words": len(vec),
+                             "what": ("digest of the broadcast weight bytes (dry run: no model)" if args.dry_run else
+                                      "every rank replays rank 0's clip: per frame two 64-bit digests of the logits bits + the label "
+                                      "histogram; all_reduce(MIN) == all_reduce(MAX)")}
+        if not agree:
+            res["rank_check"]["FAILED"] = True
+            res["rank_check"]["words_differing"] = int((vmin != vmax).sum().item())
+            exit_code = 4
+        if not args.dry_run and not args.no_cpu_baseline:
+            # rank 0 evaluates the oracle on those frames (bounded: P + 2 frames), everyone receives its labels, every rank's confusion
+            # matrix against them is summed: the end-of-run all-reduce of SURVEY 8e
+            lab_ref = torch.zeros((nchk, H, W), dtype=torch.uint8, device=dev)
+            if rank == 0:
+                from oracle import tdnet_ref                                      # checker only
+                tdnet_ref.tune_threads()
+                oracle = tdnet_ref.TDNetRef(spec, sd)
+                keep = []
+                par0, _, _ = parity_sample(model, oracle, clip, P, nchk, 0, args.precision == "fp32", torch, np, tdnet_ref, keep_labels=keep)
+                model.reset()
+                res["parity"] = par0
+                if par0.get("FAILED"):
+                    exit_code = 3
+                lab_ref.copy_(torch.from_numpy(np.stack(keep)))
+            dist.broadcast(lab_ref, src=0)
+            mine = torch.stack(my_labels).to(torch.int64)
+            cm = torch.bincount((19 * lab_ref.to(torch.int64) + mine).flatten(), minlength=361)[:361].reshape(19, 19)
+            cm = parallel.allreduce_sum(cm)
+            cmn = cm.cpu().numpy().astype(np.float64)
+            iu = np.diag(cmn) / np.maximum(1, cmn.sum(1) + cmn.sum(0) - np.diag(cmn))
+            res["rank_check"]["confusion_matrix_sum_over_ranks"] = cm.cpu().tolist()
+            res["rank_check"]["miou_vs_cpu_all_ranks"] = round(float(iu[cmn.sum(1) > 0].mean()), 6)
+            res["rank_check"]["pixels_all_ranks"] = int(cmn.sum())
+        code = torch.tensor([exit_code], dtype=torch.int64, device=dev)
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)                            # every rank leaves with the same verdict
+        exit_code = int(code.item())
     if rank == 0 and not args.dry_run:
         eng = model.engine
         opts = eng.opts()
@@ -328,18 +531,8 @@ def main():
         peak = PEAK_FP16_MFMA_TFLOPS if opts["precision"] else PEAK_FP32_MFMA_TFLOPS
         res["config"]["kernel_opts"] = opts
         # ---- roofline of the dominant kernel: profiled replay (HIP events around every launch, same stream) ----------
-        eng.set_profiling(True)
-        acc = {k: [0.0, 0.0, 0.0] for k in (0, 1, 2, 3)}
         nprof = 2 * P
-        sync()
-        with torch.no_grad():
-            for _ in range(nprof):
-                step(n_clips=1)                                       # the replay runs clip 0 alone: per-launch durations, no co-running streams
-                sync()
-                for k in acc:
-                    ms_, fl, n = eng.last(k)
-                    acc[k][0] += ms_; acc[k][1] += fl; acc[k][2] += n
-        eng.set_profiling(False)
+        acc = profile_dominant(eng, lambda: step(n_clips=1), nprof, sync, torch)   # the replay runs clip 0 alone: per-launch durations
         dom_ms, dom_fl, dom_n = acc[3]
         dom_regex = None
         if dom_n > 0 and dom_ms > 0:
@@ -411,41 +604,29 @@ def main():
             from oracle import tdnet_ref                                          # checker / baseline only
             cores = tdnet_ref.tune_threads()          # threads actually used (fastest of 8..128 on a probe conv)
             ref = (tdnet_ref.PSPNetRef if args.model == "psp" else tdnet_ref.TDNetRef)(spec, sd)
-            model.reset()
             nw, nsteady = P, max(1, args.cpu_frames)
-            cpu_t, worst, flips, outside, npx = 0.0, 0.0, 0, 0, 0
-            hist = np.zeros((19, 19), np.int64)
-            with torch.no_grad():
-                for t in range(nw + nsteady):
-                    x = clip[t % NF]
-                    out = model(x, pos_id=t % P).cpu()
-                    xc = x.cpu()
-                    c0 = time.perf_counter()
-                    exp = ref.forward(xc, t % P)
-                    c1 = time.perf_counter()
-                    if t >= nw:
-                        cpu_t += c1 - c0
-                    err = (out - exp).abs().max().item()
-                    worst = max(worst, err)
-                    lo, lr = out[0].argmax(0).numpy(), exp[0].argmax(0).numpy()
-                    bad = lo != lr
-                    flips += int(bad.sum()); npx += lo.size
-                    if bad.any():                                                 # same rule as tests/test_gpu_model.py::check_frame
-                        top2 = np.sort(exp[0].numpy(), axis=0)[-2:]
-                        outside += int(((top2[1] - top2[0])[bad] > 2 * err).sum())
-                    hist += tdnet_ref.confusion_miou(lo, lr, 19)[1]
-            iu = np.diag(hist) / np.maximum(1, hist.sum(1) + hist.sum(0) - np.diag(hist))
+            par, cpu_t, _ = parity_sample(model, ref, clip, P, nw, nsteady, args.precision == "fp32", torch, np, tdnet_ref)
             res["cpu_baseline"] = {"value": round(nsteady / cpu_t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d steady-state frames of the same clip (after %d warm-up frames), oracle/tdnet_ref.py "
                                              "= the reference's op graph on torch-CPU %s with %d threads (host has %d)"
                                              % (nsteady, nw, torch.__version__, cores, os.cpu_count() or 1)}
-            res["parity"] = {"frames": nw + nsteady, "max_abs_dlogit": float("%.3e" % worst), "label_mismatches": flips,
-                             "flips_outside_tie_band": outside, "pixels": npx, "miou_vs_cpu": round(float(iu[hist.sum(1) > 0].mean()), 6),
-                             "gate": "max|dlogit| <= 1e-3 and every label flip inside the reference's top-2 tie band (gap <= 2 max|dlogit|)"
-                                     if args.precision == "fp32" else "reported, not gated (fp16 mode)"}
-            if args.precision == "fp32" and (outside > 0 or worst > 1e-3):
+            res["parity"] = par
+            if par.get("FAILED"):
                 exit_code = 3
-                res["parity"]["FAILED"] = True
+            del ref
+
+        # ---- the other single-GPU configs of BASELINE.json on the same line (default N = 1 run only) --------------------------
+        default_workload = args.model == "td4" and args.backbone == "resnet18" and (H, W) == (1024, 2048) and args.precision == "fp32" and C == 1
+        if world == 1 and pp is None and default_workload and not args.no_other_configs:
+            ncpu = 0 if args.no_cpu_baseline else 2
+            res["other_configs"] = [
+                other_config_leg("configs[1]", "td2", "resnet18", (1024, 2048), "fp32", 24, ncpu, dev, sync,
+                                 "td2_psp50(backbone='resnet18', path_num=2), Testing/model/pspnet/td2_psp50.py:52-58"),
+                other_config_leg("configs[4]", "td2", "resnet34", (720, 960), "fp16", 24, ncpu, dev, sync,
+                                 "td2-bise34 does not exist in the reference (SURVEY 0): td2_psp50(backbone='resnet34') is its stand-in; "
+                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path")]
+            if any(l.get("parity", {}).get("FAILED") for l in res["other_configs"]):
+                exit_code = 3
     if rank == 0:
         print(json.dumps(res), flush=True)
     parallel.barrier()

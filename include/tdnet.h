@@ -64,7 +64,13 @@ typedef struct tdnet_opts {
                                 32 = Cout <= 64 convs (layer1, the stems) read their A operand straight from global memory in MFMA
                                      fragment layout instead of staging it through LDS (td_conv_ad.h),
                                 64 = the 36 planes of the Winograd workspaces V / M padded by 24 rows each (an unpadded plane is a
-                                     power of two bytes: 36 concurrent streams on the same HBM channels)                         */
+                                     power of two bytes: 36 concurrent streams on the same HBM channels),
+                                128 = precision 1 only: keep the convs that read fp16 maps on the register-staged kernel (td_conv_h.h)
+                                     instead of the LDS-DMA kernel (td_conv_hd.h) -- A/B of the round-3 kernel,
+                                256 = the 4-pixel vectorised layout change of bit 16 alone (without its 2-output max-pool),
+                                512 = the cached-frame attention steps of td4's propagation chain as ONE 512-channel launch (default: two
+                                     256-channel slices per launch, twice the workgroups),
+                                1024 = precision 1 only: no 256 x 256 tiles in the LDS-DMA conv kernel (A/B)                           */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
                                 1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -79,6 +79,13 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int qw = wave / CW, cw = wave % CW;
     const int q0 = (blockIdx.x * QW + qw) * 32;                  // first query of this wave's tile
+    if (gridDim.y > 1) {                                         // channel slices of DV in one launch: slice blockIdx.y of a p.ldv-wide value matrix
+        const int c0 = blockIdx.y * DV;
+        p.vp += c0; p.out += c0;
+        if (p.bias) p.bias += c0;
+        if (p.resid) p.resid += c0;
+        if (p.ln_part) p.ln_part += c0;
+    }
 
     // ---- this lane's query row, pre-scaled so that exp(s/8 - max) = exp2(S - M) -------------------------------
     // Out-of-range rows/keys are CLAMPED to the last valid one instead of branched around: the loads stay
@@ -458,8 +465,18 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
 // query tiles (= LayerNorm strips) of a launch
 static inline int attn_strips(int Lq, int DV) { return DV % 512 == 0 ? (Lq + 31) / 32 : 2 * ((Lq + 63) / 64); }
 
-static inline int attn_launch(AttnArgs a, int DV, int online, hipStream_t s) {
+// `slices` (DV = 512 only): the launch is split into two 256-channel slices (grid.y = 2, <1,4,2>: a lane owns 2 channels) -- for the
+// cached-frame steps of the propagation chain (Lq = Lk = 2048 at 1024x2048: 64 query tiles are 64 workgroups on 256 CUs; with two
+// slices 128, each with half the P V' work; the 64-wide Q K^T is computed by both).
+static inline int attn_launch(AttnArgs a, int DV, int online, hipStream_t s, bool slices = false) {
     a.ldv = DV;
+    if (DV == 512 && slices && !a.ln_part) {
+        const dim3 grid((a.Lq + 31) / 32, 2);
+        if (online == 2) TD_LAUNCH((k_attention<1, 4, 2, 2>), grid, dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+        else if (online) TD_LAUNCH((k_attention<1, 4, 2, 1>), grid, dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+        else TD_LAUNCH((k_attention<1, 4, 2, 0>), grid, dim3(256), (AttnLds<1, 4>::BYTES), s, a);
+        return 0;
+    }
     if (DV >= 512 && DV % 512 == 0) {
         const int grid = (a.Lq + 31) / 32;
         a.ln_nstr = grid;

@@ -57,6 +57,20 @@ TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voff_bytes, soff_bytes, 0));
 }
 
+// LDS-DMA: 16 bytes per lane from the buffer straight into LDS at lds_wave_base + 16 * lane (the destination is wave-uniform base +
+// lane-linear offset by construction of the instruction; only the SOURCE offset is per lane).  An out-of-range source offset
+// writes zeros.  Completion is tracked by vmcnt like any load; nothing orders it against ds_read but the issuing wave's own wait.
+TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
+}
+// wait until at most n of this wave's vector-memory operations (LDS-DMA pieces included) are outstanding; n is a compile-time constant
+#define TD_WAIT_VM_PIECES(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// the bare workgroup barrier: no vmcnt drain (a __syncthreads() would wait for every LDS-DMA in flight).  The wave's own LDS reads are
+// waited for first (lgkmcnt(0)) and nothing is scheduled across it: a buffer read before the barrier may be overwritten by another
+// wave's DMA right after it.
+#define TD_BARRIER_RAW() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
+                              __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
+
 // s_sleep: park the wave for ~64*n cycles (n <= 127); used to de-phase co-resident workgroups
 #define TD_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 

@@ -10,6 +10,7 @@
 #include "td_device.h"
 #include "td_conv.h"
 #include "td_conv_h.h"
+#include "td_conv_hd.h"
 #include "td_conv_ad.h"
 #include "td_wino.h"
 #include "td_gemm.h"
@@ -122,6 +123,8 @@ struct ConvLayer {
     int wino_pad = 0;                                                  // padding rows per Winograd plane (fusion bit 64)
     bool adirect = false;                                              // Cout <= 64: A operand straight from global (td_conv_ad.h, fusion bit 32)
     bool in16 = false, out16 = false;                                  // h16 only: the input (+ residual) / output map is stored as fp16 in HBM
+    int rh = 0;                                                        // h16 + in16: != 0 -> the LDS-DMA kernel with 64 rh rows per tile (td_conv_hd.h); M_out: its output pixels
+    long M_out = 0;
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
@@ -171,6 +174,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
                            int stride, int dil, int act, bool stem, long M, const tdnet_opts& o, int forced_tile = -1, int chunks = 1) {
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
+    L.M_out = M;
     L.pers = o.gemm_persistent; L.stagger = o.stagger;
     const bool deep = o.pipeline != 0;
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
@@ -761,6 +765,13 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
                 else B.c2.out16 = !last;
                 if (B.has_ds) B.ds.in16 = B.ds.out16 = true;
             }
+            // fp16 maps in, Cout >= 128: the LDS-DMA kernel (td_conv_hd.h), unless fusion bit 128 keeps the register-staged one
+            auto dma = [&](ConvLayer& c) {
+                if (c.h16 && c.in16 && !c.stem && !(n->opts.fusion & 128) && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile))
+                    c.rh = conv_dma_pick_rh(c.M_out, c.Cout, c.CoutPad % 256 == 0 && !(n->opts.fusion & 1024));
+            };
+            if (n->deep) dma(L.stem3);
+            for (auto& B : L.blocks) { dma(B.c1); dma(B.c2); if (B.bott) dma(B.c3); if (B.has_ds) dma(B.ds); }
         }
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
@@ -896,8 +907,9 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
-    prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
+    prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || L.rh) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
+    else if (L.h16 && L.rh) conv_launch_dma(a, L.rh, L.KS, L.out16, s);
     else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
@@ -915,14 +927,14 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
                          int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,
-                         _Float16* vt16 = nullptr) {
+                         _Float16* vt16 = nullptr, bool slices = false) {
     if (n && n->vt16) vt16 = n->vt16;
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
     a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
     a.ln_part = ln_part; a.ln_nstr = 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
+    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);
     return 0;
@@ -964,7 +976,7 @@ static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int 
 
 static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, hipStream_t s, int fusion) {
     prof_begin(n, 2, false, 0, s);
-    if ((fusion & 16) && (H * W) % 4 == 0 && ((size_t)img & 15) == 0)
+    if ((fusion & (16 | 256)) && (H * W) % 4 == 0 && ((size_t)img & 15) == 0)
         TD_LAUNCH(k_nchw3_to_nhwc4_x4, dim3(td_grid_for((long)H * W / 4)), dim3(256), 0, s, img, img4, H * W);
     else
     TD_LAUNCH(k_nchw3_to_nhwc4, dim3(td_grid_for((long)H * W)), dim3(256), 0, s, img, img4, H * W);
@@ -1030,9 +1042,11 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
     if (n->P == 4) {
         const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
         TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention)) return -1;   // v2 + V[1]
+        // the cached-frame steps have Lq = Lk (64 query tiles at 1024x2048): two channel slices per launch unless fusion bit 512 says no
+        const bool sl = !(n->opts.fusion & 512) && DV == 512 && n->Lk <= 8192;
+        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention, nullptr, nullptr, sl)) return -1;   // v2 + V[1]
         TD_TRY(run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention)) return -1;   // v3 + V[2]
+        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention, nullptr, nullptr, sl)) return -1;   // v3 + V[2]
         TD_TRY(run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c));                                              // (v3 + V[2]) W^T
     } else {
         TD_TRY(run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c));
@@ -1485,7 +1499,10 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
                                      int KS, int stride, int dil, const float* resid, int act, int tile, float* out, void* stream) {
     if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_f16io: KS must be 1 or 3");
     if (Cin % 64) return td_fail("tdnet_op_conv2d_f16io: Cin must be a multiple of 64");
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d", CT_COUNT);
+    // tile 16 / 17 / 18 / 19: the LDS-DMA kernel with 128 / 192 / 256-row tiles (td_conv_hd.h); -1: the heuristic (DMA kernel where it applies)
+    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : 0;           // 19: the 256 x 256 tile (Cout % 256 == 0)
+    if (force_rh) tile = CT_128x128_DEEP;
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..18", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;
@@ -1496,6 +1513,10 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     const int Ho = out_size(H, KS, stride, dil, pad), Wo = out_size(W, KS, stride, dil, pad);
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
     L.in16 = L.out16 = true;
+    if (force_rh == 8 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
+    if (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile)) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: this shape cannot run on the LDS-DMA kernel"); }
+    if (force_rh) L.rh = force_rh;
+    else if (tile < 0 && conv_dma_supports(Cin, Cout, KS, L.tile)) L.rh = conv_dma_pick_rh((long)Ho * Wo, Cout, L.CoutPad % 256 == 0);
     _Float16 *hin = nullptr, *hres = nullptr, *hout = nullptr;
     const long nin = (long)H * W * Cin, nout = (long)Ho * Wo * Cout;
     if (dev_alloc(&hin, (size_t)nin) || dev_alloc(&hout, (size_t)nout) || (resid && dev_alloc(&hres, (size_t)nout))) return -1;
@@ -1536,7 +1557,8 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     if (Lk < 1 || Lq < 1) return td_fail("tdnet_op_attention: empty input");
     hipStream_t s = (hipStream_t)stream;
     const bool padded = (online & 32) != 0;                            // online | 32: the caller's vp already has the padding rows (probes that time the kernel)
-    online &= ~32;
+    const bool slices = (online & 64) != 0;                            // online | 64: DV = 512 as two 256-channel slices in one launch (the chain's cached-frame steps)
+    online &= ~(32 | 64);
     float *part = nullptr, *mean = nullptr, *rstd = nullptr;
     if (ln_out) {                                                      // + plane LayerNorm of the result from the epilogue's strip statistics
         if (!ln_g || !ln_b) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
@@ -1553,7 +1575,7 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
         TD_HIP(hipMemcpyAsync(vpad, vp, (size_t)Lk * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
         vp = vpad;
     }
-    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt)) return -1;
+    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt, slices)) return -1;
     if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
     TD_HIP(hipStreamSynchronize(s));
     TD_HIP(hipGetLastError());

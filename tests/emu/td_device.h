@@ -12,6 +12,7 @@
 //   result = fma(a_k1, b_k1, fma(a_k0, b_k0, c))   (cdna_hip_programming.md §3).
 #ifndef TD_DEVICE_H   // same guard as the real header: the emu build force-includes this file first
 #define TD_DEVICE_H
+#define TD_EMU 1
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -148,6 +149,14 @@ TD_DEV float td_buf_ld1(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     }
     return v;
 }
+
+// LDS-DMA stand-in: synchronous copy (zeros for an out-of-range source) to lds_wave_base + 16 * lane
+TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
+    f32x4 v = td_buf_ld4(b, voff_bytes, soff_bytes);
+    memcpy(lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
+}
+#define TD_WAIT_VM_PIECES(n) ((void)0)
+#define TD_BARRIER_RAW() tdemu::syncthreads()
 
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }
 TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return tdemu::mfma32_f16(a, b, c); }

@@ -37,6 +37,20 @@ def test_self_spawn_two_ranks_over_gloo():
     assert line["rccl_bcast_ms"] > 0 and line["bcast_bytes"] > 1e6      # the weight blob really crossed the process boundary
     assert line["steps"] == 2 and line["scaling"] == "weak"
     assert sum(1 for l in out.splitlines() if l.startswith("{")) == 1    # ONE line, from rank 0
+    # the N-rank line verifies itself: every rank contributed a digest (dry run: of the broadcast weight bytes), MIN == MAX
+    assert line["rank_check"]["ranks_agree"] is True and "FAILED" not in line["rank_check"]
+    assert len(line["init_s_per_rank"]) == 2 and all(v > 0 for v in line["init_s_per_rank"])
+
+
+def test_a_rank_with_different_weights_fails_the_run():
+    """--perturb-rank (TEST ONLY) makes rank 1 hold a slightly different weight tensor after the broadcast: the line must carry
+    ranks_agree false and EVERY rank must exit non-zero -- an 8-GPU scaling run cannot pass with one rank computing something else."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--perturb-rank", "1"],
+                       env=_env(), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode != 0, out[-2000:]
+    line = _last_json(out)
+    assert line["rank_check"]["ranks_agree"] is False and line["rank_check"]["FAILED"] is True
 
 
 def test_launcher_form_and_world_size_mismatch():

@@ -77,6 +77,15 @@ def test_attention(lib):
     opcheck.attention(lib, MEM, 64, 64, 128, False, True)
 
 
+def test_attention_channel_slices(lib):
+    """td_attn.h: DV = 512 as two 256-channel slices in one launch (grid.y = 2, k_attention<1,4,2,*>: the cached-frame steps of td4's
+    propagation chain) for the three softmax schedules, ragged query / key tiles, bias and residual through the sliced pointers."""
+    for online in (0, 1, 2):
+        opcheck.attention(lib, MEM, 45, 6, 512, online=online | 64)
+        opcheck.attention(lib, MEM, 153, 200, 512, True, True, spike=True, online=online | 64)
+        opcheck.attention(lib, MEM, 64, 128, 512, False, False, online=online | 64)
+
+
 def test_attention_online_softmax_and_layernorm_statistics(lib):
     """tdnet_opts.attention = 1 (single pass, lazily moved reference) and fusion bit 2 (plane-LayerNorm strip statistics written by
     the epilogue): same gate as the two-pass kernel, on ragged shapes, with a dominating key, and with scores that keep growing
@@ -208,6 +217,23 @@ def test_fp16_storage_conv_attention_and_pipeline(lib, golden_dir):
         assert (out[0].argmax(0) == ref[0].argmax(0)).mean() >= 0.995
         assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 3e-2 * np.abs(g["f%d_c4" % t]).max()
     e.close()
+
+
+def test_fp16_conv_on_lds_dma(lib):
+    """td_conv_hd.h k_conv_dma_h: the fp16-map convs fed by LDS-DMA -- 256 / 192 / 128-row tiles (tile codes 18 / 17 / 16; 3- and
+    2-buffer rings), the XOR-swizzled activation image and the piece -> wave assignment (RH = 3 repeats two pieces), 3x3 with dilation /
+    stride / padding taps on every side, 1x1 with stride, ragged M (rows past the map read zeros) and Cout not a multiple of 128,
+    1 .. 27 K steps, residual and activations; then the heuristic's own choice."""
+    opcheck.conv_f16io(lib, MEM, 13, 21, 128, 256, 3, 1, 1, 1, True, 19)             # the 256 x 256 tile: a wave multiplies two 64-slot weight groups
+    opcheck.conv_f16io(lib, MEM, 20, 23, 64, 512, 3, 1, 2, 2, True, 19)              # two M tiles (ragged), two N tiles
+    opcheck.conv_f16io(lib, MEM, 9, 11, 192, 256, 1, 2, 1, 0, False, 19)
+    for tile in (18, 17, 16, None):
+        opcheck.conv_f16io(lib, MEM, 13, 21, 128, 160, 3, 1, 1, 1, True, tile)       # ragged M and N, two N tiles
+        opcheck.conv_f16io(lib, MEM, 7, 9, 64, 128, 1, 1, 1, 0, False, tile)         # a single K step
+        opcheck.conv_f16io(lib, MEM, 9, 11, 192, 130, 1, 2, 1, 2, True, tile)        # 1x1 stride 2, three steps, 130 channels
+        opcheck.conv_f16io(lib, MEM, 12, 17, 64, 128, 3, 2, 1, 1, False, tile)       # stride-2 3x3
+        opcheck.conv_f16io(lib, MEM, 10, 14, 128, 256, 3, 1, 4, 1, True, tile)       # dilation 4: most taps padded
+        opcheck.conv_f16io(lib, MEM, 20, 23, 64, 128, 3, 1, 2, 0, False, tile)       # 460 pixels: several M tiles, ragged last one
 
 
 def test_winograd_conv_and_pipeline(lib, golden_dir):

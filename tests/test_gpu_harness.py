@@ -77,3 +77,24 @@ def test_bench_two_ranks_sharing_the_gpu():
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["world_size_seen"] == 2 and line["shared_gpu"] is True and line["value"] is None
     assert len(line["per_rank_fps"]) == 2 and min(line["per_rank_fps"]) > 0 and line["bcast_bytes"] > 2e8
+    # the line verifies itself: both ranks replayed rank 0's clip and produced bit-identical logits; rank 0's are held to the oracle;
+    # the confusion matrices of both ranks against the oracle's labels were all-reduced into the line
+    rc = line["rank_check"]
+    assert rc["ranks_agree"] is True and rc["frames"] == 6 and rc["miou_vs_cpu_all_ranks"] >= 0.9995
+    assert rc["pixels_all_ranks"] == 2 * 6 * 257 * 513 and line["parity"]["flips_outside_tie_band"] == 0
+    assert len(line["init_s_per_rank"]) == 2
+
+
+def test_bench_two_ranks_one_perturbed_rank_fails():
+    """The same with rank 1's weights perturbed after the broadcast (--perturb-rank): real kernels, different logits -> the digests
+    disagree, the line says so and the run exits non-zero."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "4", "--warmup", "6",
+                        "--size", "129x257", "--perturb-rank", "1", "--no-cpu-baseline"], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode != 0, out[-3000:]
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["rank_check"]["ranks_agree"] is False and line["rank_check"]["FAILED"] is True
