@@ -41,7 +41,7 @@ typedef struct tdnet_cfg {
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
 #define TDNET_FUSION_DEFAULT 6
-#define TDNET_OVERLAP_DEFAULT 1
+#define TDNET_OVERLAP_DEFAULT 33   /* row-parity chains, 4 channels per lane: +2 % on MI355X (profiles/r03a_ab_overlap_*) */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
                                 convs (Cin >= 256, Cout >= 128), 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) =

@@ -33,6 +33,13 @@ struct ConvDmaGeom {
 // NB = 2: 256 output channels per tile (a wave multiplies 64 rows x 128 channels = two 64-slot groups of the packed weights): 64 KB
 // per K step for 256 MFMAs -- 31 bytes per clock and CU from L2 at the full MFMA rate, against 47 for the 256 x 128 tile and 62
 // for 128 x 128: with every CU streaming, the L2 -> CU fabric is what these kernels run into first.
+#ifdef TD_DMA_TRACE   // tools/conv_dma_trace.hip only: s_memtime stamps (shader cycles) of workgroups 0..3, every wave, the first 24 K steps:
+// [wg][wave][step][0..3] = after the DMA issue, after the MFMAs, after the vmcnt wait, after the barrier
+#define TD_DMA_STAMP(slot) do { if (blockIdx.x < 4 && step < 24 && lane == 0) \
+    TD_DMA_TRACE[(((size_t)blockIdx.x * 8 + wave) * 24 + step) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TD_DMA_STAMP(slot) ((void)0)
+#endif
 template <int RH, int KS, bool OUT16, int NBUF, int NB = 1>
 TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     using G = ConvDmaGeom<RH, NB>;
@@ -79,26 +86,38 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
         b_off[jb] = (unsigned)((pb / (2 * NB)) * p.CoutPad + n0 + (pb % (2 * NB)) * 64 + lane) * 16u;
     }
 
+    // ---- DMA issue, one piece at a time.  An LDS-DMA instruction costs the issuing wave 100-150 cycles (tools/conv_dma_trace.hip: the
+    // eight pieces of a step issued back to back right after the barrier took 700-1200 cycles, in both waves of every SIMD at once,
+    // with the matrix pipe idle -- a third of the step).  So the pieces of step s + NBUF - 1 are issued BETWEEN the MFMA groups of
+    // step s (NSLOT slots of four MFMAs), where the SIMD's other wave and the wave's own queued MFMAs cover them.
     int l_step = 0, l_chunk = 0, l_tap = 0;
-    auto issue = [&](int buf) {                                       // all NPW pieces of the next K step -> LDS buffer `buf`
-        char* base = smem + buf * G::BUF_BYTES;
+    unsigned i_delta = 0u, i_wsoff = 0u;                              // of the step being issued
+    auto issue_begin = [&]() {
         const int ky = l_tap / KS;
         const int dy = ky * p.dil, dx = (l_tap - ky * KS) * p.dil;
-        const unsigned delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * 2u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = ((a_taps[j] >> l_tap) & 1u) != 0u;
-            td_buf_ld16_lds(in_buf, base + (wave + NW * j) * 1024, ok ? a_off[j] + delta : TD_BUF_OOB, 0u);
-        }
-        const unsigned wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;
-#pragma unroll
-        for (int jb = 0; jb < NPW - 4; ++jb) {
-            int pb = wave + NW * jb;
+        i_delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * 2u;
+        i_wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;   // past the last step: a harmless surplus tile
+    };
+    auto issue_piece = [&](int buf, int pc) {                         // pc: compile-time piece number of this wave, 0..NPW-1
+        char* base = smem + buf * G::BUF_BYTES;
+        if (pc < 4) {
+            const bool ok = ((a_taps[pc] >> l_tap) & 1u) != 0u;
+            td_buf_ld16_lds(in_buf, base + (wave + NW * pc) * 1024, ok ? a_off[pc] + i_delta : TD_BUF_OOB, 0u);
+        } else {
+            int pb = wave + NW * (pc - 4);
             if (pb >= G::NPB) pb -= NW;
-            td_buf_ld16_lds(w_buf, base + G::A_BYTES + pb * 1024, b_off[jb], wsoff);
+            td_buf_ld16_lds(w_buf, base + G::A_BYTES + pb * 1024, b_off[pc - 4], i_wsoff);
         }
+    };
+    auto issue_end = [&]() {
         ++l_step;
         if (++l_tap == NTAPS) { l_tap = 0; ++l_chunk; }
+    };
+    auto issue_all = [&](int buf) {
+        issue_begin();
+#pragma unroll
+        for (int pc = 0; pc < NPW; ++pc) issue_piece(buf, pc);
+        issue_end();
     };
 
     // ---- MFMA fragment addresses (bytes inside a buffer) -----------------------------------------------------------------
@@ -120,9 +139,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // one K step on buffer `buf`, with the NPW pieces of the next issue spread over its 8 MFMA groups (ibuf < 0: nothing to issue)
+    // One piece per group of MFMAs (8 groups per step; 256-channel tiles: four MFMAs per group, two otherwise).  Measured with the
+    // in-kernel stamps (profiles/r03g_*): issue phase 700-1200 -> 200 cycles per step, 256 x 256 tile 150 -> 140 us per launch; packing
+    // the pieces into the first four groups instead changed nothing for that tile and cost the 128 x 128 one 3 %.
+    constexpr int NSLOT = 8;
+    auto compute = [&](int buf, int ibuf) {
         const char* base = smem + buf * G::BUF_BYTES;
         f16x8 af[2][2], bf[2][NJ];
+        issue_begin();
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(base + a_rd[i][0]);
 #pragma unroll
@@ -136,25 +161,35 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
                 for (int j = 0; j < NJ; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f16x8*>(base + b_rd + (g + 1) * 2 * BKQ + j * 512);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(af[g & 1][i], bf[g & 1][j], acc[i][j]);
+                TD_SCHED_FENCE();
+#pragma unroll
+                for (int pc = 0; pc < NPW; ++pc)
+                    if (pc % NSLOT == 2 * g + i) issue_piece(ibuf, pc);
+                TD_SCHED_FENCE();
+            }
         }
+        issue_end();
     };
 
-    // ---- ring: the DMA of step s + NBUF - 1 is issued before the MFMAs of step s; a counted wait leaves the newest step(s) in
-    // flight.  Order per step: issue, compute, wait for the NEXT step's pieces (this wave's), barrier (everyone's have landed, and
+    // ---- ring: the DMA of step s + NBUF - 1 is issued during the MFMAs of step s; a counted wait leaves the newest step(s) in
+    // flight.  Order per step: compute (+ issue), wait for the NEXT step's pieces (this wave's), barrier (everyone's have landed, and
     // everyone is done reading the buffer the next issue overwrites).
-    issue(0);
-    if (NBUF == 3) issue(1);
+    issue_all(0);
+    if (NBUF == 3) issue_all(1);
     if (NBUF == 3) TD_WAIT_VM_PIECES(NPW); else TD_WAIT_VM_PIECES(0);
     TD_BARRIER_RAW();
     int cb = 0, ib = NBUF - 1;                                        // buffer being multiplied / buffer being filled
     for (int step = 0; step < p.nsteps; ++step) {
-        issue(ib);                                                    // past the last step: a harmless surplus tile (clamped weights, zeros)
-        compute(cb);
+        TD_DMA_STAMP(0);
+        compute(cb, ib);
+        TD_DMA_STAMP(1);
         if (NBUF == 3) TD_WAIT_VM_PIECES(NPW); else TD_WAIT_VM_PIECES(0);
+        TD_DMA_STAMP(2);
         TD_BARRIER_RAW();
+        TD_DMA_STAMP(3);
         cb = cb + 1 == NBUF ? 0 : cb + 1;
         ib = ib + 1 == NBUF ? 0 : ib + 1;
     }
@@ -175,20 +210,22 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     }
 }
 
-// rows per tile / 64 for an output of M pixels x Cout channels: the launch ends when the busiest CU is done, one workgroup per CU
-// (RH = 4, 3) or two (RH = 2, two LDS buffers); relative tile efficiencies from the memory-path arithmetic in the header comment.
-// returns rh, or 8 for the 256 x 256 tile (CoutPad must be a multiple of 256 for it: the caller checks)
+// Tile for an output of M pixels x Cout channels.  Returns 4 / 3 / 2 (64 rh rows x 128 channels), 8 (256 x 256; needs CoutPad % 256 == 0:
+// the caller says so), or 0 = leave the conv on the register-staged kernel with its 64 x 128 tiles (many small workgroups).
+// Cost = what the busiest CU has to do: ceil(tiles / 256 CUs) tiles of rh x nb units, divided by the tile's relative throughput --
+// measured on MI355X at 1024x2048 (profiles/r03d_*): 256 x 256 1070 TFLOP/s, 256 x 128 950, the register-staged 128 x 128 930; the
+// smaller ones estimated from their bytes per MFMA.  At 720x960 (10800 pixels) this sends the 128-channel layers to the old 64 x 128
+// tiles (169 workgroups instead of 57), the 256-channel ones to 128 x 128 (170) and the 512-channel ones to 192 x 128 (228).
 static inline int conv_dma_pick_rh(long M, int Cout, bool allow256 = true) {
+    static const struct { int code, rows, nb; double eff; } cand[5] = {{4, 4, 1, 1.00}, {3, 3, 1, 0.95}, {2, 2, 1, 0.85}, {8, 4, 2, 1.13}, {0, 1, 1, 0.60}};
     int best = 4;
     double best_cost = 0.0;
-    static const struct { int rh, nb; double eff; int per_cu; } cand[4] = {{4, 1, 1.00, 1}, {3, 1, 0.94, 1}, {2, 1, 0.80, 2}, {4, 2, 1.25, 1}};
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (cand[i].nb == 2 && (!allow256 || Cout % 256)) continue;
         const long tn = (Cout + 128 * cand[i].nb - 1) / (128 * cand[i].nb);
-        const long tiles = ((M + 64 * cand[i].rh - 1) / (64 * cand[i].rh)) * tn, slots = 256L * cand[i].per_cu;
-        const long rounds = (tiles + slots - 1) / slots;
-        const double cost = (double)rounds * cand[i].per_cu * cand[i].rh * cand[i].nb / cand[i].eff;
-        if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].nb == 2 ? 8 : cand[i].rh; }
+        const long tiles = ((M + 64 * cand[i].rows - 1) / (64 * cand[i].rows)) * tn;
+        const double cost = (double)((tiles + 255) / 256) * cand[i].rows * cand[i].nb / cand[i].eff;
+        if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].code; }
     }
     return best;
 }

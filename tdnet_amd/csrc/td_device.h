@@ -17,6 +17,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define TD_KERNEL __global__
 #define TD_DEV __device__ __forceinline__
 #define TD_HOSTDEV __host__ __device__ __forceinline__
+#define TD_DEV_MEMBER static __device__ __forceinline__        // static member function of a device-side helper struct
 #define TD_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
 // all LDS is dynamic and 16-byte aligned (cdna_hip_programming.md Guideline 17)
 #define TD_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]

@@ -292,15 +292,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
 template <int VW> struct WinoVec;
 template <> struct WinoVec<1> {
     typedef float T;
-    static TD_DEV T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld1(b, v, s); }
-    static TD_DEV void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st1(b, v, s, x); }
-    static TD_DEV T act(T x, float slope) { return td_activate(x, slope); }
+    TD_DEV_MEMBER T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld1(b, v, s); }
+    TD_DEV_MEMBER void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st1(b, v, s, x); }
+    TD_DEV_MEMBER T act(T x, float slope) { return td_activate(x, slope); }
 };
 template <> struct WinoVec<2> {
     typedef f32x2 T;
-    static TD_DEV T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld2(b, v, s); }
-    static TD_DEV void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st2(b, v, s, x); }
-    static TD_DEV T act(T x, float slope) { x[0] = td_activate(x[0], slope); x[1] = td_activate(x[1], slope); return x; }
+    TD_DEV_MEMBER T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld2(b, v, s); }
+    TD_DEV_MEMBER void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st2(b, v, s, x); }
+    TD_DEV_MEMBER T act(T x, float slope) { x[0] = td_activate(x[0], slope); x[1] = td_activate(x[1], slope); return x; }
 };
 #ifndef TD_VW4_FIX
 #define TD_VW4_FIX 1
@@ -311,18 +311,18 @@ template <> struct WinoVec<4> {
     // of a 16-byte buffer access (tools/wino_vw_probe.py: with soffset, this kernel's results were wrong on MI355X in the odd dwords
     // of lanes 12-15 of every 16 -- non-deterministically, never in the emulator, never with 4- or 8-byte accesses); bit 2: a pause
     // between the arithmetic that produces a vector and the store that reads it.
-    static TD_DEV T ld(TdBuf b, unsigned v, unsigned s) {
+    TD_DEV_MEMBER T ld(TdBuf b, unsigned v, unsigned s) {
         if (TD_VW4_FIX & 1) return td_buf_ld4(b, v == TD_BUF_OOB ? v : v + s, 0u);
         return td_buf_ld4(b, v, s);
     }
-    static TD_DEV void st(TdBuf b, unsigned v, unsigned s, T x) {
+    TD_DEV_MEMBER void st(TdBuf b, unsigned v, unsigned s, T x) {
 #if (TD_VW4_FIX & 2) && !defined(TD_EMU)
         asm volatile("s_nop 7" : "+v"(x));
 #endif
         if (TD_VW4_FIX & 1) td_buf_st4(b, v == TD_BUF_OOB ? v : v + s, 0u, x);
         else td_buf_st4(b, v, s, x);
     }
-    static TD_DEV T act(T x, float slope) {
+    TD_DEV_MEMBER T act(T x, float slope) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = td_activate(x[e], slope);
         return x;

@@ -91,6 +91,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
 #define TD_KERNEL static
 #define TD_DEV static inline
 #define TD_HOSTDEV static inline
+#define TD_DEV_MEMBER static inline
 #define TD_LAUNCH_BOUNDS(t, w)
 #define TD_DYN_LDS(name) char* name = tdemu::g_lds
 #define TD_LAUNCH(kern, grid, block, lds, stream, ...) \

@@ -1,5 +1,11 @@
 """cityscapesLoader keeps the reference's contract (Testing/dataloader.py:44-88): sorted PNG glob, item =
-[img[1,3,H,W] fp32, name, folder, (W,H)], ImageNet normalisation in float64 -> float32, 19-colour palette."""
+[img[1,3,H,W] fp32, name, folder, (W,H)], ImageNet normalisation in float64 -> float32, 19-colour palette.
+
+PARITY UNPINNED for one function: `resize_linear_u8` restates cv2.resize's INTER_LINEAR (OpenCV's 11-bit fixed-point coefficients,
+half-pixel centres; Testing/dataloader.py:64) and is pinned here by hand-derived answers only -- neither this image nor the GPU box
+has cv2, so no cv2-generated fixture exists.  The day an image with cv2 is available: run cv2.resize on the arrays of
+test_resize_is_cv2_inter_linear_not_pil_bilinear below, commit input/output pairs under tests/golden/ with the generating script, and compare
+bit for bit.  The headline metric does not depend on it (synthetic tensors)."""
 import os
 
 import numpy as np

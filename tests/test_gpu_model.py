@@ -160,7 +160,14 @@ def test_full_size_digest_from_reference(golden_dir):
                 assert np.abs(out[0, :, ::61, ::67] - g["%s_f%d_sample" % (tag, t)]).max() <= 1e-3, (tag, t)
                 stats = np.array([out.min(), out.max(), out.mean(), np.sqrt((out.astype(np.float64) ** 2).sum())])
                 assert np.allclose(stats, g["%s_f%d_stats" % (tag, t)], rtol=1e-4, atol=1e-4), (tag, t)
-                assert (out[0].argmax(0)[::61, ::67] != g["%s_f%d_labels_sample" % (tag, t)]).mean() <= 0.002, (tag, t)
+                # labels: a sampled label may differ from the reference's only inside the reference's top-2 tie band at that pixel (the
+                # digest holds all 19 reference logits of every sampled pixel), and rarely
+                ref_s, got_s = g["%s_f%d_sample" % (tag, t)], out[0, :, ::61, ::67]
+                bad = got_s.argmax(0) != g["%s_f%d_labels_sample" % (tag, t)]
+                assert bad.mean() <= 0.002, (tag, t)
+                if bad.any():
+                    top2 = np.sort(ref_s, axis=0)[-2:]
+                    assert ((top2[1] - top2[0])[bad] <= 2 * max(float(np.abs(got_s - ref_s).max()), 1e-6)).all(), (tag, t, "sampled label flip outside the tie band")
                 checked += 1
         assert checked == T - spec.fifo, (tag, checked)
 
