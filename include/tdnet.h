@@ -143,7 +143,7 @@ double tdnet_last_flops(const tdnet_t* h, int which);
 double tdnet_last_launches(const tdnet_t* h, int which);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
- * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d_tile).                        */
+ * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d).                             */
 double tdnet_bench_mfma_peak(int waves_per_simd, int iters, void* stream);
 double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int stride, int dil, int tile /* -1: heuristic */, int iters,
                         const tdnet_opts* opts /* NULL = defaults */, void* stream);

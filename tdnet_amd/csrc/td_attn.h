@@ -62,6 +62,13 @@ struct AttnLds {
     static constexpr int BYTES = (2 * P_FLOATS + 3 * RED_FLOATS) * 4;   // P (double buffered), row-max / row-sum exchange, per-wave rescale factors
 };
 
+#ifdef TD_ATTN_TRACE   // tools/attn_trace.hip only: s_memtime stamps of workgroups 0..7, every wave, the first 12 key super-tiles (ONLINE = 2):
+// [wg][wave][st][0..4] = loop top, P written, next scores + maxima done, after the barrier, after the P V' MFMAs
+#define TD_ATTN_STAMP(slot) do { if (blockIdx.x < 8 && st < 12 && lane == 0) \
+    TD_ATTN_TRACE[(((size_t)blockIdx.x * 4 + wave) * 12 + st) * 5 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TD_ATTN_STAMP(slot) ((void)0)
+#endif
 template <int QW, int CW, int NT, int ONLINE>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
     static_assert(QW * CW == 4, "4 waves per block");
@@ -215,6 +222,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
         for (int st = 0; st < nsuper; ++st) {
             const int kbase = st * SK, kb = kbase + cw * 32;
             f32x4 bb[3][4];
+            TD_ATTN_STAMP(0);
             load_v(kbase, 0, bb[0]);
             load_v(kbase, 1, bb[1]);
             // A: maxima of tile st (published by the previous barrier) -> reference -> P of tile st
@@ -257,6 +265,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
                 const f32x4 v = {pr[4 * u], pr[4 * u + 1], pr[4 * u + 2], pr[4 * u + 3]};
                 td_st4(Pw + ((cw * 8 + 2 * u + half) * 32 + l31) * 4, v);
             }
+            TD_ATTN_STAMP(1);
             // B: scores of tile st+1 and their maxima, before the barrier
             if (st + 1 < nsuper) {
                 s = score_tile(kf);
@@ -264,7 +273,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
                 if (half == 0) redb[(st + 1) & 1][(qw * CW + cw) * 32 + l31] = lm;
                 if (st + 2 < nsuper) load_k(kb + 2 * SK, kf);     // in flight under the P V' MFMAs below
             }
+            TD_ATTN_STAMP(2);
             __syncthreads();
+            TD_ATTN_STAMP(3);
 #pragma unroll
             for (int G = 0; G < 4 * CW; ++G) {
                 if (G + 2 < 4 * CW) load_v(kbase, G + 2, bb[(G + 2) % 3]);
@@ -276,6 +287,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
                 if (G + 2 < 4 * CW) { TD_SCHED_GROUP(0x020, 4); TD_SCHED_GROUP(0x100, 1); }
                 TD_SCHED_GROUP(0x008, 4 * NT);
             }
+            TD_ATTN_STAMP(4);
         }
     } else {
     f32x4 kf[8];

@@ -1227,7 +1227,23 @@ static int frame_checks(tdnet* n, int pos_id, const char* who) {
     return 0;
 }
 
+// Error path of a frame: whatever the internal streams (cache-only attention chain, second row-parity chain) were given before the
+// failure is joined back into the caller's stream, so that a failed call leaves no work of this handle running unordered behind it.
+static void rejoin_streams(tdnet* n, hipStream_t s) {
+    for (hipStream_t c : {n->side, n->chain2}) {
+        if (!c) continue;
+        hipEvent_t& e = c == n->side ? n->ev_join : n->ev_cjoin;
+        if (e && hipEventRecord(e, c) == hipSuccess) (void)hipStreamWaitEvent(s, e, 0);
+    }
+}
+
+static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s);
 static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
+    const int rc = forward_lowres_impl(n, img, pos_id, s);
+    if (rc && n && n->finalized) rejoin_streams(n, s);
+    return rc;
+}
+static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s) {
     if (frame_checks(n, pos_id, "tdnet_forward")) return -1;
     if (n->pending_slot >= 0) return td_fail("tdnet_forward: a frame encoded with tdnet_encode is waiting for tdnet_propagate");
     PathLayers& L = n->paths[pos_id];
@@ -1282,7 +1298,7 @@ extern "C" int tdnet_encode(tdnet_t* n, const float* img, int pos_id, void* stre
     if (n->pending_slot >= 0) return td_fail("tdnet_encode: the previous encoded frame has not been propagated");
     n->nrec = 0;
     n->failed = false;
-    if (encode_frame(n, n->paths[pos_id], img, (hipStream_t)stream)) return -1;
+    if (encode_frame(n, n->paths[pos_id], img, (hipStream_t)stream)) { rejoin_streams(n, (hipStream_t)stream); return -1; }
     n->pending_pos = pos_id;
     TD_HIP(hipGetLastError());
     return 0;
@@ -1291,8 +1307,8 @@ static int propagate_lowres(tdnet* n, hipStream_t s) {
     if (n->pending_slot < 0) return td_fail("tdnet_propagate: no encoded frame (call tdnet_encode first)");
     PathLayers& L = n->paths[n->pending_pos];
     const bool steady = (int)n->fifo.size() >= n->FIFO;
-    if (steady && launch_chain(n, L, s)) return -1;
-    return finish_frame(n, L, steady, s);
+    if ((steady && launch_chain(n, L, s)) || finish_frame(n, L, steady, s)) { rejoin_streams(n, s); return -1; }
+    return 0;
 }
 extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
     if (!n || !logits) return td_fail("tdnet_propagate: null argument");
@@ -1487,9 +1503,8 @@ extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const flo
     const long M = (long)out_size(H, KS, stride, dil, pad) * out_size(W, KS, stride, dil, pad);
     // tdnet_opts.overlap bit 1: an even-dilation Winograd conv runs as its two row-parity chunks (here one after the other)
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M, o, tile < 0 ? -1 : tile, (o.overlap & 1) ? 2 : 1)) return -1;
-    const int rc = run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
-    TD_HIP(hipStreamSynchronize((hipStream_t)stream));
-    TD_HIP(hipGetLastError());
+    int rc = run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = td_fail("tdnet_op_conv2d: device error");
     free_conv_layer(L);
     return rc;
 }
@@ -1519,16 +1534,17 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     else if (tile < 0 && conv_dma_supports(Cin, Cout, KS, L.tile)) L.rh = conv_dma_pick_rh((long)Ho * Wo, Cout, L.CoutPad % 256 == 0);
     _Float16 *hin = nullptr, *hres = nullptr, *hout = nullptr;
     const long nin = (long)H * W * Cin, nout = (long)Ho * Wo * Cout;
-    if (dev_alloc(&hin, (size_t)nin) || dev_alloc(&hout, (size_t)nout) || (resid && dev_alloc(&hres, (size_t)nout))) return -1;
+    auto cleanup = [&]() {                                             // one release path, also for the error returns
+        for (_Float16* q : {hin, hout, hres}) if (q) hipFree(q);
+        free_conv_layer(L);
+    };
+    if (dev_alloc(&hin, (size_t)nin) || dev_alloc(&hout, (size_t)nout) || (resid && dev_alloc(&hres, (size_t)nout))) { cleanup(); return -1; }
     TD_LAUNCH(k_f2h, dim3(td_grid_for(nin)), dim3(256), 0, s, in, hin, nin);
     if (resid) TD_LAUNCH(k_f2h, dim3(td_grid_for(nout)), dim3(256), 0, s, resid, hres, nout);
-    const int rc = run_conv(nullptr, L, (const float*)hin, H, W, (const float*)hres, (float*)hout, s);
+    int rc = run_conv(nullptr, L, (const float*)hin, H, W, (const float*)hres, (float*)hout, s);
     TD_LAUNCH(k_h2f, dim3(td_grid_for(nout)), dim3(256), 0, s, (const _Float16*)hout, out, nout);
-    TD_HIP(hipStreamSynchronize(s));
-    TD_HIP(hipGetLastError());
-    hipFree(hin); hipFree(hout);
-    if (hres) hipFree(hres);
-    free_conv_layer(L);
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) rc = td_fail("tdnet_op_conv2d_f16io: device error");
+    cleanup();
     return rc;
 }
 extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host, const float* bias_host, const tdnet_opts* opts,
@@ -1559,30 +1575,30 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     const bool padded = (online & 32) != 0;                            // online | 32: the caller's vp already has the padding rows (probes that time the kernel)
     const bool slices = (online & 64) != 0;                            // online | 64: DV = 512 as two 256-channel slices in one launch (the chain's cached-frame steps)
     online &= ~(32 | 64);
-    float *part = nullptr, *mean = nullptr, *rstd = nullptr;
-    if (ln_out) {                                                      // + plane LayerNorm of the result from the epilogue's strip statistics
-        if (!ln_g || !ln_b) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
-        if (dev_alloc(&part, (size_t)2 * attn_strips(Lq, DV) * DV) || dev_alloc(&mean, DV) || dev_alloc(&rstd, DV)) return -1;
-    }
-    _Float16* vt = nullptr;                                            // online == 16: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
-    if (online == 16 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) return -1;
+    // arguments are validated BEFORE anything is allocated; every later exit goes through cleanup()
+    if (ln_out && (!ln_g || !ln_b)) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
     if (online != 16 && (online < 0 || online > 2)) return td_fail("tdnet_op_attention: online must be 0, 1, 2 or 16");
-    float* vpad = nullptr;                                             // the kernels' contract: V' padded to attn_vp_rows(Lk) zero rows
-    if (online != 16 && !padded && attn_vp_rows(Lk) != Lk) {
+    float *part = nullptr, *mean = nullptr, *rstd = nullptr, *vpad = nullptr;
+    _Float16* vt = nullptr;                                            // online == 16: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
+    auto cleanup = [&]() {
+        for (float* q2 : {part, mean, rstd, vpad}) if (q2) hipFree(q2);
+        if (vt) hipFree(vt);
+    };
+    int rc = 0;
+    if (ln_out && (dev_alloc(&part, (size_t)2 * attn_strips(Lq, DV) * DV) || dev_alloc(&mean, DV) || dev_alloc(&rstd, DV))) rc = -1;   // + plane LayerNorm of the result from the epilogue's strip statistics
+    if (!rc && online == 16 && dev_alloc(&vt, (size_t)DV * attn_lkpad(Lk))) rc = -1;
+    if (!rc && online != 16 && !padded && attn_vp_rows(Lk) != Lk) {    // the kernels' contract: V' padded to attn_vp_rows(Lk) zero rows
         const size_t rows = (size_t)attn_vp_rows(Lk);
-        if (dev_alloc(&vpad, rows * DV)) return -1;
-        TD_HIP(hipMemsetAsync(vpad, 0, rows * DV * sizeof(float), s));
-        TD_HIP(hipMemcpyAsync(vpad, vp, (size_t)Lk * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
-        vp = vpad;
+        if (dev_alloc(&vpad, rows * DV)) rc = -1;
+        else if (hipMemsetAsync(vpad, 0, rows * DV * sizeof(float), s) != hipSuccess ||
+                 hipMemcpyAsync(vpad, vp, (size_t)Lk * DV * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = td_fail("tdnet_op_attention: copy failed");
+        else vp = vpad;
     }
-    if (run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt, slices)) return -1;
-    if (ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
-    TD_HIP(hipStreamSynchronize(s));
-    TD_HIP(hipGetLastError());
-    if (vt) hipFree(vt);
-    if (vpad) hipFree(vpad);
-    if (part) { hipFree(part); hipFree(mean); hipFree(rstd); }
-    return 0;
+    if (!rc) rc = run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online == 16 ? 1 : online, part, vt, slices);
+    if (!rc && ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) rc = td_fail("tdnet_op_attention: device error");
+    cleanup();
+    return rc;
 }
 extern "C" int tdnet_op_layernorm_hw(const float* x, int HW, int C, const float* g, const float* b, float* out, void* stream) {
     if (C % 4 || (C / 4 <= 256 ? 256 % (C / 4) != 0 : C / 4 > 512)) return td_fail("tdnet_op_layernorm_hw: C must be one of 4*{1,2,4,...,256} or 2048");
