@@ -272,7 +272,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         m(clip[t % NF], pos_id=t % P)
         st["t"] = t + 1
     with torch.no_grad():
-        for _ in range(P + 2):
+        for _ in range(max(12, P + 2)):                                # the first frames of a new model also load its kernel variants
             step()
         sync()
         t0 = time.perf_counter()
@@ -555,6 +555,28 @@ def main():
                                "frac": round(achieved / peak, 4), "traffic": None,
                                "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nprof,
                                "gflop_per_launch": round(dom_fl / dom_n / 1e9, 2)}
+        # With the row-parity chains (tdnet_opts.overlap) two launches of the dominant kernel are in flight at a time, each progressing at
+        # about half speed: `frac` (per-launch durations, the figure rocprofv3's kernel stats reproduce) then understates the kernel.
+        # The same replay on a handle WITHOUT the chains gives the kernel's own rate, reported beside it.
+        if "roofline" in res and opts.get("overlap", 0) & 1 and opts["winograd"] >= 3 and not opts["precision"] and world == 1 and pp is None and not args.no_direct_line:
+            ms_ = make_model(dict(kopts, overlap=0))
+            st2 = {"t": 0}
+
+            def step_serial():
+                t = st2["t"]
+                ms_(clip[t % NF], pos_id=t % P)
+                st2["t"] = t + 1
+            with torch.no_grad():
+                for _ in range(P + 2):
+                    step_serial()
+            acc_s = profile_dominant(ms_.engine, step_serial, nprof, sync, torch)
+            if acc_s[3][2] > 0 and acc_s[3][0] > 0:
+                a_s = acc_s[3][1] / (acc_s[3][0] * 1e-3) / 1e12
+                res["roofline"]["serial_launches"] = {"achieved": round(a_s, 2), "frac": round(a_s / peak, 4),
+                                                      "avg_launch_ms": round(acc_s[3][0] / acc_s[3][2], 4), "launches_per_frame": acc_s[3][2] / nprof,
+                                                      "note": "the same kernel on a handle with kernel_opts overlap=0 (one launch at a time, whole convs): "
+                                                              "its own rate; in the default configuration two launches run concurrently and share the CUs"}
+            del ms_
         exec_gflop = (acc[0][1] + acc[1][1]) / nprof / 1e9           # conv/GEMM (executed: Winograd GEMM FLOP) + attention matmuls
         single_fps = C * args.steps / tmax                            # this GPU's frames/s
         res["frame"] = {"algorithmic_gflop": round(gflop, 1), "algorithmic_tflops": round(gflop * single_fps / 1e3, 2),
@@ -621,9 +643,9 @@ def main():
         if world == 1 and pp is None and default_workload and not args.no_other_configs:
             ncpu = 0 if args.no_cpu_baseline else 2
             res["other_configs"] = [
-                other_config_leg("configs[1]", "td2", "resnet18", (1024, 2048), "fp32", 24, ncpu, dev, sync,
+                other_config_leg("configs[1]", "td2", "resnet18", (1024, 2048), "fp32", 40, ncpu, dev, sync,
                                  "td2_psp50(backbone='resnet18', path_num=2), Testing/model/pspnet/td2_psp50.py:52-58"),
-                other_config_leg("configs[4]", "td2", "resnet34", (720, 960), "fp16", 24, ncpu, dev, sync,
+                other_config_leg("configs[4]", "td2", "resnet34", (720, 960), "fp16", 40, ncpu, dev, sync,
                                  "td2-bise34 does not exist in the reference (SURVEY 0): td2_psp50(backbone='resnet34') is its stand-in; "
                                  "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path")]
             if any(l.get("parity", {}).get("FAILED") for l in res["other_configs"]):

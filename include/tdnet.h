@@ -77,6 +77,8 @@ typedef struct tdnet_opts {
                                     chains -- on two HIP streams: the HBM-bound transforms of one chain run under the MFMA-bound GEMMs of
                                     the other (low-register transform kernels that fit beside three resident GEMM workgroups per CU),
                                 2 = the low-register transform kernels for every F(4x4) conv, chained or not,
+                                4 = with bit 1: the second chain starts half a conv late (when the first chain's first input transform is
+                                    done), so that one chain's transforms meet the other's GEMMs instead of its transforms,
                                 bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
     int32_t reserved[8];     /* must be 0                                                                                        */
 } tdnet_opts;

@@ -162,7 +162,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.stagger = d.stagger < 0 ? 0 : d.stagger > 64 ? 64 : d.stagger;
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
-    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0x33;
+    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0x37;
     if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
     return d;
 }
@@ -305,7 +305,7 @@ struct tdnet {
     // (downsample output) and seg_x[b] (block output).
     int seg_block = -1, seg_conv = 0;
     hipStream_t chain2 = nullptr;
-    hipEvent_t ev_cfork = nullptr, ev_cjoin = nullptr;
+    hipEvent_t ev_cfork = nullptr, ev_cjoin = nullptr, ev_cstag = nullptr;
     float *wino_v2 = nullptr, *wino_m2 = nullptr;
     std::vector<float*> seg_t, seg_r, seg_x;
     float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
@@ -469,6 +469,7 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     if (n->chain2) hipStreamDestroy(n->chain2);
     if (n->ev_cfork) hipEventDestroy(n->ev_cfork);
     if (n->ev_cjoin) hipEventDestroy(n->ev_cjoin);
+    if (n->ev_cstag) hipEventDestroy(n->ev_cstag);
     if (n->side) hipStreamDestroy(n->side);
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ev_join) hipEventDestroy(n->ev_join);
@@ -786,6 +787,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         TD_HIP(hipStreamCreateWithFlags(&n->chain2, hipStreamNonBlocking));
         TD_HIP(hipEventCreateWithFlags(&n->ev_cfork, hipEventDisableTiming));
         TD_HIP(hipEventCreateWithFlags(&n->ev_cjoin, hipEventDisableTiming));
+        TD_HIP(hipEventCreateWithFlags(&n->ev_cstag, hipEventDisableTiming));
     }
     TD_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TD_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
@@ -831,8 +833,10 @@ static void launch_wino4_c(bool out_side, const WinoArgs& wa, hipStream_t s) {
 
 // Winograd conv (or one chunk of it): input transform -> (m+2)^2 batched GEMMs -> output transform, all on stream s.
 // V / Mb: workspaces for THIS call ([nb][Tc + pad][C]); nullptr = the handle's (n->wino_v / wino_m) or, without a handle, temporary ones.
+// after_in / waiter: an event recorded right after the input transform and a stream made to wait for it (the staggered start of the
+// second row-parity chain); nullptr = none.
 static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
-                    const LnFuse* lnf, const WinoChunk& ck, float* V, float* Mb) {
+                    const LnFuse* lnf, const WinoChunk& ck, float* V, float* Mb, hipEvent_t after_in = nullptr, hipStream_t waiter = nullptr) {
     const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
     const long T = (long)L.dil * L.dil * TY * TX;
     const bool chunked = ck.ny != 1 || ck.nx != 1;
@@ -867,6 +871,10 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         prof_end(n, s);
     };
     transform(false);
+    if (after_in && waiter) {
+        TD_HIP(hipEventRecord(after_in, s));
+        TD_HIP(hipStreamWaitEvent(waiter, after_in, 0));
+    }
     prof_begin(n, 0, 2, 2.0 * nb * Tc * (double)L.Cin * L.Cout, s);
     if (L.pers && gemm_supports(L.Cin)) {
         GemmArgs ga;
@@ -1088,17 +1096,23 @@ static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t 
     }
     TD_HIP(hipEventRecord(n->ev_cfork, s));
     TD_HIP(hipStreamWaitEvent(n->chain2, n->ev_cfork, 0));
+    // overlap bit 4: chain 1 starts when chain 0's FIRST input transform is done, i.e. together with chain 0's first GEMM.  Started
+    // together the chains run in lockstep (transform beside transform, GEMM beside GEMM: profiles/r03a_timeline_*); half a conv apart,
+    // one chain's transforms meet the other's GEMMs.
+    bool stagger_pending = (n->opts.overlap & 4) != 0;
     for (int b = sb; b < nblk; ++b) {
         BlockLayers& B = L.blocks[b];
         const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
         for (int c = 0; c < 2; ++c) {
             WinoChunk ck; ck.ny = 2; ck.cy = c;
-            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c], c == 0 && stagger_pending ? n->ev_cstag : nullptr, c == 0 && stagger_pending ? n->chain2 : nullptr));
+            if (c == 0 && !(b == sb && n->seg_conv == 1)) stagger_pending = false;
             if (B.has_ds && b > sb) TD_TRY(run_ds_rows(n, B.ds, xin, h, w, n->seg_r[b], 2, c, st[c]));
         }
         for (int c = 0; c < 2; ++c) {
             WinoChunk ck; ck.ny = 2; ck.cy = c;
-            TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+            TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c], c == 0 && stagger_pending ? n->ev_cstag : nullptr, c == 0 && stagger_pending ? n->chain2 : nullptr));
+            if (c == 0) stagger_pending = false;
         }
     }
     TD_HIP(hipEventRecord(n->ev_cjoin, n->chain2));

@@ -303,7 +303,8 @@ def test_winograd_chunked_low_register_transforms(lib):
 
 
 @pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 1}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
-                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td4", "resnet18", {"overlap": 1, "winograd": 4})])
+                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td4", "resnet18", {"overlap": 1, "winograd": 4}),
+                                          ("td4", "resnet18", {"overlap": 1 | 4 | 32})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     """tdnet_opts.overlap bit 1: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows)
     against the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd."""
