@@ -79,6 +79,8 @@ typedef struct tdnet_opts {
                                 2 = the low-register transform kernels for every F(4x4) conv, chained or not,
                                 4 = with bit 1: the second chain starts half a conv late (when the first chain's first input transform is
                                     done), so that one chain's transforms meet the other's GEMMs instead of its transforms,
+                                8 = the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h: no staging registers, 82 VGPRs),
+                                64 = with bits 1 and 8: the transforms of layer4 ride as a fifth wave inside the other chain's GEMM workgroups,
                                 bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
     int32_t reserved[8];     /* must be 0                                                                                        */
 } tdnet_opts;

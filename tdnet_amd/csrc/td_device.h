@@ -72,6 +72,9 @@ TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, u
 #define TD_BARRIER_RAW() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
                               __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 
+// wave priority 0..3 for the SIMD's instruction arbiter (priority first, then age)
+#define TD_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+
 // s_sleep: park the wave for ~64*n cycles (n <= 127); used to de-phase co-resident workgroups
 #define TD_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 

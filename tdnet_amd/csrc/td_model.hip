@@ -14,6 +14,7 @@
 #include "td_conv_ad.h"
 #include "td_wino.h"
 #include "td_gemm.h"
+#include "td_gemm_dma.h"
 #include "td_attn.h"
 #include "td_attn_h.h"
 #include "td_misc.h"
@@ -128,6 +129,7 @@ struct ConvLayer {
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
+    bool gdma = false;                                                 // the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h; tdnet_opts.overlap bit 8)
     int vw = 0;                                                        // != 0: the low-register F(4x4) transform kernels with vw channels per lane (td_wino.h k_wino4_*_c)
     int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 2 = F(2x2,3x3), 4 = F(4x4,3x3)): d_wp = (m+2)^2 packed 1x1 weight sets (td_wino.h)
     float* d_zero = nullptr;                                           // zero bias for the batched GEMM pass
@@ -162,7 +164,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.stagger = d.stagger < 0 ? 0 : d.stagger > 64 ? 64 : d.stagger;
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
-    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0x37;
+    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0x7f;
     if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
     return d;
 }
@@ -186,6 +188,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         L.chunks = (L.wino == 4 && chunks > 1 && dil % chunks == 0 && o.gemm_persistent && gemm_supports(Cin)) ? chunks : 1;
         chunks = L.chunks;
         L.vw = (L.wino == 4 && (L.chunks > 1 || (o.overlap & 2))) ? (1 << ((o.overlap >> 4) & 3)) : 0;
+        L.gdma = (o.overlap & 8) != 0;
         // nb = (m+2)^2 batched [T x Cin] x [Cin x Cout] GEMMs, T = M / m^2 tiles: nb * T rows in total -> pick the tile for that many workgroups
         const int nb = (L.wino + 2) * (L.wino + 2);
         const bool pers = o.gemm_persistent && gemm_supports(Cin);
@@ -527,6 +530,9 @@ static int upload(float** d, const std::vector<float>& v) {
 // of the backbone (ResNet-18/34: layer3.0.conv2 .. layer4.1.conv2, dilations 2,2,2,4,4,8,4 -- resnet.py:181-198) the even and the odd
 // rows are two INDEPENDENT chains of convs (residual adds and the 1x1 downsample are pixel-wise), each with half the Winograd tiles.
 static bool conv_chainable(int cin, int cout, int stride, int dil, const tdnet_opts& o) {
+    // rider schedule (overlap bit 64): a chunk's 36 GEMM batches go out as 24 + 12, which are whole tiles per resident workgroup only
+    // when a batch of a chunk is a multiple of 64 tiles of 64 x 128 -- the 512-channel layers; the narrower ones stay outside the run
+    if ((o.overlap & 64) && (o.overlap & 8) && cout < 512) return false;
     return stride == 1 && dil % 2 == 0 && cin >= 128 && cout >= 128 && gemm_supports(cin) && cout % 4 == 0;
 }
 static void plan_chains(tdnet* n) {
@@ -880,7 +886,8 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         GemmArgs ga;
         ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
         ga.M = (int)Tc; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP; ga.stagger = L.stagger;
-        gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
+        if (L.gdma && gemm_dma_supports(L.Cin, L.Cout, L.tile)) gemm_dma_launch(ga, nullptr, L.pers > 1 ? L.pers : 0, s);
+        else gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else {
         ConvArgs g;
         g.in = V; g.wp = L.d_wp; g.bias = L.d_zero; g.resid = nullptr; g.out = Mb;
@@ -1063,6 +1070,99 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
     return 0;
 }
 
+static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int W, float* out, int ny, int cy, hipStream_t s);
+
+// ---- the pieces of a Winograd conv chunk for the rider schedule (td_gemm_dma.h): its argument block, a stand-alone transform launch,
+// and the GEMMs of the batches [b0, b0 + nbs) with the transforms of OTHER chunks riding in the fifth wave of its workgroups -------------
+static WinoArgs wino_chunk_args(const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, const WinoChunk& ck,
+                                float* V, float* Mb) {
+    const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
+    const long Tc = (long)(L.dil / ck.ny) * (L.dil / ck.nx) * TY * TX;
+    WinoArgs wa;
+    wa.in = in; wa.V = V; wa.Mb = Mb; wa.bias = L.d_bias; wa.resid = resid; wa.out = out;
+    wa.H = H; wa.W = W; wa.C = L.Cin; wa.Cout = L.Cout; wa.dil = L.dil; wa.TY = TY; wa.TX = TX; wa.T = (int)((long)L.dil * L.dil * TY * TX);
+    wa.act = L.act; wa.TP = (int)(Tc + L.wino_pad);
+    wa.ln_mean = wa.ln_rstd = wa.ln_g = wa.ln_b = nullptr;
+    wa.Tc = (int)Tc; wa.ny = ck.ny; wa.cy = ck.cy; wa.nx = ck.nx; wa.cx = ck.cx;
+    return wa;
+}
+static void wino_transform_alone(tdnet* n, const ConvLayer& L, const WinoArgs& wa, bool out_side, hipStream_t s) {
+    prof_begin(n, 2, false, 0, s);
+    const int C = out_side ? L.Cout : L.Cin;
+    if (L.vw == 4 && C % 4 == 0) launch_wino4_c<4>(out_side, wa, s);
+    else if (L.vw == 2 && C % 2 == 0) launch_wino4_c<2>(out_side, wa, s);
+    else launch_wino4_c<1>(out_side, wa, s);
+    prof_end(n, s);
+}
+static void wino_gemm_with_rider(tdnet* n, const ConvLayer& L, const WinoArgs& wa, int b0, int nbs, const WinoArgs* ride_in,
+                                 const WinoArgs* ride_out, hipStream_t s) {
+    GemmArgs ga;
+    const int nsteps = L.Cin / 32;
+    ga.a = wa.V + (size_t)b0 * wa.TP * L.Cin; ga.wp = L.d_wp + (size_t)b0 * nsteps * 8 * L.CoutPad * 4; ga.bias = L.d_zero; ga.resid = nullptr;
+    ga.out = const_cast<float*>(wa.Mb) + (size_t)b0 * wa.TP * L.Cout;
+    ga.M = wa.Tc; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nbs; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = wa.TP; ga.stagger = 0;
+    RiderArgs rw;
+    rw.in_u0 = rw.in_u1 = rw.out_u0 = rw.out_u1 = 0;
+    if (ride_in) { rw.tin = *ride_in; rw.in_u1 = ride_in->Tc * ((ride_in->C + 63) / 64); }
+    if (ride_out) { rw.tout = *ride_out; rw.out_u1 = ride_out->Tc * ((ride_out->Cout + 63) / 64); }
+    static const int dbg = getenv("TD_RIDER_DEBUG") ? atoi(getenv("TD_RIDER_DEBUG")) : 0;   // timing experiments only (results are wrong): 1 = riders idle, 2 = no fifth wave
+    if (dbg == 1) { rw.in_u1 = rw.in_u0; rw.out_u1 = rw.out_u0; }
+    if (dbg == 2) { ride_in = ride_out = nullptr; }
+    const int riders = dbg == 3 ? 1 : 2;
+    prof_begin(n, 0, 2, 2.0 * nbs * wa.Tc * (double)L.Cin * L.Cout, s);
+    gemm_dma_launch(ga, (ride_in || ride_out) ? &rw : nullptr, L.pers > 1 ? L.pers : 0, s, riders);
+    prof_end(n, s);
+}
+
+// The run of even-dilation convs with RIDERS (tdnet_opts.overlap bit 64): ONE stream, the two row-parity chains interleaved, every
+// transform except the first and the last riding in the fifth wave of the other chain's GEMM workgroups.  The 36 GEMM batches of a chunk
+// are two launches, 24 + 12 batches (for the 512-channel layers: 1536 and 768 tiles = 2 and 1 per resident workgroup), because the two
+// transforms between a chain's consecutive GEMMs depend on each other through neighbouring tiles -- out(i) must be COMPLETE before
+// in(i + 1) starts -- and so need two launches of the other chain to ride on:
+//     GA(E,i) + out(O,i-1) | GB(E,i) + in(O,i) | GA(O,i) + out(E,i) | GB(O,i) + in(E,i+1) | ...
+// Every dependency is the stream order of whole launches: no events, no flags, nothing to wait for inside a kernel.
+static int run_parity_chains_riders(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
+    const int sb = n->seg_block, nblk = (int)L.blocks.size();
+    {
+        BlockLayers& B = L.blocks[sb];
+        if (n->seg_conv == 1) TD_TRY(run_conv(n, B.c1, n->bx, h, w, nullptr, n->seg_t[sb], s));
+        if (B.has_ds) TD_TRY(run_conv(n, B.ds, n->bx, h, w, nullptr, n->seg_r[sb], s));
+    }
+    struct Job { const ConvLayer* L; WinoArgs wa[2]; const ConvLayer* ds; const float* ds_in; float* ds_out; };
+    std::vector<Job> jobs;
+    float* Vw[2] = {n->wino_v, n->wino_v2};
+    float* Mw[2] = {n->wino_m, n->wino_m2};
+    for (int b = sb; b < nblk; ++b) {
+        BlockLayers& B = L.blocks[b];
+        const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
+        if (!(b == sb && n->seg_conv == 1)) {
+            Job j; j.L = &B.c1; j.ds = nullptr; j.ds_in = nullptr; j.ds_out = nullptr;
+            for (int c = 0; c < 2; ++c) { WinoChunk ck; ck.ny = 2; ck.cy = c; j.wa[c] = wino_chunk_args(B.c1, xin, h, w, nullptr, n->seg_t[b], ck, Vw[c], Mw[c]); }
+            jobs.push_back(j);
+        }
+        Job j; j.L = &B.c2; j.ds = (B.has_ds && b > sb) ? &B.ds : nullptr; j.ds_in = xin; j.ds_out = n->seg_r[b];
+        for (int c = 0; c < 2; ++c) {
+            WinoChunk ck; ck.ny = 2; ck.cy = c;
+            j.wa[c] = wino_chunk_args(B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], ck, Vw[c], Mw[c]);
+        }
+        jobs.push_back(j);
+    }
+    const int nj = (int)jobs.size();
+    for (auto& j : jobs)
+        if (!j.L->gdma || !gemm_dma_supports(j.L->Cin, j.L->Cout, j.L->tile) || j.L->wino != 4) return td_fail("internal: rider schedule on a conv the LDS-DMA GEMM cannot run");
+    wino_transform_alone(n, *jobs[0].L, jobs[0].wa[0], false, s);                    // in(E,0)
+    for (int i = 0; i < nj; ++i) {
+        Job& J = jobs[i];
+        if (J.ds) for (int c = 0; c < 2; ++c) TD_TRY(run_ds_rows(n, *J.ds, J.ds_in, h, w, J.ds_out, 2, c, s));   // its input: out(.,i-2), long complete
+        wino_gemm_with_rider(n, *J.L, J.wa[0], 0, 24, nullptr, i > 0 ? &jobs[i - 1].wa[1] : nullptr, s);          // GA(E,i) + out(O,i-1)
+        wino_gemm_with_rider(n, *J.L, J.wa[0], 24, 12, &J.wa[1], nullptr, s);                                      // GB(E,i) + in(O,i)
+        wino_gemm_with_rider(n, *J.L, J.wa[1], 0, 24, nullptr, &J.wa[0], s);                                       // GA(O,i) + out(E,i)
+        wino_gemm_with_rider(n, *J.L, J.wa[1], 24, 12, i + 1 < nj ? &jobs[i + 1].wa[0] : nullptr, nullptr, s);     // GB(O,i) + in(E,i+1)
+    }
+    wino_transform_alone(n, *jobs[nj - 1].L, jobs[nj - 1].wa[1], true, s);           // out(O,last)
+    return 0;
+}
+
 // The 1x1 stride-1 downsample conv (resnet.py:172-177) on the image rows y = ny * i + cy only: a batched GEMM, batch = row, M = W pixels,
 // row pitch ny * W pixels, one weight set (td_gemm.h GemmArgs.wshare).
 static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int W, float* out, int ny, int cy, hipStream_t s) {
@@ -1084,7 +1184,9 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
 // while one chain's GEMM holds the matrix pipes, the other's transforms (HBM-bound, one wave per SIMD beside the GEMM's three) run
 // under it, and a chain's GEMM workgroups start as the other's retire.  Host enqueue order alternates between the chains so that
 // neither stream runs dry while the other's launches are being issued.
+static int run_parity_chains_riders(tdnet* n, PathLayers& L, int h, int w, hipStream_t s);
 static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
+    if ((n->opts.overlap & 64) && (n->opts.overlap & 8)) return run_parity_chains_riders(n, L, h, w, s);
     const int sb = n->seg_block, nblk = (int)L.blocks.size();
     hipStream_t st[2] = {s, n->chain2};
     float* Vw[2] = {n->wino_v, n->wino_v2};

@@ -346,11 +346,10 @@ TD_DEV void td_wino4_at_t(const T (&m)[6], T (&y)[4]) {
     y[2] = p + 4.f * r;
     y[3] = q + 8.f * s + m[5];
 }
-// (wave-uniform) tile of a chunk -> phase and tile coordinates; returns false past the end
+// (wave-uniform) unit wv of a chunk -> tile, channel slice, phase and tile coordinates
 struct WinoTile { int tl, sl, py, px, ty, tx; };
-TD_DEV bool td_wino_chunk_tile(const WinoArgs& p, int slices, WinoTile& w) {
-    const int wv = TD_UNIFORM((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    if (wv >= p.Tc * slices) return false;
+TD_DEV WinoTile td_wino_unit_tile(const WinoArgs& p, int slices, int wv) {
+    WinoTile w;
     w.tl = wv / slices; w.sl = wv - w.tl * slices;
     int t = w.tl;
     w.tx = t % p.TX; t /= p.TX;
@@ -358,16 +357,18 @@ TD_DEV bool td_wino_chunk_tile(const WinoArgs& p, int slices, WinoTile& w) {
     const int pw = p.dil / p.nx;
     w.px = p.nx * (t % pw) + p.cx;
     w.py = p.ny * (t / pw) + p.cy;
-    return true;
+    return w;
 }
 
-template <int VW>
-TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
+// One unit = one wave's work: (tile, slice of 64 VW channels) of the input transform.  `mid()` is called between the issue of the 36
+// patch loads and their first use: a no-op in the transform kernels; in the rider wave of k_gemm_dma (td_gemm_dma.h) it is the
+// workgroup's barrier, so that the loads are in flight while the wave waits there.
+template <int VW, typename Mid>
+TD_DEV void td_wino4_in_unit(const WinoArgs& p, int wv, Mid&& mid) {
     typedef WinoVec<VW> X;
     typedef typename X::T T;
     const int slices = (p.C + 64 * VW - 1) / (64 * VW);
-    WinoTile w;
-    if (!td_wino_chunk_tile(p, slices, w)) return;
+    const WinoTile w = td_wino_unit_tile(p, slices, wv);
     const WinoBufs wb = td_wino_bufs(p);
     const int c0 = (w.sl * 64 + (int)(threadIdx.x & 63)) * VW;        // this lane's first channel
     const unsigned coff = c0 < p.C ? (unsigned)c0 * 4u : TD_BUF_OOB;  // lanes past C (C not a multiple of 64 VW): nothing read, nothing written
@@ -376,27 +377,33 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
         const TdBuf mb = td_make_buf(p.ln_mean, (unsigned)p.C * 4u), rb = td_make_buf(p.ln_rstd, (unsigned)p.C * 4u);
         m4 = X::ld(mb, coff, 0u); r4 = X::ld(rb, coff, 0u);
     }
-    T tm[6][6];
+    T dd[6][6];                                                       // [c][r]
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const int x = w.px + p.dil * (4 * w.tx - 1 + c);
-        T d[6], col[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int y = w.py + p.dil * (4 * w.ty - 1 + r);
             const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;          // wave-uniform
             const unsigned pix = (unsigned)y * (unsigned)p.W + (unsigned)x;
             T z = X::ld(wb.in, ok ? coff : TD_BUF_OOB, ok ? pix * (unsigned)p.C * 4u : 0u);
-            if (p.ln_mean) {                                         // the arithmetic of td_wino_ld / k_ln_apply, same order
+            if (p.ln_mean) {                                         // uniform; the arithmetic of td_wino_ld / k_ln_apply, same order (the head conv only:
                 const float g = td_buf_ld1(wb.g, ok ? 0u : TD_BUF_OOB, ok ? pix * 4u : 0u), b = td_buf_ld1(wb.b, ok ? 0u : TD_BUF_OOB, ok ? pix * 4u : 0u);
-                z = (z - m4) * r4 * g + b;
+                z = (z - m4) * r4 * g + b;                           // never on a rider wave, so waiting for the loads here costs nothing)
             }
-            d[r] = z;
+            dd[c][r] = z;
         }
-        td_wino4_bt_t(d, col);                                        // B^T d, one column
+    }
+    mid();
+    T tm[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        T col[6];
+        td_wino4_bt_t(dd[c], col);                                    // B^T d, one column
 #pragma unroll
         for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
     }
+    mid();                                                            // (a rider splits a unit over two barrier intervals)
     const unsigned plane = (unsigned)p.TP * (unsigned)p.C * 4u;
     const TdBuf vb = td_make_buf(p.V, 36u * plane);
     const unsigned voff = (unsigned)w.tl * (unsigned)p.C * 4u;
@@ -409,13 +416,12 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
     }
 }
 
-template <int VW>
-TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_out_c(WinoArgs p) {
+template <int VW, typename Mid>
+TD_DEV void td_wino4_out_unit(const WinoArgs& p, int wv, Mid&& mid) {
     typedef WinoVec<VW> X;
     typedef typename X::T T;
     const int slices = (p.Cout + 64 * VW - 1) / (64 * VW);
-    WinoTile w;
-    if (!td_wino_chunk_tile(p, slices, w)) return;
+    const WinoTile w = td_wino_unit_tile(p, slices, wv);
     const WinoBufs wb = td_wino_bufs(p);
     const float slope = td_act_slope(p.act);
     const int c0 = (w.sl * 64 + (int)(threadIdx.x & 63)) * VW;
@@ -440,18 +446,23 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_out_c(WinoArgs p) 
     const unsigned plane = (unsigned)p.TP * (unsigned)p.Cout * 4u;
     const TdBuf mb = td_make_buf(p.Mb, 36u * plane);
     const unsigned moff = (unsigned)w.tl * (unsigned)p.Cout * 4u;
+    T mm[6][6];                                                       // [c][r]
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) mm[c][r] = X::ld(mb, coff, (unsigned)(r * 6 + c) * plane + moff);
+    const TdBuf bbuf = td_make_buf(p.bias, (unsigned)p.Cout * 4u);
+    const T b = X::ld(bbuf, coff, 0u);
+    mid();
     T sm[4][6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        T m[6], col[4];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) m[r] = X::ld(mb, coff, (unsigned)(r * 6 + c) * plane + moff);
-        td_wino4_at_t(m, col);                                        // A^T m, one column
+        T col[4];
+        td_wino4_at_t(mm[c], col);                                    // A^T m, one column
 #pragma unroll
         for (int r = 0; r < 4; ++r) sm[r][c] = col[r];
     }
-    const TdBuf bb = td_make_buf(p.bias, (unsigned)p.Cout * 4u);
-    const T b = X::ld(bb, coff, 0u);
+    mid();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         T o4[4];
@@ -464,6 +475,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_out_c(WinoArgs p) 
             X::st(wb.out, ok ? coff : TD_BUF_OOB, ok ? offy[r] + offx[c] : 0u, X::act(o, slope));
         }
     }
+}
+
+template <int VW>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
+    const int slices = (p.C + 64 * VW - 1) / (64 * VW);
+    const int wv = TD_UNIFORM((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wv >= p.Tc * slices) return;
+    td_wino4_in_unit<VW>(p, wv, []() {});
+}
+template <int VW>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_out_c(WinoArgs p) {
+    const int slices = (p.Cout + 64 * VW - 1) / (64 * VW);
+    const int wv = TD_UNIFORM((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wv >= p.Tc * slices) return;
+    td_wino4_out_unit<VW>(p, wv, []() {});
 }
 // grid of a chunked transform: one wave per (tile, channel slice)
 static inline unsigned wino_chunk_grid(int Tc, int C, int VW) { return (unsigned)(((long)Tc * ((C + 64 * VW - 1) / (64 * VW)) + 3) / 4); }

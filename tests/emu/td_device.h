@@ -103,6 +103,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
 #define TD_PIN(x) ((void)0)
 #define TD_UNIFORM(x) (x)
 #define TD_SLEEP(n) ((void)0)
+#define TD_SETPRIO(n) ((void)0)
 
 struct TdBuf { const char* p; unsigned bytes; };
 #define TD_BUF_OOB 0x80000000u

@@ -300,11 +300,22 @@ def test_winograd_chunked_low_register_transforms(lib):
             opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 2 | (vw << 4)})       # whole conv on the new kernels
             opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1 | (vw << 4)})       # even dilation: two chunks
     opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 1, "gemm_persistent": 3, "fusion": 64})
+    # td_gemm_dma.h (overlap bit 8): the batched GEMMs fed by LDS-DMA -- K = 32 .. 256 (1 .. 8 steps), ragged M and N, several tiles per
+    # workgroup (grid forced small), padded planes, whole convs and chunks; bit-identical to the register-staged GEMM
+    for a in shapes:
+        e0 = opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1})
+        e1 = opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1 | 8})
+        assert e0 == e1, (a, e0, e1)
+    for cap in (2, 3, 5, 8):
+        opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 8, "gemm_persistent": cap, "fusion": 64})
+        opcheck.conv(lib, MEM, 13, 21, 96, 128, 3, 1, 2, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 9 | 16, "gemm_persistent": cap})
 
 
 @pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 1}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
                                           ("td2", "resnet18", {"overlap": 3 | 32}), ("td4", "resnet18", {"overlap": 1, "winograd": 4}),
-                                          ("td4", "resnet18", {"overlap": 1 | 4 | 32})])
+                                          ("td4", "resnet18", {"overlap": 1 | 4 | 32}), ("td4", "resnet18", {"overlap": 1 | 8 | 32}),
+                                          ("td4", "resnet18", {"overlap": 1 | 8 | 64 | 32}), ("td4", "resnet34", {"overlap": 1 | 8 | 64}),
+                                          ("td2", "resnet18", {"overlap": 1 | 8 | 64 | 32, "gemm_persistent": 5})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     """tdnet_opts.overlap bit 1: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows)
     against the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd."""
