@@ -41,7 +41,7 @@ typedef struct tdnet_cfg {
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
 #define TDNET_FUSION_DEFAULT 6
-#define TDNET_OVERLAP_DEFAULT 33   /* row-parity chains, 4 channels per lane: +2 % on MI355X (profiles/r03a_ab_overlap_*) */
+#define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
                                 convs (Cin >= 256, Cout >= 128), 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) =
@@ -80,7 +80,9 @@ typedef struct tdnet_opts {
                                 4 = with bit 1: the second chain starts half a conv late (when the first chain's first input transform is
                                     done), so that one chain's transforms meet the other's GEMMs instead of its transforms,
                                 8 = the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h: no staging registers, 82 VGPRs),
-                                64 = with bits 1 and 8: the transforms of layer4 ride as a fifth wave inside the other chain's GEMM workgroups,
+                                64 = with bits 1 and 8: the transforms of layer4 ride INSIDE the other chain's GEMM launches, in the instruction
+                                     stream of its matrix waves, everything on one stream (td_gemm_dma.h TT = 1 / 2).  Measured: -4 %; the fp32
+                                     MFMA leaves its SIMD no VALU issue to spare.  Opt-in experiment,
                                 bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
     int32_t reserved[8];     /* must be 0                                                                                        */
 } tdnet_opts;

@@ -1,12 +1,22 @@
-// td_gemm_dma.h -- the batched fp32-MFMA GEMM of the Winograd convs (td_gemm.h ROLE 1) with both operands fed by LDS-DMA, and an
-// optional fifth "rider" wave per workgroup that runs Winograd transforms of OTHER data while the four matrix waves multiply.
+// td_gemm_dma.h -- the batched fp32-MFMA GEMM of the Winograd convs (td_gemm.h ROLE 1) with both operands fed by LDS-DMA, and
+// optionally Winograd transforms of OTHER data riding in the instruction stream of its matrix waves.
 //
 // Why.  The transforms of a Winograd conv are HBM-bound, its GEMMs MFMA-bound, and on one stream they run in series:
 // 0.6 ms of a 3.7 ms frame with idle matrix pipes.  The workgroup dispatcher does not overlap them (a kernel that arrives while the
-// persistent GEMM holds the CUs is not admitted beside it), so the overlap has to be built INTO the GEMM's workgroups: a fifth wave that
-// issues transform loads / stores between the workgroup's barriers.  For three such workgroups to stay resident per CU, 15 waves must fit
-// the SIMDs' register files as (4,4,4,3): tools/occupancy_probe.hip shows 5-wave workgroups at 128 VGPRs get only TWO per CU, at 96
-// three.  The register-staged GEMM needs 130; fed by DMA it needs no staging registers at all.
+// persistent GEMM holds the CUs is not admitted beside it), so the overlap has to be built INTO the GEMM's workgroups.  First attempt: a
+// fifth "rider" wave per workgroup doing transform units between the barriers (needs <= 96 VGPRs for three 5-wave workgroups per CU,
+// tools/occupancy_probe.hip; fed by DMA the GEMM needs 82).  Structure free (idle riders cost nothing), but a wave on a SIMD whose
+// matrix pipe is saturated gets ~1 VALU instruction per 26 cycles: 4.9 us per unit against a K step of 2.9 us, the rider paced the
+// barriers and every launch took the transform's stand-alone time longer (profiles/r03n_*).  A wave's OWN MFMA, though, leaves it ~13
+// issue slots per 64-cycle MFMA on paper, so the second attempt (this file, TT = 1 / 2) lets each MATRIX wave carry one transform unit at
+// a time: loads requested at the top of a K step, arithmetic and stores in the next step.  MEASURED (profiles/r03n_*): the same +22 us
+// per launch (GA 116, GB 71 us against 94 / 49 with the units disabled), and spreading the units evenly over the launch made it worse
+// (134 / 83: every step of every workgroup then has one late wave).  The cost is the transform's ~350 instructions per unit at ~22
+// cycles each wherever they run: the fp32 MFMA occupies its SIMD's issue port for its whole 64 cycles, and at 87 % matrix-pipe
+// utilisation a fifth of the cycles is all the VALU gets.  One channel per lane makes the transforms VALU-heavy (33 VALU per KB; the
+// stand-alone 4-channel kernels need 8 and are HBM-bound), and the 4-channel form does not fit the registers of a GEMM wave.  So on
+// this chip the transforms of an fp32 Winograd conv cannot hide under its own kind of GEMM: TT = 1 / 2 stay as a measured, opt-in
+// experiment (tdnet_opts.overlap bit 64); the default uses TT = 0, which is simply the faster GEMM (82 VGPRs, +2.6 % over td_gemm.h).
 //
 //   out[b][m][n] = sum_k A[b][m][k] W[b][k][n]      (plain epilogue: bias, residual and activation belong to the output transform)
 //
@@ -27,16 +37,16 @@ struct GemmDmaGeom {
     static constexpr int A_BYTES = BM * 128, B_BYTES = 8 * BN * 16, BUF_BYTES = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF_BYTES;
 };
 
-// What the rider wave of a launch does: units [u0, u1) of an input transform and / or of an output transform (td_wino.h WinoArgs of
-// the chunk they belong to; a unit = one (tile, 64-channel slice)).  Workgroup w takes the units w, w + G, w + 2 G, ...
+// What rides in a launch: units [u0, u1) of an input transform OR of an output transform (td_wino.h WinoArgs of the chunk they belong
+// to; a unit = one (tile, 64-channel slice), one channel per lane).  Wave v of workgroup w takes the units 4 w + v, + 4 G, + 8 G, ...
 struct RiderArgs {
     WinoArgs tin, tout;
     int in_u0, in_u1, out_u0, out_u1;
 };
 
-// RIDER = number of rider waves per workgroup (0, 1, 2): waves 4 .. 3 + RIDER
-template <int RIDER>
-TD_KERNEL void TD_LAUNCH_BOUNDS(256 + 64 * RIDER, RIDER ? 5 : 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
+// TT: 0 = GEMM only; 1 = units [in_u0, in_u1) of the input transform rw.tin ride along; 2 = units [out_u0, out_u1) of rw.tout
+template <int TT>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
     using G = GemmDmaGeom;
     TD_DYN_LDS(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
@@ -51,29 +61,28 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 + 64 * RIDER, RIDER ? 5 : 3) k_gemm_dma(Gemm
     const int xbase = xcd < rem ? xcd * (nq + 1) : rem * (nq + 1) + (xcd - rem) * nq;
     const int xcount = nq + (xcd < rem ? 1 : 0);
     const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
-    const int nbar = my_tiles > 0 ? 1 + my_tiles * nsteps : 0;        // barriers every wave of this workgroup goes through
 
-    if (RIDER && wave >= 4) {
-        // ---- the rider: transform units between the workgroup's barriers.  Loads are issued before a barrier and consumed after it,
-        // so the wave never sits in a memory wait while the matrix waves are at the barrier behind it. -------------------------------
-        // Highest wave priority: beside three matrix waves that keep the SIMD's issue port busy, a wave at the default priority gets
-        // its VALU instructions through 3-5x slower and the rider, not the MFMAs, would pace the workgroup's barriers
-        // (first version, profiles/r03n_*: 3.5 us per K step against 2.9 without a rider).  Its few hundred instructions per step cost
-        // the matrix waves next to nothing.
-        TD_SETPRIO(3);
-        int bar = 0;
-        auto sync = [&]() { if (bar < nbar) { TD_BARRIER_RAW(); ++bar; } };
-        // One rider wave alone needs ~4.9 us per unit (430 instructions beside three matrix waves on its SIMD: profiles/r03o_*) against a
-        // K step of 2.9 us: with a unit per barrier it PACED the workgroup, and a launch took 22 us longer -- exactly the transform's
-        // stand-alone time.  So: RIDER waves share the units, and a unit spans two barrier intervals (loads | column pass | row pass +
-        // stores), each shorter than a K step.
-        const int gsz = (int)gridDim.x * RIDER, first = (int)blockIdx.x * RIDER + (wave - 4);
-        for (int u = rw.out_u0 + first; u < rw.out_u1; u += gsz) { td_wino4_out_unit<1>(rw.tout, u, sync); }
-        for (int u = rw.in_u0 + first; u < rw.in_u1; u += gsz) { td_wino4_in_unit<1>(rw.tin, u, sync); }
-        while (bar < nbar) sync();
+    // ---- the riding transform: this wave's units u_next, u_next + u_stride, ... ------------------------------------------------
+    WinoInRide ride_i;
+    WinoOutRide ride_o;
+    bool ride_pending = false;                                        // loads of a unit requested, not yet finished
+    const int u_stride = (int)gridDim.x * 4;
+    int u_next = (TT == 1 ? rw.in_u0 : rw.out_u0) + (int)blockIdx.x * 4 + wave;
+    const int u_end = TT == 1 ? rw.in_u1 : TT == 2 ? rw.out_u1 : 0;
+    auto ride_issue = [&]() {
+        if (TT == 0 || u_next >= u_end) return;                       // wave-uniform
+        if (TT == 1) td_wino4_in_issue(rw.tin, u_next, ride_i); else td_wino4_out_issue(rw.tout, u_next, ride_o);
+        u_next += u_stride;
+        ride_pending = true;
+    };
+    auto ride_finish = [&]() {
+        if (TT == 1) td_wino4_in_finish(rw.tin, ride_i); else if (TT == 2) td_wino4_out_finish(rw.tout, ride_o);
+        ride_pending = false;
+    };
+    if (my_tiles == 0) {                                              // no tile for this workgroup: its waves still do their units
+        while (TT && u_next < u_end) { ride_issue(); ride_finish(); }
         return;
     }
-    if (my_tiles == 0) return;
 
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
@@ -144,9 +153,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 + 64 * RIDER, RIDER ? 5 : 3) k_gemm_dma(Gemm
             for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
     };
     // one K step on buffer `buf`; the six pieces of the next step go out after the MFMA half-groups (eight slots of four MFMAs)
-    auto compute = [&](int buf, int ibuf) {
+    auto compute = [&](int buf, int ibuf, auto with_ride) {
+        constexpr bool RIDE = TT != 0 && decltype(with_ride)::value;
         const char* base = smem + buf * G::BUF_BYTES;
         f32x4 af[2], bf[2][2];
+        // The riding unit's arithmetic and stores: independent of everything below.  Left to itself the compiler puts all ~350 of those
+        // instructions AHEAD of the step's first MFMA (the wave then reaches the barrier 2-3 k cycles late and paces its workgroup); the
+        // scheduling groups at the end of this block pin them BETWEEN the MFMAs, ten VALU and a store per MFMA.
+        if constexpr (RIDE) ride_finish();
         af[0] = *reinterpret_cast<const f32x4*>(base + a_rd[0]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(base + b_rd + j * 512);
@@ -163,9 +177,26 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 + 64 * RIDER, RIDER ? 5 : 3) k_gemm_dma(Gemm
                 for (int s = 2 * h2; s < 2 * h2 + 2; ++s)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[0][j] = td_mfma32(af[g & 1][s], bf[g & 1][j][s], acc[0][j]);
-                TD_SCHED_FENCE();
+                if constexpr (!RIDE) TD_SCHED_FENCE();
                 if (2 * g + h2 < 6) issue_piece(ibuf, 2 * g + h2);
-                TD_SCHED_FENCE();
+                if constexpr (!RIDE) TD_SCHED_FENCE();
+            }
+        }
+        if constexpr (RIDE) {
+            TD_SCHED_GROUP(0x100, 3);                                 // the first fragments
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        TD_SCHED_GROUP(0x008, 1);                     // one MFMA ...
+                        TD_SCHED_GROUP(0x002, 10);                    // ... ten VALU of the riding unit in its shadow ...
+                        TD_SCHED_GROUP(0x040, 1);                     // ... and one of its stores
+                    }
+                    TD_SCHED_GROUP(0x020, 1);                         // the DMA piece of this half group
+                    if (h2 == 0 && g < 3) TD_SCHED_GROUP(0x100, 3);   // the next group's fragments
+                }
             }
         }
         issue_end();
@@ -182,15 +213,21 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 + 64 * RIDER, RIDER ? 5 : 3) k_gemm_dma(Gemm
     int cb = 0;
     for (int t = 0; t < my_tiles; ++t) {
         for (int st = 0; st < nsteps; ++st) {
-            compute(cb, cb ^ 1);
+            if (TT != 0 && ride_pending) compute(cb, cb ^ 1, std::true_type{});      // wave-uniform
+            else compute(cb, cb ^ 1, std::false_type{});
             TD_WAIT_VM_PIECES(0);
             TD_BARRIER_RAW();
             cb ^= 1;
+            ride_issue();                                             // the next unit's loads: a whole K step ahead of their use
         }
         float* outb = p.out + (size_t)spos.b * p.MP * p.N;
         td_store_acc<1, 2, true, true>(acc, outb, p.bias, nullptr, p.M, p.N, 0, spos.tm * G::BM + wm * 32, spos.tn * G::BN + wn * 64, lane);
         zero_acc();
         advance(spos);
+    }
+    if (TT != 0) {                                                    // units left over when the tiles ran out (short launches): unhidden tail
+        if (ride_pending) ride_finish();
+        while (u_next < u_end) { ride_issue(); ride_finish(); }
     }
 }
 
@@ -199,14 +236,15 @@ static inline bool gemm_dma_supports(int K, int N, ConvTile tile) {
     return K % 32 == 0 && d.BN == 128 && d.WGN == 2 && N % 4 == 0;
 }
 // grid_cap > 0 forces the number of workgroups (tests); rw == nullptr: four waves, no rider
-static inline void gemm_dma_launch(GemmArgs a, const RiderArgs* rw, int grid_cap, hipStream_t s, int riders = 2) {
+// rw: one transform rides (its input OR its output units; a launch carries one kind); nullptr = GEMM only
+static inline void gemm_dma_launch(GemmArgs a, const RiderArgs* rw, int grid_cap, hipStream_t s) {
     a.tiles_m = (a.M + 63) / 64;
     a.tiles_n = a.NPad / 128;
     const long total = (long)a.tiles_m * a.tiles_n * a.nbatch;
     long grid = grid_cap > 0 ? grid_cap : 768;
     if (grid > total) grid = total;
-    if (rw && riders == 2) TD_LAUNCH((k_gemm_dma<2>), dim3((unsigned)grid), dim3(384), GemmDmaGeom::LDS_BYTES, s, a, *rw);
-    else if (rw) TD_LAUNCH((k_gemm_dma<1>), dim3((unsigned)grid), dim3(320), GemmDmaGeom::LDS_BYTES, s, a, *rw);
+    if (rw && rw->in_u1 > rw->in_u0) TD_LAUNCH((k_gemm_dma<1>), dim3((unsigned)grid), dim3(256), GemmDmaGeom::LDS_BYTES, s, a, *rw);
+    else if (rw && rw->out_u1 > rw->out_u0) TD_LAUNCH((k_gemm_dma<2>), dim3((unsigned)grid), dim3(256), GemmDmaGeom::LDS_BYTES, s, a, *rw);
     else {
         RiderArgs none;
         none.in_u0 = none.in_u1 = none.out_u0 = none.out_u1 = 0;

@@ -1105,12 +1105,8 @@ static void wino_gemm_with_rider(tdnet* n, const ConvLayer& L, const WinoArgs& w
     rw.in_u0 = rw.in_u1 = rw.out_u0 = rw.out_u1 = 0;
     if (ride_in) { rw.tin = *ride_in; rw.in_u1 = ride_in->Tc * ((ride_in->C + 63) / 64); }
     if (ride_out) { rw.tout = *ride_out; rw.out_u1 = ride_out->Tc * ((ride_out->Cout + 63) / 64); }
-    static const int dbg = getenv("TD_RIDER_DEBUG") ? atoi(getenv("TD_RIDER_DEBUG")) : 0;   // timing experiments only (results are wrong): 1 = riders idle, 2 = no fifth wave
-    if (dbg == 1) { rw.in_u1 = rw.in_u0; rw.out_u1 = rw.out_u0; }
-    if (dbg == 2) { ride_in = ride_out = nullptr; }
-    const int riders = dbg == 3 ? 1 : 2;
     prof_begin(n, 0, 2, 2.0 * nbs * wa.Tc * (double)L.Cin * L.Cout, s);
-    gemm_dma_launch(ga, (ride_in || ride_out) ? &rw : nullptr, L.pers > 1 ? L.pers : 0, s, riders);
+    gemm_dma_launch(ga, (ride_in || ride_out) ? &rw : nullptr, L.pers > 1 ? L.pers : 0, s);
     prof_end(n, s);
 }
 

@@ -477,6 +477,110 @@ TD_DEV void td_wino4_out_unit(const WinoArgs& p, int wv, Mid&& mid) {
     }
 }
 
+// ---- the same units in two halves, one channel per lane, for the transforms that ride in the MATRIX waves of k_gemm_dma (td_gemm_dma.h):
+// *_issue requests the unit's loads into a register block that stays live across a K step; *_finish -- a step later, the data long
+// landed -- does the arithmetic and the stores, straight-line VALU / VMEM work the compiler threads between the step's MFMAs.
+struct WinoInRide { float d[6][6]; int wv; };                         // [c][r]
+struct WinoOutRide { float m[6][6]; float b; int wv; };          // the 16 residual values are requested in *_finish (its first instructions): 16 fewer live registers across the step
+TD_DEV void td_wino4_in_issue(const WinoArgs& p, int wv, WinoInRide& st) {
+    const int slices = (p.C + 63) / 64;
+    const WinoTile w = td_wino_unit_tile(p, slices, wv);
+    const TdBuf inb = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.C * 4u);
+    const int c0 = w.sl * 64 + (int)(threadIdx.x & 63);
+    const unsigned coff = c0 < p.C ? (unsigned)c0 * 4u : TD_BUF_OOB;
+    st.wv = wv;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int x = w.px + p.dil * (4 * w.tx - 1 + c);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int y = w.py + p.dil * (4 * w.ty - 1 + r);
+            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            st.d[c][r] = td_buf_ld1(inb, ok ? coff : TD_BUF_OOB, ok ? ((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.C * 4u : 0u);
+        }
+    }
+}
+TD_DEV void td_wino4_in_finish(const WinoArgs& p, const WinoInRide& st) {
+    const int slices = (p.C + 63) / 64;
+    const int tl = st.wv / slices, sl = st.wv - tl * slices;
+    const int c0 = sl * 64 + (int)(threadIdx.x & 63);
+    const unsigned coff = c0 < p.C ? (unsigned)c0 * 4u : TD_BUF_OOB;
+    float tm[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float col[6];
+        td_wino4_bt_t(st.d[c], col);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
+    }
+    const unsigned plane = (unsigned)p.TP * (unsigned)p.C * 4u;
+    const TdBuf vb = td_make_buf(p.V, 36u * plane);
+    const unsigned voff = (unsigned)tl * (unsigned)p.C * 4u;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float v[6];
+        td_wino4_bt_t(tm[r], v);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) td_buf_st1(vb, coff, (unsigned)(r * 6 + c) * plane + voff, v[c]);
+    }
+}
+TD_DEV void td_wino4_out_issue(const WinoArgs& p, int wv, WinoOutRide& st) {
+    const int slices = (p.Cout + 63) / 64;
+    const WinoTile w = td_wino_unit_tile(p, slices, wv);
+    const int c0 = w.sl * 64 + (int)(threadIdx.x & 63);
+    const unsigned coff = c0 < p.Cout ? (unsigned)c0 * 4u : TD_BUF_OOB;
+    st.wv = wv;
+    const unsigned plane = (unsigned)p.TP * (unsigned)p.Cout * 4u;
+    const TdBuf mb = td_make_buf(p.Mb, 36u * plane);
+    const unsigned moff = (unsigned)w.tl * (unsigned)p.Cout * 4u;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) st.m[c][r] = td_buf_ld1(mb, coff, (unsigned)(r * 6 + c) * plane + moff);
+    const TdBuf bbuf = td_make_buf(p.bias, (unsigned)p.Cout * 4u);
+    st.b = td_buf_ld1(bbuf, coff, 0u);
+}
+TD_DEV void td_wino4_out_finish(const WinoArgs& p, const WinoOutRide& st) {
+    const int slices = (p.Cout + 63) / 64;
+    const WinoTile w = td_wino_unit_tile(p, slices, st.wv);
+    const unsigned pixn = (unsigned)p.H * (unsigned)p.W;
+    const TdBuf outb = td_make_buf(p.out, pixn * (unsigned)p.Cout * 4u);
+    const TdBuf resb = td_make_buf(p.resid, p.resid ? pixn * (unsigned)p.Cout * 4u : 0u);
+    const float slope = td_act_slope(p.act);
+    const int c0 = w.sl * 64 + (int)(threadIdx.x & 63);
+    const unsigned coff = c0 < p.Cout ? (unsigned)c0 * 4u : TD_BUF_OOB;
+    float rs[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int y = w.py + p.dil * (4 * w.ty + r), x = w.px + p.dil * (4 * w.tx + c);
+            const bool ok = y < p.H && x < p.W;
+            rs[r][c] = td_buf_ld1(resb, ok ? coff : TD_BUF_OOB, ok ? ((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.Cout * 4u : 0u);
+        }
+    float sm[4][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float col[4];
+        td_wino4_at_t(st.m[c], col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[r][c] = col[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float o4[4];
+        td_wino4_at_t(sm[r], o4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int y = w.py + p.dil * (4 * w.ty + r), x = w.px + p.dil * (4 * w.tx + c);
+            const bool ok = y < p.H && x < p.W;
+            float o = o4[c] + st.b;
+            o = o + rs[r][c];
+            td_buf_st1(outb, ok ? coff : TD_BUF_OOB, ok ? ((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.Cout * 4u : 0u, td_activate(o, slope));
+        }
+    }
+}
+
 template <int VW>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
     const int slices = (p.C + 64 * VW - 1) / (64 * VW);
