@@ -83,6 +83,9 @@ typedef struct tdnet_opts {
                                 64 = with bits 1 and 8: the transforms of layer4 ride INSIDE the other chain's GEMM launches, in the instruction
                                      stream of its matrix waves, everything on one stream (td_gemm_dma.h TT = 1 / 2).  Measured: -4 %; the fp32
                                      MFMA leaves its SIMD no VALU issue to spare.  Opt-in experiment,
+                                128 = the cache-only attention chain of the NEXT frame (it needs only cached entries) is launched at the end of
+                                      this frame, beside the HBM-bound LayerNorm / head / classifier / upsample, assuming pos_id + 1 on an
+                                      untouched FIFO (checked at the next call; otherwise the chain is launched again as before),
                                 bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
     int32_t reserved[8];     /* must be 0                                                                                        */
 } tdnet_opts;

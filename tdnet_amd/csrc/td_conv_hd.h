@@ -46,7 +46,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     static_assert(NB == 1 || (NB == 2 && RH == 4 && NBUF == 2), "256-channel tiles: 256 rows, two LDS buffers");
     constexpr int NJ = 2 * NB;                                      // 32-column accumulators per wave
     constexpr int BM = G::BM, NW = G::NW, NPW = G::NPW, NTAPS = KS * KS;
-    static_assert(NBUF == 2 || NBUF == 3, "ring of 2 or 3 LDS buffers");
+    static_assert(NBUF >= 2 && NBUF <= 4, "ring of 2, 3 or 4 LDS buffers");
+    constexpr int INFLIGHT = (NBUF - 2) * G::NPW;                    // pieces of this wave that may still be in flight when the next step starts
     TD_DYN_LDS(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
@@ -92,21 +93,23 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     // step s (NSLOT slots of four MFMAs), where the SIMD's other wave and the wave's own queued MFMAs cover them.
     int l_step = 0, l_chunk = 0, l_tap = 0;
     unsigned i_delta = 0u, i_wsoff = 0u;                              // of the step being issued
+    bool i_live = true;                                               // false past the last step: the ring's surplus issues fetch nothing (zero fill)
     auto issue_begin = [&]() {
+        i_live = l_step < p.nsteps;
         const int ky = l_tap / KS;
         const int dy = ky * p.dil, dx = (l_tap - ky * KS) * p.dil;
         i_delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * 2u;
-        i_wsoff = (unsigned)(l_step < p.nsteps ? l_step : p.nsteps - 1) * w_step_bytes;   // past the last step: a harmless surplus tile
+        i_wsoff = (unsigned)(i_live ? l_step : 0) * w_step_bytes;
     };
     auto issue_piece = [&](int buf, int pc) {                         // pc: compile-time piece number of this wave, 0..NPW-1
         char* base = smem + buf * G::BUF_BYTES;
         if (pc < 4) {
-            const bool ok = ((a_taps[pc] >> l_tap) & 1u) != 0u;
+            const bool ok = ((a_taps[pc] >> l_tap) & 1u) != 0u && i_live;
             td_buf_ld16_lds(in_buf, base + (wave + NW * pc) * 1024, ok ? a_off[pc] + i_delta : TD_BUF_OOB, 0u);
         } else {
             int pb = wave + NW * (pc - 4);
             if (pb >= G::NPB) pb -= NW;
-            td_buf_ld16_lds(w_buf, base + G::A_BYTES + pb * 1024, b_off[pc - 4], i_wsoff);
+            td_buf_ld16_lds(w_buf, base + G::A_BYTES + pb * 1024, i_live ? b_off[pc - 4] : TD_BUF_OOB, i_wsoff);
         }
     };
     auto issue_end = [&]() {
@@ -177,16 +180,16 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     // ---- ring: the DMA of step s + NBUF - 1 is issued during the MFMAs of step s; a counted wait leaves the newest step(s) in
     // flight.  Order per step: compute (+ issue), wait for the NEXT step's pieces (this wave's), barrier (everyone's have landed, and
     // everyone is done reading the buffer the next issue overwrites).
-    issue_all(0);
-    if (NBUF == 3) issue_all(1);
-    if (NBUF == 3) TD_WAIT_VM_PIECES(NPW); else TD_WAIT_VM_PIECES(0);
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) issue_all(b);
+    TD_WAIT_VM_PIECES(INFLIGHT);
     TD_BARRIER_RAW();
     int cb = 0, ib = NBUF - 1;                                        // buffer being multiplied / buffer being filled
     for (int step = 0; step < p.nsteps; ++step) {
         TD_DMA_STAMP(0);
         compute(cb, ib);
         TD_DMA_STAMP(1);
-        if (NBUF == 3) TD_WAIT_VM_PIECES(NPW); else TD_WAIT_VM_PIECES(0);
+        TD_WAIT_VM_PIECES(INFLIGHT);
         TD_DMA_STAMP(2);
         TD_BARRIER_RAW();
         TD_DMA_STAMP(3);
@@ -216,6 +219,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
 // measured on MI355X at 1024x2048 (profiles/r03d_*): 256 x 256 1070 TFLOP/s, 256 x 128 950, the register-staged 128 x 128 930; the
 // smaller ones estimated from their bytes per MFMA.  At 720x960 (10800 pixels) this sends the 128-channel layers to the old 64 x 128
 // tiles (169 workgroups instead of 57), the 256-channel ones to 128 x 128 (170) and the 512-channel ones to 192 x 128 (228).
+constexpr int TD_CUS = 256;                                            // MI355X: 8 XCDs x 32 CUs
 static inline int conv_dma_pick_rh(long M, int Cout, bool allow256 = true) {
     static const struct { int code, rows, nb; double eff; } cand[5] = {{4, 4, 1, 1.00}, {3, 3, 1, 0.95}, {2, 2, 1, 0.85}, {8, 4, 2, 1.13}, {0, 1, 1, 0.60}};
     int best = 4;
@@ -224,7 +228,7 @@ static inline int conv_dma_pick_rh(long M, int Cout, bool allow256 = true) {
         if (cand[i].nb == 2 && (!allow256 || Cout % 256)) continue;
         const long tn = (Cout + 128 * cand[i].nb - 1) / (128 * cand[i].nb);
         const long tiles = ((M + 64 * cand[i].rows - 1) / (64 * cand[i].rows)) * tn;
-        const double cost = (double)((tiles + 255) / 256) * cand[i].rows * cand[i].nb / cand[i].eff;
+        const double cost = (double)((tiles + TD_CUS - 1) / TD_CUS) * cand[i].rows * cand[i].nb / cand[i].eff;
         if (i == 0 || cost < best_cost) { best_cost = cost; best = cand[i].code; }
     }
     return best;
@@ -244,11 +248,16 @@ static inline void conv_launch_dma_t(const ConvArgs& a, int KS, bool out16, hipS
     else if (out16) TD_LAUNCH((k_conv_dma_h<RH, 1, true, NBUF, NB>), dim3(grid), dim3(128 * RH), lds, s, a);
     else TD_LAUNCH((k_conv_dma_h<RH, 1, false, NBUF, NB>), dim3(grid), dim3(128 * RH), lds, s, a);
 }
-// rh: 4 / 3 (three LDS buffers, one workgroup per CU), 2 (two buffers, two per CU), 8 = 256 rows x 256 channels (two buffers, one per CU)
+// rh: 4 / 3 (three LDS buffers, one workgroup per CU), 2 (128 x 128), 8 = 256 rows x 256 channels (two buffers, one per CU).
+// 128 x 128 has two forms: two buffers (64 KB: two workgroups per CU cover each other's waits) when the grid has more workgroups than
+// CUs, and a ring of FOUR (128 KB) when it has not -- a lone workgroup of four waves issues the last piece of step s + 1 at the end of
+// step s and then waits for it: every step paid a full memory latency (measured at 720x960, 256 channels, 170 workgroups: 36 steps in
+// 35.6 us = 1 us per step for 0.25 us of MFMAs).  rh = 5 / 6 force the two- / four-buffer form (probes and tests).
 static inline void conv_launch_dma(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
     a.tiles_n = a.CoutPad / (rh == 8 ? 256 : 128);
     if (rh == 8) conv_launch_dma_t<4, 2, 2>(a, KS, out16, s);
     else if (rh == 4) conv_launch_dma_t<4, 3, 1>(a, KS, out16, s);
     else if (rh == 3) conv_launch_dma_t<3, 3, 1>(a, KS, out16, s);
+    else if (rh == 6 || (rh == 2 && (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS)) conv_launch_dma_t<2, 4, 1>(a, KS, out16, s);
     else conv_launch_dma_t<2, 2, 1>(a, KS, out16, s);
 }

@@ -164,7 +164,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.stagger = d.stagger < 0 ? 0 : d.stagger > 64 ? 64 : d.stagger;
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
-    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0x7f;
+    d.overlap = d.overlap < 0 ? 0 : d.overlap & 0xff;
     if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
     return d;
 }
@@ -286,6 +286,14 @@ struct tdnet {
     float *rowpart = nullptr, *pooled = nullptr, *ppmfeat = nullptr, *z = nullptr;
     float *v_cur = nullptr, *q1 = nullptr, *q_cur = nullptr, *k1 = nullptr;
     float *vp = nullptr, *chain_a = nullptr, *chain_b = nullptr, *feat = nullptr;
+    // overlap bit 128: the cache-only chain of the NEXT frame is launched at the end of this one (beside the HBM-bound LayerNorm / head /
+    // classifier / upsample instead of beside the next frame's stem and layer1): a second V' buffer, and what the launch assumed
+    float* vp2 = nullptr;
+    float* vp_read = nullptr;                                          // the V' the final attention of the current frame reads
+    bool pre_valid = false;                                            // a chain was pre-launched ...
+    int pre_pos = -1;                                                  // ... for this pos_id ...
+    unsigned pre_epoch = 0, fifo_epoch = 0;                            // ... with the FIFO as it was at this epoch (reset / external pushes bump it)
+    float* pre_vp = nullptr;
     float *ln_part = nullptr, *ln_mean = nullptr, *ln_rstd = nullptr, *ln = nullptr;
     float *headmid = nullptr, *lowres = nullptr, *stage_tmp = nullptr, *logits_tmp = nullptr;
     float *wino_v = nullptr, *wino_m = nullptr;                        // Winograd workspaces [16][T][Cin] / [16][T][Cout]
@@ -461,7 +469,7 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     TD_ON_DEVICE(n);
     for (auto& p : n->paths) free_path(p);
     for (float* q : {n->img4, n->s1, n->s1b, n->bx, n->bt, n->br, n->bu, n->rowpart, n->pooled, n->ppmfeat, n->z, n->v_cur, n->q1, n->q_cur,
-                     n->k1, n->vp, n->chain_a, n->chain_b, n->feat, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, n->headmid,
+                     n->k1, n->vp, n->vp2, n->chain_a, n->chain_b, n->feat, n->ln_part, n->ln_mean, n->ln_rstd, n->ln, n->headmid,
                      n->lowres, n->stage_tmp, n->logits_tmp, n->wino_v, n->wino_m})
         if (q) hipFree(q);
     for (auto& s : n->slots) { if (s.q) hipFree(s.q); if (s.k) hipFree(s.k); if (s.v) hipFree(s.v); }
@@ -613,6 +621,11 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->v_cur, hw * n->DV) || dev_alloc(&n->q1, hw * 64) || dev_alloc(&n->q_cur, hw * 64)) return -1;
     if (dev_alloc(&n->k1, lk * 64) || dev_alloc(&n->vp, (size_t)attn_vp_rows((int)lk) * n->DV) || dev_alloc(&n->chain_a, lk * n->DV) || dev_alloc(&n->chain_b, lk * n->DV)) return -1;
     TD_HIP(hipMemset(n->vp, 0, (size_t)attn_vp_rows((int)lk) * n->DV * sizeof(float)));   // padding rows of V' stay zero (td_attn.h load_v)
+    if (n->opts.overlap & 128) {
+        if (dev_alloc(&n->vp2, (size_t)attn_vp_rows((int)lk) * n->DV)) return -1;
+        TD_HIP(hipMemset(n->vp2, 0, (size_t)attn_vp_rows((int)lk) * n->DV * sizeof(float)));
+    }
+    n->vp_read = n->vp;
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
     if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
@@ -1049,25 +1062,32 @@ static void fifo_commit(tdnet* n, int slot) {
     n->last_slot = slot;
 }
 
-static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s) {
+// vp: the V' buffer the chain ends in (the final attention of the frame it belongs to reads it); e0, e1, e2: the cache slots that frame
+// sees as its FIFO, oldest first (td2: e0 only).
+static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s, float* vp, int e0, int e1, int e2) {
     const int DV = n->DV;
     hipStream_t c = n->side;
     TD_HIP(hipEventRecord(n->ev_fork, s));
     TD_HIP(hipStreamWaitEvent(c, n->ev_fork, 0));
     if (n->P == 4) {
-        const CacheSlot &c0 = n->slots[n->fifo[0]], &c1 = n->slots[n->fifo[1]], &c2 = n->slots[n->fifo[2]];
-        TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, n->vp, c));
+        const CacheSlot &c0 = n->slots[e0], &c1 = n->slots[e1], &c2 = n->slots[e2];
+        TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, vp, c));
         // the cached-frame steps have Lq = Lk (64 query tiles at 1024x2048): two channel slices per launch unless fusion bit 512 says no
         const bool sl = !(n->opts.fusion & 512) && DV == 512 && n->Lk <= 8192;
-        if (run_attention(n, c1.q, c0.k, n->vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention, nullptr, nullptr, sl)) return -1;   // v2 + V[1]
-        TD_TRY(run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, n->vp, c));
-        if (run_attention(n, c2.q, c1.k, n->vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention, nullptr, nullptr, sl)) return -1;   // v3 + V[2]
-        TD_TRY(run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, n->vp, c));                                              // (v3 + V[2]) W^T
+        if (run_attention(n, c1.q, c0.k, vp, L.atn[0].d_bias, c1.v, n->Lk, n->Lk, DV, n->chain_a, c, n->opts.attention, nullptr, nullptr, sl)) return -1;   // v2 + V[1]
+        TD_TRY(run_conv(n, L.atn[1].fc, n->chain_a, 1, n->Lk, nullptr, vp, c));
+        if (run_attention(n, c2.q, c1.k, vp, L.atn[1].d_bias, c2.v, n->Lk, n->Lk, DV, n->chain_b, c, n->opts.attention, nullptr, nullptr, sl)) return -1;   // v3 + V[2]
+        TD_TRY(run_conv(n, L.atn[2].fc, n->chain_b, 1, n->Lk, nullptr, vp, c));                                              // (v3 + V[2]) W^T
     } else {
-        TD_TRY(run_conv(n, L.atn[0].fc, n->slots[n->fifo[0]].v, 1, n->Lk, nullptr, n->vp, c));
+        TD_TRY(run_conv(n, L.atn[0].fc, n->slots[e0].v, 1, n->Lk, nullptr, vp, c));
     }
     TD_HIP(hipEventRecord(n->ev_join, c));
     return 0;
+}
+// the chain of the frame that is about to be propagated, against the FIFO as it stands
+static int launch_chain_now(tdnet* n, PathLayers& L, hipStream_t s) {
+    n->vp_read = n->vp;
+    return launch_chain(n, L, s, n->vp, n->fifo[0], n->P == 4 ? n->fifo[1] : -1, n->P == 4 ? n->fifo[2] : -1);
 }
 
 static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int W, float* out, int ny, int cy, hipStream_t s);
@@ -1298,7 +1318,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
 }
 
 // chain_launched: launch_chain() already ran for this frame (it read the FIFO as it is now)
-static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
+static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s, int prelaunch_pos = -1) {
     const int DV = n->DV;
     const float* feat = n->v_cur;
     int stats_nstr = 0;
@@ -1307,13 +1327,28 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
         const CacheSlot& ck = n->slots[n->fifo[n->FIFO - 1]];
         const AtnLayer& A = L.atn[n->P == 4 ? 2 : 0];                   // td4_psp18.py:147 / td2_psp50.py:120
         stats_nstr = (n->opts.fusion & 2) ? attn_strips(n->Lq, DV) : 0;                                         // LayerNorm strip statistics from the epilogue
-        if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention,
+        if (run_attention(n, n->q_cur, ck.k, n->vp_read, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention,
                           stats_nstr ? n->ln_part : nullptr)) return -1;                                                  // v4 + v_cur
         feat = n->feat;
     } else {
         // warm-up (td4_psp18.py:142-143): feat = v_cur; keep a copy so the "feat" stage is well defined
         TD_HIP(hipMemcpyAsync(n->feat, n->v_cur, (size_t)n->Lq * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
         feat = n->feat;
+    }
+    // FIFO push (td4_psp18.py:153-154, :123-134): host bookkeeping only -- the entry's data was written by encode_frame
+    {
+        const int slot = n->pending_slot;
+        n->pending_slot = -1;
+        fifo_commit(n, slot);
+    }
+    // overlap bit 128: the NEXT frame's cache-only chain starts here, when this frame's final attention is done -- beside the HBM-bound
+    // rest of this frame (matrix pipes idle) instead of beside the next frame's stem and layer1, which it slowed by 20-50 %.  It assumes
+    // the next call is pos_id + 1 on an untouched FIFO; forward_lowres checks and falls back to launching the chain itself.
+    n->pre_valid = false;
+    if (prelaunch_pos >= 0 && (n->opts.overlap & 128) && n->vp2 && (int)n->fifo.size() >= n->FIFO) {
+        float* target = n->vp_read == n->vp ? n->vp2 : n->vp;
+        if (launch_chain(n, n->paths[prelaunch_pos], s, target, n->fifo[0], n->P == 4 ? n->fifo[1] : -1, n->P == 4 ? n->fifo[2] : -1)) return -1;
+        n->pre_valid = true; n->pre_pos = prelaunch_pos; n->pre_epoch = n->fifo_epoch; n->pre_vp = target;
     }
     // fusion bit 4: the normalised map is never written -- the head's Winograd input transform normalises while it reads `feat`
     const bool ln_in_head = (n->opts.fusion & 4) && L.head3.wino;
@@ -1326,10 +1361,6 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
     } else
     TD_TRY(run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s));
     TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
-    // FIFO push (td4_psp18.py:153-154, :123-134)
-    const int slot = n->pending_slot;
-    n->pending_slot = -1;
-    fifo_commit(n, slot);
     return n->failed ? -1 : 0;
 }
 
@@ -1362,10 +1393,14 @@ static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream
     n->nrec = 0;
     n->failed = false;
     const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
-    if (steady && launch_chain(n, L, s)) return -1;                    // overlaps the backbone below
+    if (steady) {
+        if (n->pre_valid && n->pre_pos == pos_id && n->pre_epoch == n->fifo_epoch) n->vp_read = n->pre_vp;   // launched at the end of the previous frame
+        else if (launch_chain_now(n, L, s)) return -1;                 // overlaps the backbone below
+    }
+    n->pre_valid = false;
     if (encode_frame(n, L, img, s)) return -1;
     if (n->cfg.model == 1) return 0;
-    return finish_frame(n, L, steady, s);
+    return finish_frame(n, L, steady, s, (pos_id + 1) % n->P);
 }
 
 extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* logits, void* stream) {
@@ -1419,7 +1454,8 @@ static int propagate_lowres(tdnet* n, hipStream_t s) {
     if (n->pending_slot < 0) return td_fail("tdnet_propagate: no encoded frame (call tdnet_encode first)");
     PathLayers& L = n->paths[n->pending_pos];
     const bool steady = (int)n->fifo.size() >= n->FIFO;
-    if ((steady && launch_chain(n, L, s)) || finish_frame(n, L, steady, s)) { rejoin_streams(n, s); return -1; }
+    n->pre_valid = false;
+    if ((steady && launch_chain_now(n, L, s)) || finish_frame(n, L, steady, s)) { rejoin_streams(n, s); return -1; }
     return 0;
 }
 extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
@@ -1472,10 +1508,13 @@ extern "C" int tdnet_cache_push(tdnet_t* n, const float* q, const float* k, cons
     TD_HIP(hipMemcpyAsync(c.k, k, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     TD_HIP(hipMemcpyAsync(c.v, v, (size_t)n->Lk * n->DV * sizeof(float), hipMemcpyDeviceToDevice, s));
     fifo_commit(n, slot);
+    n->fifo_epoch++;                                                   // the FIFO changed behind a pre-launched chain's back
     return 0;
 }
 extern "C" int tdnet_reset(tdnet_t* n) {
     if (!n) return td_fail("tdnet_reset: null handle");
+    n->fifo_epoch++;
+    n->pre_valid = false;
     n->fifo.clear();
     n->last_slot = -1;
     n->pending_slot = n->pending_pos = -1;
@@ -1626,10 +1665,11 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
                                      int KS, int stride, int dil, const float* resid, int act, int tile, float* out, void* stream) {
     if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_f16io: KS must be 1 or 3");
     if (Cin % 64) return td_fail("tdnet_op_conv2d_f16io: Cin must be a multiple of 64");
-    // tile 16 / 17 / 18 / 19: the LDS-DMA kernel with 128 / 192 / 256-row tiles (td_conv_hd.h); -1: the heuristic (DMA kernel where it applies)
-    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : 0;           // 19: the 256 x 256 tile (Cout % 256 == 0)
+    // tile 16 / 17 / 18 / 19: the LDS-DMA kernel with 128 / 192 / 256-row tiles, 256 x 256 (td_conv_hd.h); 20 / 21: 128 rows on a ring of
+    // four / two LDS buffers whatever the grid (16 chooses by the grid); -1: the heuristic (DMA kernel where it applies)
+    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : tile == 20 ? 6 : tile == 21 ? 5 : 0;   // 19: 256 x 256 (Cout % 256 == 0); 20 / 21: 128 x 128 on four / two LDS buffers
     if (force_rh) tile = CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..18", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..21", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;

@@ -220,14 +220,14 @@ def test_fp16_storage_conv_attention_and_pipeline(lib, golden_dir):
 
 
 def test_fp16_conv_on_lds_dma(lib):
-    """td_conv_hd.h k_conv_dma_h: the fp16-map convs fed by LDS-DMA -- 256 / 192 / 128-row tiles (tile codes 18 / 17 / 16; 3- and
+    """td_conv_hd.h k_conv_dma_h: the fp16-map convs fed by LDS-DMA -- 256 / 192 / 128-row tiles (tile codes 18 / 17 / 16; 4-, 3- and
     2-buffer rings), the XOR-swizzled activation image and the piece -> wave assignment (RH = 3 repeats two pieces), 3x3 with dilation /
     stride / padding taps on every side, 1x1 with stride, ragged M (rows past the map read zeros) and Cout not a multiple of 128,
     1 .. 27 K steps, residual and activations; then the heuristic's own choice."""
     opcheck.conv_f16io(lib, MEM, 13, 21, 128, 256, 3, 1, 1, 1, True, 19)             # the 256 x 256 tile: a wave multiplies two 64-slot weight groups
     opcheck.conv_f16io(lib, MEM, 20, 23, 64, 512, 3, 1, 2, 2, True, 19)              # two M tiles (ragged), two N tiles
     opcheck.conv_f16io(lib, MEM, 9, 11, 192, 256, 1, 2, 1, 0, False, 19)
-    for tile in (18, 17, 16, None):
+    for tile in (18, 17, 16, 20, 21, None):                                           # 20 / 21: 128 rows on a ring of four / two buffers
         opcheck.conv_f16io(lib, MEM, 13, 21, 128, 160, 3, 1, 1, 1, True, tile)       # ragged M and N, two N tiles
         opcheck.conv_f16io(lib, MEM, 7, 9, 64, 128, 1, 1, 1, 0, False, tile)         # a single K step
         opcheck.conv_f16io(lib, MEM, 9, 11, 192, 130, 1, 2, 1, 2, True, tile)        # 1x1 stride 2, three steps, 130 channels
@@ -311,14 +311,15 @@ def test_winograd_chunked_low_register_transforms(lib):
         opcheck.conv(lib, MEM, 13, 21, 96, 128, 3, 1, 2, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 9 | 16, "gemm_persistent": cap})
 
 
-@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 1}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
-                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td4", "resnet18", {"overlap": 1, "winograd": 4}),
-                                          ("td4", "resnet18", {"overlap": 1 | 4 | 32}), ("td4", "resnet18", {"overlap": 1 | 8 | 32}),
-                                          ("td4", "resnet18", {"overlap": 1 | 8 | 64 | 32}), ("td4", "resnet34", {"overlap": 1 | 8 | 64}),
-                                          ("td2", "resnet18", {"overlap": 1 | 8 | 64 | 32, "gemm_persistent": 5})])
+@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 41}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
+                                          ("td2", "resnet18", {"overlap": 3 | 32 | 4}), ("td4", "resnet18", {"overlap": 1 | 8 | 64 | 32}),
+                                          ("td2", "resnet18", {"overlap": 1 | 8 | 64, "gemm_persistent": 5}), ("td4", "resnet18", {"overlap": 41 | 128}),
+                                          ("td2", "resnet18", {"overlap": 128})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
-    """tdnet_opts.overlap bit 1: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows)
-    against the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd."""
+    """tdnet_opts.overlap: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows), 1 / 2 /
+    4 channels per lane in the transforms, the LDS-DMA-fed GEMM (bit 8; 41 = the library default), the staggered start (bit 4) and the
+    single-stream schedule with the transforms riding in the GEMM's matrix waves (bit 64, also with several tiles per workgroup) against
+    the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd."""
     H, W = 33, 65
     spec = arch.model_spec(name, 19, bb)
     h, w = arch.feat_size(H), arch.feat_size(W)
@@ -360,6 +361,41 @@ def test_activation_propagates_non_finite_values_like_the_reference(lib):
             assert np.isfinite(np.delete(out[clean], 7, axis=1)).all(), (KS, o, act)
             col = out[clean][:, 7]
             assert (col == 0).all() if act == 1 else np.isneginf(col).all(), (KS, o, act, col[:4])
+
+
+def test_prelaunched_chain_falls_back_when_the_next_call_is_not_the_predicted_one(lib):
+    """tdnet_opts.overlap bit 128: the cache-only attention chain of frame t + 1 is launched at the end of frame t for pos_id + 1 on
+    the FIFO as it stands.  Any other next call -- a repeated or skipped pos_id, a reset, a split encode / propagate, an entry pushed
+    from outside -- must give exactly what a handle without the pre-launch gives (bit for bit: same kernels, same data)."""
+    H, W = 33, 65
+    spec = arch.model_spec("td4", 19, "resnet18")
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    sd = weights.synth_state_dict(spec, h, w, 0)
+    frames = weights.synth_video(H, W, 12, seed=5)
+    a = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"overlap": 41})
+    b = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"overlap": 41 | 128})
+    a.load_state_dict(sd); b.load_state_dict(sd)
+    lk, dk, dv = a.cache_dims()
+    seq = [0, 1, 2, 3, 0, 2, 2, 3, 0, 1, "reset", 0, 1, 2, 3, "split", 1, "push", 2, 3]
+    t = 0
+    for step in seq:
+        if step == "reset":
+            a.reset(); b.reset()
+            continue
+        if step == "push":                                                        # an entry arrives from a peer between two frames
+            q, k, v = (np.random.default_rng(t).standard_normal(s_).astype(np.float32) for s_ in ((lk, dk), (lk, dk), (lk, dv)))
+            a.cache_push(q, k, v); b.cache_push(q, k, v)
+            continue
+        x = frames[t % len(frames)]
+        oa, ob = np.zeros((1, 19, H, W), np.float32), np.zeros((1, 19, H, W), np.float32)
+        if step == "split":
+            a.encode(x, 0); a.propagate(oa)
+            b.encode(x, 0); b.propagate(ob)
+        else:
+            a.forward(x, step, oa); b.forward(x, step, ob)
+        assert np.array_equal(oa, ob), (t, step, float(np.abs(oa - ob).max()))
+        t += 1
+    a.close(); b.close()
 
 
 def test_persistent_gemm_multi_tile(lib):
