@@ -21,13 +21,17 @@
 #pragma once
 #include "td_conv_h.h"
 
-template <int RH, int NB = 1>
+// MI = 32-row accumulator blocks per wave: 2 = waves of 64 x 64 (2 RH waves), 1 = waves of 32 x 64 (4 RH waves: two per SIMD at RH = 2,
+// for the grids that put a single workgroup on a CU -- a wave's DMA issue is then covered by the other wave of its SIMD).
+template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
-    static constexpr int BM = 64 * RH, BN = 128 * NB, NW = 2 * RH;
+    static constexpr int BM = 64 * RH, BN = 128 * NB, NW = 2 * RH * (2 / MI);
     static constexpr int A_BYTES = BM * 128, B_BYTES = 8 * BN * 16, BUF_BYTES = A_BYTES + B_BYTES;
     static constexpr int NPA = BM / 8, NPB = 16 * NB;               // 1 KB DMA pieces per step: A = 8 pixels x 128 B, B = 64 packed weight slots
-    static constexpr int NPW = (NPA + NPB + NW - 1) / NW;           // pieces per wave and step (RH = 3: 42 for 40, two waves repeat a piece)
-    static_assert(NPA % NW == 0 && NPA / NW == 4, "every wave stages four A pieces per step");
+    static constexpr int NA = NPA / NW, NBW = (NPB + NW - 1) / NW;   // A / B pieces per wave and step
+    static constexpr int NPW = NA + NBW;                             // (RH = 3: 42 for 40, two waves repeat a B piece)
+    static_assert(MI == 1 || MI == 2, "waves of 32 or 64 rows");
+    static_assert(NPA % NW == 0, "every wave stages the same number of A pieces per step");
 };
 
 // NB = 2: 256 output channels per tile (a wave multiplies 64 rows x 128 channels = two 64-slot groups of the packed weights): 64 KB
@@ -40,10 +44,11 @@ struct ConvDmaGeom {
 #else
 #define TD_DMA_STAMP(slot) ((void)0)
 #endif
-template <int RH, int KS, bool OUT16, int NBUF, int NB = 1>
-TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
-    using G = ConvDmaGeom<RH, NB>;
-    static_assert(NB == 1 || (NB == 2 && RH == 4 && NBUF == 2), "256-channel tiles: 256 rows, two LDS buffers");
+template <int RH, int KS, bool OUT16, int NBUF, int NB = 1, int MI = 2>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
+    using G = ConvDmaGeom<RH, NB, MI>;
+    static_assert(NB == 1 || (NB == 2 && RH == 4 && NBUF == 2 && MI == 2), "256-channel tiles: 256 rows, two LDS buffers");
+    constexpr int NA = G::NA;
     constexpr int NJ = 2 * NB;                                      // 32-column accumulators per wave
     constexpr int BM = G::BM, NW = G::NW, NPW = G::NPW, NTAPS = KS * KS;
     static_assert(NBUF >= 2 && NBUF <= 4, "ring of 2, 3 or 4 LDS buffers");
@@ -59,9 +64,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
 
     // ---- DMA geometry: A piece j of this wave = rows 8 (wave + NW j) .. + 7; lane l -> row + (l >> 3), LDS slot l & 7, which holds
     // the channels 8 kq .. 8 kq + 7 of the chunk with kq = slot ^ ((row >> 1) & 7) ------------------------------------------------
-    unsigned a_off[4], a_taps[4];
+    unsigned a_off[NA], a_taps[NA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NA; ++j) {
         const int row = 8 * (wave + NW * j) + (lane >> 3);
         const int m = m0 + row;
         const int oy = m / p.Wo, ox = m - oy * p.Wo;
@@ -79,9 +84,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
     const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
     // B piece pb = (BN / 64) kq + q (64 consecutive packed slots of k-group kq); this wave stages pb = wave + NW jb
-    unsigned b_off[NPW - 4];
+    unsigned b_off[NPW - NA];
 #pragma unroll
-    for (int jb = 0; jb < NPW - 4; ++jb) {
+    for (int jb = 0; jb < NPW - NA; ++jb) {
         int pb = wave + NW * jb;
         if (pb >= G::NPB) pb -= NW;                                  // RH = 3: the two surplus slots repeat a piece (same bytes, same place)
         b_off[jb] = (unsigned)((pb / (2 * NB)) * p.CoutPad + n0 + (pb % (2 * NB)) * 64 + lane) * 16u;
@@ -103,13 +108,13 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     };
     auto issue_piece = [&](int buf, int pc) {                         // pc: compile-time piece number of this wave, 0..NPW-1
         char* base = smem + buf * G::BUF_BYTES;
-        if (pc < 4) {
+        if (pc < NA) {
             const bool ok = ((a_taps[pc] >> l_tap) & 1u) != 0u && i_live;
             td_buf_ld16_lds(in_buf, base + (wave + NW * pc) * 1024, ok ? a_off[pc] + i_delta : TD_BUF_OOB, 0u);
         } else {
-            int pb = wave + NW * (pc - 4);
+            int pb = wave + NW * (pc - NA);
             if (pb >= G::NPB) pb -= NW;
-            td_buf_ld16_lds(w_buf, base + G::A_BYTES + pb * 1024, i_live ? b_off[pc - 4] : TD_BUF_OOB, i_wsoff);
+            td_buf_ld16_lds(w_buf, base + G::A_BYTES + pb * 1024, i_live ? b_off[pc - NA] : TD_BUF_OOB, i_wsoff);
         }
     };
     auto issue_end = [&]() {
@@ -124,19 +129,19 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     };
 
     // ---- MFMA fragment addresses (bytes inside a buffer) -----------------------------------------------------------------
-    unsigned a_rd[2][4];                                              // [i][g]: row wm 64 + 32 i + l31, k-group 2 g + half, swizzled slot
+    unsigned a_rd[MI][4];                                             // [i][g]: row wm 32 MI + 32 i + l31, k-group 2 g + half, swizzled slot
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + 32 * i + l31;
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm * 32 * MI + 32 * i + l31;
 #pragma unroll
         for (int g = 0; g < 4; ++g) a_rd[i][g] = (unsigned)(row * 128 + (((2 * g + half) ^ ((row >> 1) & 7)) << 4));
     }
     constexpr int BKQ = G::BN * 16;                                   // bytes per k-group of the weight image
     const unsigned b_rd = (unsigned)(G::A_BYTES + half * BKQ + (wn * 64 * NB + l31) * 16);
 
-    f32x16 acc[2][NJ];                                                // [i][2 sb + nt]: rows 32 i .., packed slots wn 64 NB + 64 sb + 32 nt ..
+    f32x16 acc[MI][NJ];                                               // [i][2 sb + nt]: rows 32 i .., packed slots wn 64 NB + 64 sb + 32 nt ..
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -146,31 +151,31 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     // One piece per group of MFMAs (8 groups per step; 256-channel tiles: four MFMAs per group, two otherwise).  Measured with the
     // in-kernel stamps (profiles/r03g_*): issue phase 700-1200 -> 200 cycles per step, 256 x 256 tile 150 -> 140 us per launch; packing
     // the pieces into the first four groups instead changed nothing for that tile and cost the 128 x 128 one 3 %.
-    constexpr int NSLOT = 8;
+    constexpr int NSLOT = 4 * MI;
     auto compute = [&](int buf, int ibuf) {
         const char* base = smem + buf * G::BUF_BYTES;
-        f16x8 af[2][2], bf[2][NJ];
+        f16x8 af[2][MI], bf[2][NJ];
         issue_begin();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(base + a_rd[i][0]);
+        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(base + a_rd[i][0]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(base + b_rd + j * 512);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < 3) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f16x8*>(base + a_rd[i][g + 1]);
+                for (int i = 0; i < MI; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f16x8*>(base + a_rd[i][g + 1]);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f16x8*>(base + b_rd + (g + 1) * 2 * BKQ + j * 512);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(af[g & 1][i], bf[g & 1][j], acc[i][j]);
                 TD_SCHED_FENCE();
 #pragma unroll
                 for (int pc = 0; pc < NPW; ++pc)
-                    if (pc % NSLOT == 2 * g + i) issue_piece(ibuf, pc);
+                    if (pc % NSLOT == MI * g + i) issue_piece(ibuf, pc);
                 TD_SCHED_FENCE();
             }
         }
@@ -199,8 +204,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(128 * RH, 1) k_conv_dma_h(ConvArgs p) {
     TD_WAIT_VM_PIECES(0);                                             // the surplus pieces must not land in an LDS that has been handed on
 
     if constexpr (NB == 1) {
-        td_store_acc_h<2, 2, OUT16, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64, lane);
-    } else {
+        td_store_acc_h<MI, 2, OUT16, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    } else if constexpr (MI == 2) {
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) {                            // each 64-slot group is one wave-column of the weight packing: its own epilogue
             f32x16 part[2][2];
@@ -235,29 +240,34 @@ static inline int conv_dma_pick_rh(long M, int Cout, bool allow256 = true) {
 }
 static inline bool conv_dma_supports(int Cin, int Cout, int KS, ConvTile tile) {
     const ConvTileDims d = conv_tile_dims(tile);
-    return Cin % 64 == 0 && Cout >= 128 && d.BN == 128 && d.WGN == 2 && (KS == 1 || KS == 3);
+    return Cin % 64 == 0 && Cout >= 64 && d.BN == 128 && d.WGN == 2 && (KS == 1 || KS == 3);   // Cout < 128: a half-empty tile (the caller's tile decides)
 }
 
-template <int RH, int NBUF, int NB>
+template <int RH, int NBUF, int NB, int MI = 2>
 static inline void conv_launch_dma_t(const ConvArgs& a, int KS, bool out16, hipStream_t s) {
-    using G = ConvDmaGeom<RH, NB>;
+    using G = ConvDmaGeom<RH, NB, MI>;
     const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
     const int lds = NBUF * G::BUF_BYTES;
-    if (KS == 3 && out16) TD_LAUNCH((k_conv_dma_h<RH, 3, true, NBUF, NB>), dim3(grid), dim3(128 * RH), lds, s, a);
-    else if (KS == 3) TD_LAUNCH((k_conv_dma_h<RH, 3, false, NBUF, NB>), dim3(grid), dim3(128 * RH), lds, s, a);
-    else if (out16) TD_LAUNCH((k_conv_dma_h<RH, 1, true, NBUF, NB>), dim3(grid), dim3(128 * RH), lds, s, a);
-    else TD_LAUNCH((k_conv_dma_h<RH, 1, false, NBUF, NB>), dim3(grid), dim3(128 * RH), lds, s, a);
+    if (KS == 3 && out16) TD_LAUNCH((k_conv_dma_h<RH, 3, true, NBUF, NB, MI>), dim3(grid), dim3(64 * G::NW), lds, s, a);
+    else if (KS == 3) TD_LAUNCH((k_conv_dma_h<RH, 3, false, NBUF, NB, MI>), dim3(grid), dim3(64 * G::NW), lds, s, a);
+    else if (out16) TD_LAUNCH((k_conv_dma_h<RH, 1, true, NBUF, NB, MI>), dim3(grid), dim3(64 * G::NW), lds, s, a);
+    else TD_LAUNCH((k_conv_dma_h<RH, 1, false, NBUF, NB, MI>), dim3(grid), dim3(64 * G::NW), lds, s, a);
 }
 // rh: 4 / 3 (three LDS buffers, one workgroup per CU), 2 (128 x 128), 8 = 256 rows x 256 channels (two buffers, one per CU).
 // 128 x 128 has two forms: two buffers (64 KB: two workgroups per CU cover each other's waits) when the grid has more workgroups than
 // CUs, and a ring of FOUR (128 KB) when it has not -- a lone workgroup of four waves issues the last piece of step s + 1 at the end of
 // step s and then waits for it: every step paid a full memory latency (measured at 720x960, 256 channels, 170 workgroups: 36 steps in
-// 35.6 us = 1 us per step for 0.25 us of MFMAs).  rh = 5 / 6 force the two- / four-buffer form (probes and tests).
+// 35.6 us = 1 us per step for 0.25 us of MFMAs).  The four-buffer form runs as EIGHT waves of 32 x 64 (two per SIMD; 3-5 % faster than
+// four of 64 x 64, tools/conv_h_ring_probe.sh).  What paces a step then is the LDS port (tools/conv_dma_trace.hip: 1000 cycles per
+// step whatever the wave shape): the DMA writes 32 KB per step at 64 B/clk (tools/lds_dma_bw.hip) = 512 cycles and the fragment reads
+// take 64 KB at 256 B/clk = 256 more, against 512 cycles of MFMAs -- only the 256 x 256 tile (1024 + 768 against 2048) is MFMA-bound.
+// rh = 5 / 6 / 7 force two buffers / four buffers with four waves / four buffers with eight waves (probes and tests).
 static inline void conv_launch_dma(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
     a.tiles_n = a.CoutPad / (rh == 8 ? 256 : 128);
     if (rh == 8) conv_launch_dma_t<4, 2, 2>(a, KS, out16, s);
     else if (rh == 4) conv_launch_dma_t<4, 3, 1>(a, KS, out16, s);
     else if (rh == 3) conv_launch_dma_t<3, 3, 1>(a, KS, out16, s);
-    else if (rh == 6 || (rh == 2 && (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS)) conv_launch_dma_t<2, 4, 1>(a, KS, out16, s);
+    else if (rh == 7 || (rh == 2 && (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS)) conv_launch_dma_t<2, 4, 1, 1>(a, KS, out16, s);
+    else if (rh == 6) conv_launch_dma_t<2, 4, 1>(a, KS, out16, s);
     else conv_launch_dma_t<2, 2, 1>(a, KS, out16, s);
 }

@@ -369,6 +369,26 @@ TD_KERNEL void k_ln_apply(const float* __restrict__ x, const float* __restrict__
     }
 }
 
+// The same with an fp16 map out (tdnet_opts.precision = 1: the head's 3x3 conv reads fp16 through the LDS-DMA kernel).  The fp32 value
+// is the one k_ln_apply computes and the rounding is the one the conv kernel applies to an fp32 input when it stages it.
+TD_KERNEL void k_ln_apply_h(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                            const float* __restrict__ g, const float* __restrict__ b, _Float16* __restrict__ y, int HW, int C) {
+    const int CV = C >> 2;
+    const long total = (long)HW * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long p = i / CV;
+        const f32x4 v = td_ld4(x + (size_t)p * C + cv * 4);
+        const f32x4 m = td_ld4(mean + cv * 4), rs = td_ld4(rstd + cv * 4);
+        const f32x4 r = (v - m) * rs * g[p] + b[p];
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (_Float16)r[k];
+        *reinterpret_cast<f16x4*>(y + (size_t)p * C + cv * 4) = o;
+    }
+}
+
 // ---- classifier: 1x1 conv C -> NC (+bias) (td4_psp18.py:299), NHWC in, PLANAR [NC][HW] out ------------------------
 // One workgroup = 64 pixels x 4 channel quarters (one wave each): a lane streams its quarter of its pixel's channels (C bytes,
 // whole cache lines) against the LDS-resident weights, the four partial sums meet in LDS and are added in a fixed order.

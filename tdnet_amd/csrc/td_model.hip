@@ -787,11 +787,14 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             }
             // fp16 maps in, Cout >= 128: the LDS-DMA kernel (td_conv_hd.h), unless fusion bit 128 keeps the register-staged one
             auto dma = [&](ConvLayer& c) {
-                if (c.h16 && c.in16 && !c.stem && !(n->opts.fusion & 128) && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile))
+                if (c.h16 && c.in16 && !c.stem && !(n->opts.fusion & 128) && c.Cout >= 128 && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile))
                     c.rh = conv_dma_pick_rh(c.M_out, c.Cout, c.CoutPad % 256 == 0 && !(n->opts.fusion & 1024));
             };
             if (n->deep) dma(L.stem3);
             for (auto& B : L.blocks) { dma(B.c1); dma(B.c2); if (B.bott) dma(B.c3); if (B.has_ds) dma(B.ds); }
+            // The head's 3x3 conv (d_v -> d_v / 4 channels; >= 128 for td4): LayerNorm writes its map as fp16 -- the rounding the conv
+            // applied to the fp32 map while staging it -- and the conv runs on the LDS-DMA kernel (1024x2048: 77 -> 46 us).
+            if (n->cfg.model != 1 && L.head3.h16 && !L.head3.wino) { L.head3.in16 = true; dma(L.head3); if (!L.head3.rh) L.head3.in16 = false; }
         }
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
@@ -972,7 +975,7 @@ static int run_attention(tdnet* n, const float* q, const float* k, const float* 
 // wrote them: stats_nstr > 0 strips of 32 rows), their exact combination, and the normalisation (skipped when y == nullptr: the
 // head's Winograd input transform applies it on the fly, run_conv's LnFuse).
 static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* g, const float* b, float* part, float* mean,
-                          float* rstd, float* y, hipStream_t s, int stats_nstr = 0) {
+                          float* rstd, float* y, hipStream_t s, int stats_nstr = 0, bool y16 = false) {
     const int CV = C / 4, threads = CV > 256 ? CV : 256, rows = threads / CV;                   // C = 2048 (td4 on ResNet-50): 512 threads, one row each
     int nstr = stats_nstr, per = 32;
     prof_begin(n, 2, false, 0, s);
@@ -983,7 +986,8 @@ static void run_layernorm(tdnet* n, const float* x, int HW, int C, const float* 
         TD_LAUNCH(k_ln_stats, dim3(nstr), dim3(threads), (rows + 1) * C * 4, s, x, part, HW, C);   // part: [2][nstr][C]
     }
     TD_LAUNCH(k_ln_finalize, dim3((C + 3) / 4), dim3(256), (256 + 32 + 4) * 4, s, (const float*)part, nstr, per, HW, C, 1e-5f, mean, rstd);
-    if (y) TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
+    if (y && y16) TD_LAUNCH(k_ln_apply_h, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, (_Float16*)y, HW, C);
+    else if (y) TD_LAUNCH(k_ln_apply, dim3(td_grid_for((long)HW * CV)), dim3(256), 0, s, x, (const float*)mean, (const float*)rstd, g, b, y, HW, C);
     prof_end(n, s);
 }
 
@@ -1352,8 +1356,9 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s, int
     }
     // fusion bit 4: the normalised map is never written -- the head's Winograd input transform normalises while it reads `feat`
     const bool ln_in_head = (n->opts.fusion & 4) && L.head3.wino;
-    run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, ln_in_head ? nullptr : n->ln, s, stats_nstr);
-    n->ln_pending = ln_in_head;
+    const bool ln16 = L.head3.in16;                                     // fp16 mode: n->ln holds the map as fp16; the fp32 stage is made on request
+    run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, ln_in_head ? nullptr : n->ln, s, stats_nstr, ln16);
+    n->ln_pending = ln_in_head || ln16;
     n->ln_path = (int)(&L - &n->paths[0]);
     if (ln_in_head) {
         const LnFuse lf = {n->ln_mean, n->ln_rstd, L.d_ln_g, L.d_ln_b};
@@ -1667,9 +1672,9 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (Cin % 64) return td_fail("tdnet_op_conv2d_f16io: Cin must be a multiple of 64");
     // tile 16 / 17 / 18 / 19: the LDS-DMA kernel with 128 / 192 / 256-row tiles, 256 x 256 (td_conv_hd.h); 20 / 21: 128 rows on a ring of
     // four / two LDS buffers whatever the grid (16 chooses by the grid); -1: the heuristic (DMA kernel where it applies)
-    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : tile == 20 ? 6 : tile == 21 ? 5 : 0;   // 19: 256 x 256 (Cout % 256 == 0); 20 / 21: 128 x 128 on four / two LDS buffers
+    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : tile == 20 ? 6 : tile == 21 ? 5 : tile == 22 ? 7 : 0;   // 19: 256 x 256 (Cout % 256 == 0); 20 / 21: 128 x 128 on four / two LDS buffers
     if (force_rh) tile = CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..21", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..22", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;

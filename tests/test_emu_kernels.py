@@ -217,6 +217,22 @@ def test_fp16_storage_conv_attention_and_pipeline(lib, golden_dir):
         assert (out[0].argmax(0) == ref[0].argmax(0)).mean() >= 0.995
         assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 3e-2 * np.abs(g["f%d_c4" % t]).max()
     e.close()
+    # td4: the head's 3x3 conv has 128 output channels -- LayerNorm writes its map as fp16 and the conv runs on the LDS-DMA kernel; the
+    # fp32 "ln" stage is materialised on request from the same statistics
+    name = "td4"
+    spec = arch.model_spec(name, 19, bb)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    e = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"precision": 1})
+    e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    for t, x in enumerate(weights.synth_video(H, W, 5, seed=1)):
+        out = np.full((1, 19, H, W), 7e7, np.float32)
+        e.forward(x, t % 4, out)
+        ref = g["f%d_logits" % t]
+        assert np.abs(out - ref).max() <= 3e-2, (t, np.abs(out - ref).max())
+        assert (out[0].argmax(0) == ref[0].argmax(0)).mean() >= 0.995
+        ln = e.stage("ln", (1, 512, h, w))
+        assert np.abs(ln - g["f%d_ln" % t]).max() <= 3e-2 * np.abs(g["f%d_ln" % t]).max(), t
+    e.close()
 
 
 def test_fp16_conv_on_lds_dma(lib):
@@ -227,7 +243,7 @@ def test_fp16_conv_on_lds_dma(lib):
     opcheck.conv_f16io(lib, MEM, 13, 21, 128, 256, 3, 1, 1, 1, True, 19)             # the 256 x 256 tile: a wave multiplies two 64-slot weight groups
     opcheck.conv_f16io(lib, MEM, 20, 23, 64, 512, 3, 1, 2, 2, True, 19)              # two M tiles (ragged), two N tiles
     opcheck.conv_f16io(lib, MEM, 9, 11, 192, 256, 1, 2, 1, 0, False, 19)
-    for tile in (18, 17, 16, 20, 21, None):                                           # 20 / 21: 128 rows on a ring of four / two buffers
+    for tile in (18, 17, 16, 20, 21, 22, None):                                       # 20 / 21: 128 rows on a ring of four / two buffers; 22: eight waves of 32 x 64
         opcheck.conv_f16io(lib, MEM, 13, 21, 128, 160, 3, 1, 1, 1, True, tile)       # ragged M and N, two N tiles
         opcheck.conv_f16io(lib, MEM, 7, 9, 64, 128, 1, 1, 1, 0, False, tile)         # a single K step
         opcheck.conv_f16io(lib, MEM, 9, 11, 192, 130, 1, 2, 1, 2, True, tile)        # 1x1 stride 2, three steps, 130 channels

@@ -49,7 +49,7 @@ def test_fp16_kernels():
     opcheck.conv_f16io(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, 19)           # the 256 x 256 tile at the dominant layer4 shape
     opcheck.conv_f16io(lib, mem, 97, 193, 256, 256, 3, 1, 2, 1, True, 19)
     opcheck.conv_f16io(lib, mem, 13, 21, 128, 256, 1, 1, 1, 0, False, 19)
-    for tile in (16, 17, 18, 20, 21, None):                         # the LDS-DMA kernel (td_conv_hd.h): 128 / 192 / 256-row tiles, 128 rows on 4 / 2 buffers, the heuristic
+    for tile in (16, 17, 18, 20, 21, 22, None):                     # the LDS-DMA kernel (td_conv_hd.h): 128 / 192 / 256-row tiles, 128 rows on 4 / 2 buffers / 8 waves, the heuristic
         opcheck.conv_f16io(lib, mem, 13, 21, 128, 160, 3, 1, 1, 1, True, tile)       # padding taps on every side, ragged M and N
         opcheck.conv_f16io(lib, mem, 9, 11, 192, 130, 1, 2, 1, 2, True, tile)
         opcheck.conv_f16io(lib, mem, 40, 40, 64, 128, 3, 2, 1, 1, False, tile)

@@ -1,6 +1,6 @@
 // GPU-box probe: where do the waves of k_conv_dma_h (td_conv_hd.h) spend a K step?  The kernel compiled with TD_DMA_TRACE stamps
 // s_memtime after the DMA issue, after the MFMAs, after the vmcnt wait and after the barrier, for workgroups 0..3, every wave, the
-// first 24 steps, on the dominant layer4 shape (128x256x512 -> 512, 3x3, dilation 4, fp16 maps).
+// first 24 steps, on the dominant layer4 shape (128x256x512 -> 512, 3x3, dilation 4, fp16 maps) or the one given: code H W Cin Cout dil.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value tools/conv_dma_trace.hip -o tools/_build/conv_dma_trace
 #include <hip/hip_runtime.h>
 __device__ unsigned long long TD_DMA_TRACE[4 * 8 * 24 * 4];
@@ -11,8 +11,9 @@ __device__ unsigned long long TD_DMA_TRACE[4 * 8 * 24 * 4];
 #include <cstdlib>
 #include <vector>
 int main(int argc, char** argv) {
-    const int code = argc > 1 ? atoi(argv[1]) : 8;                    // 8 = 256 x 256, 4 = 256 x 128, 3, 2
-    const int H = 128, W = 256, Cin = 512, Cout = 512, KS = 3, dil = 4;
+    const int code = argc > 1 ? atoi(argv[1]) : 8;                    // 8 = 256 x 256, 4 = 256 x 128, 3, 2 (5 / 6: two / four buffers), 7 = 128 x 128 with eight waves
+    const int H = argc > 2 ? atoi(argv[2]) : 128, W = argc > 3 ? atoi(argv[3]) : 256, Cin = argc > 4 ? atoi(argv[4]) : 512,
+              Cout = argc > 5 ? atoi(argv[5]) : 512, KS = 3, dil = argc > 6 ? atoi(argv[6]) : 4;
     std::vector<float> w((size_t)Cout * Cin * 9);
     unsigned st = 1u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xFFFF) / 32768.0f - 1.0f; };
@@ -40,7 +41,8 @@ int main(int argc, char** argv) {
     printf("tile code %d: %.1f us per launch (with the stamps), %.0f TFLOP/s\n", code, ms / 5 * 1e3, 2.0 * H * W * Cin * 9.0 * Cout / (ms / 5 * 1e-3) / 1e12);
     std::vector<unsigned long long> t(4 * 8 * 24 * 4);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(TD_DMA_TRACE), t.size() * 8);
-    const int nw = code == 8 || code == 4 ? 8 : 2 * code;
+    const int nw = code == 8 || code == 4 || code == 7 ? 8 : code >= 5 ? 4 : 2 * code;
+    printf("shape %d x %d x %d -> %d, dilation %d: %d K steps per tile\n", H, W, Cin, Cout, dil, nsteps);
     for (int wg = 0; wg < 2; ++wg) {
         printf("workgroup %d: per wave, mean over steps 4..23 of [issue, MFMAs, vmcnt wait, barrier] in shader cycles, and the step period\n", wg);
         for (int wv = 0; wv < nw; ++wv) {

@@ -10,13 +10,13 @@ import numpy as np, torch
 from tdnet_amd import _capi
 lib = _capi.lib()
 g = np.random.default_rng(0)
-cases = [("720x960 layer3 256ch d2", 90, 120, 256, 256, 2, (21, 20, 17, 18, 1, 3)),
-         ("720x960 layer4 512ch d4", 90, 120, 512, 512, 4, (21, 20, 17, 18, 19, 1, 3)),
-         ("720x960 layer2 128ch d1", 90, 120, 128, 128, 1, (21, 20, 1, 3)),
-         ("1024x2048 layer2 128ch d1", 128, 256, 128, 128, 1, (21, 20, 18, 1, 3)),
-         ("1024x2048 layer3 256ch d2", 128, 256, 256, 256, 2, (21, 20, 18, 17)),
-         ("769x1537 layer3 256ch d2", 97, 193, 256, 256, 2, (21, 20, 18, 17)),
-         ("769x1537 layer4 512ch d4", 97, 193, 512, 512, 4, (21, 20, 18, 17, 19))]
+cases = [("720x960 layer3 256ch d2", 90, 120, 256, 256, 2, (21, 20, 22)),
+         ("720x960 layer4 512ch d4", 90, 120, 512, 512, 4, (17, 20, 22)),
+         ("720x960 layer2 128ch d1", 90, 120, 128, 128, 1, (1, 20, 22)),
+         ("1024x2048 layer2 128ch d1", 128, 256, 128, 128, 1, (20, 22)),
+         ("1024x2048 head 512->128", 128, 256, 512, 128, 1, (20, 22)),
+         ("769x1537 layer3 256ch d2", 97, 193, 256, 256, 2, (17, 20, 22)),
+         ("769x1537 layer2 128ch d1", 97, 193, 128, 128, 1, (1, 20, 22))]
 order = []
 for name, H, W, Cin, Cout, d, tiles in cases:
     x = torch.from_numpy(g.standard_normal((H, W, Cin)).astype(np.float32)).cuda()

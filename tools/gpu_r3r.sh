@@ -14,7 +14,7 @@ try:
 except Exception as e: print("FAILED", e)')" | tee -a $R/summary.txt; tail -4 $R/v.log | head -3 | cut -c1-300 >> $R/errs.txt; }
 run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"
 run "--quick --model td4 --size 1024x2048 --precision fp16"
-run "--quick --model td4 --size 769x1537 --precision fp16"
+run "--quick --model td4 --size 769x1537 --precision fp16"; run "--no-pmc --no-direct-line --no-other-configs --cpu-frames 2 --model td4 --size 1024x2048 --precision fp16"
 run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 6 --quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"
