@@ -70,7 +70,9 @@ typedef struct tdnet_opts {
                                 256 = the 4-pixel vectorised layout change of bit 16 alone (without its 2-output max-pool),
                                 512 = the cached-frame attention steps of td4's propagation chain as ONE 512-channel launch (default: two
                                      256-channel slices per launch, twice the workgroups),
-                                1024 = precision 1 only: no 256 x 256 tiles in the LDS-DMA conv kernel (A/B)                           */
+                                1024 = precision 1 only: no 256 x 256 tiles in the LDS-DMA conv kernel (A/B),
+                                2048 = precision 1 only: the LDS-DMA conv stages its activation operand tap by tap (k_conv_dma_h) instead of
+                                     one LDS image per kernel row shared by the row's three taps (k_conv_dma_h3) -- A/B                      */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
                                 1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

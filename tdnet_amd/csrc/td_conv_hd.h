@@ -23,6 +23,7 @@
 
 // MI = 32-row accumulator blocks per wave: 2 = waves of 64 x 64 (2 RH waves), 1 = waves of 32 x 64 (4 RH waves: two per SIMD at RH = 2,
 // for the grids that put a single workgroup on a CU -- a wave's DMA issue is then covered by the other wave of its SIMD).
+constexpr int TD_CUS = 256;                                            // MI355X: 8 XCDs x 32 CUs
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
     static constexpr int BM = 64 * RH, BN = 128 * NB, NW = 2 * RH * (2 / MI);
@@ -218,13 +219,334 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
     }
 }
 
+// ---- 3x3, stride 1, "same" padding: the three taps of a kernel ROW read one LDS image ------------------------------------------------
+// k_conv_dma_h stages the activation operand once per TAP: the same input pixels travel global -> LDS nine times per 64 channels,
+// and the LDS port -- not the matrix pipe -- paces every tile but 256 x 256 (DMA writes + fragment reads, 768 cycles
+// against 512 of MFMAs for 128 x 128).  Here a "super-step" (64 input channels, one kernel row ky) stages ONE image: the input pixels
+// of row offset (ky - 1) dil under the tile's BM consecutive output pixels, in a linear order WITH a horizontal halo of dil zero
+// columns on either side of every image row (halo-linear index gs = iy' (W + 2 dil) + ix + dil); the tap kx of output pixel (oy, ox)
+// is then slot (oy W' + ox - gs0) + kx dil of the same image, for all three kx.  A tile of BM pixels spans R <= (BM - 2) / W + 2 image
+// rows, so the image has S = BM + 2 dil R slots instead of 3 BM: the activation traffic (L2 -> CU and LDS writes) of a 3x3 conv
+// drops to a third plus the halo.  Slots are XOR-swizzled by (slot >> 1) & 7 like the rows of k_conv_dma_h (conflict-free fragment
+// reads; image rows meet at an even distance 2 dil).
+//   * two images (super-step u + 1 is staged during the steps kx = 0 and kx = 1 of super-step u: SH0 / SH1 pieces per wave), a ring
+//     of NBB weight buffers as before; per step the weight pieces are issued first and the counted wait lets this step's image
+//     pieces fly: vmcnt((NBB - 2) NBW + share(kx)).
+//   * steps are unrolled by three so that the tap's fragment addresses are compile-time registers.
+template <int RH, int NB, int MI, int NBB, int SH0, int SH1>
+struct ConvDma3Geom {
+    using G = ConvDmaGeom<RH, NB, MI>;
+    static constexpr int NAP = SH0 + SH1;                            // image pieces per wave
+    static constexpr int CAP = NAP * G::NW * 8;                      // image capacity in slots (pixels)
+    static constexpr int IMG_BYTES = CAP * 128, LDS_BYTES = 2 * IMG_BYTES + NBB * G::B_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
+    static_assert(NBB == 6 ? 3 * G::NBW + NAP <= 12 * MI : G::NBW + (SH0 > SH1 ? SH0 : SH1) <= 4 * MI, "one DMA piece per MFMA group");
+};
+template <int RH, int OUT16, int NB, int MI, int NBB, int SH0, int SH1>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h3(ConvArgs p) {
+    using G = ConvDmaGeom<RH, NB, MI>;
+    using G3 = ConvDma3Geom<RH, NB, MI, NBB, SH0, SH1>;
+    constexpr int NJ = 2 * NB, BM = G::BM, NW = G::NW, NBW = G::NBW, NAP = G3::NAP;
+    static_assert(NBB == 2 || NBB == 3 || NBB == 4 || NBB == 6, "two or three weight buffers; four = data lands a step early; six = one barrier per super-step");
+    TD_DYN_LDS(smem);
+    char* const wbase = smem + 2 * G3::IMG_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * G::BN;
+    const int d = p.dil, Wh = p.W + 2 * d;
+    const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
+    const int gs0 = oy0 * Wh + ox0;                                   // halo-linear index of image slot 0
+    const int S = BM + 2 * d * ((BM - 2) / p.W + 2);                  // slots any tile can need
+
+    // ---- image pieces: piece j of this wave = slots 8 (wave + NW j) .. + 7; lane -> slot + (lane >> 3), 16-byte LDS slot lane & 7 ------
+    unsigned a_base[NAP], a_ok[NAP];                                  // source offset for ky = 1, chunk 0; bit ky: the row exists (and the column does)
+#pragma unroll
+    for (int j = 0; j < NAP; ++j) {
+        const int sl = 8 * (wave + NW * j) + (lane >> 3);
+        const int gs = gs0 + sl;
+        const int r = gs / Wh, ix = gs - r * Wh - d;
+        const int kq = (lane & 7) ^ ((sl >> 1) & 7);
+        a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+        const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
+        a_ok[j] = 0u;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
+    }
+    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
+    const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
+    const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
+    unsigned b_off[NBW];
+#pragma unroll
+    for (int jb = 0; jb < NBW; ++jb) {
+        int pb = wave + NW * jb;
+        if (pb >= G::NPB) pb -= NW;
+        b_off[jb] = (unsigned)((pb / (2 * NB)) * p.CoutPad + n0 + (pb % (2 * NB)) * 64 + lane) * 16u;
+    }
+    const int nsuper = p.nsteps / 3;
+    auto issue_image_piece = [&](int u, int j) {                      // piece j of the image of super-step u (chunk u / 3, kernel row u % 3)
+        const int chunk = u / 3, ky = u - chunk * 3;
+        const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
+        const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
+        td_buf_ld16_lds(in_buf, smem + (u & 1) * G3::IMG_BYTES + (wave + NW * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
+    };
+    auto issue_weight_piece = [&](int step, int buf, int jb) {       // piece jb of the weights of K step `step` into weight buffer `buf`
+        int pb = wave + NW * jb;
+        if (pb >= G::NPB) pb -= NW;
+        const bool live = step < p.nsteps;
+        td_buf_ld16_lds(w_buf, wbase + buf * G::B_BYTES + pb * 1024, live ? b_off[jb] : TD_BUF_OOB, (unsigned)(live ? step : 0) * w_step_bytes);
+    };
+
+    // ---- fragment addresses: a_rd[kx][i] = byte address of k-group `half` of this lane's row in the image, tap kx; k-group 2 g + half is
+    // the same address with bits 5-6 XORed by g (the swizzle key touches bits 4-6 only) ------------------------------------------------
+    unsigned a_rd[3][MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 32 * MI + 32 * i + l31;
+        const int oy = m / p.W, ox = m - oy * p.W;
+        const int sm = (oy - oy0) * Wh + ox - ox0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sl = sm + kx * d;
+            a_rd[kx][i] = (unsigned)(sl * 128 + (((half) ^ ((sl >> 1) & 7)) << 4));
+        }
+    }
+    constexpr int BKQ = G::BN * 16;
+    const unsigned b_rd = (unsigned)(half * BKQ + (wn * 64 * NB + l31) * 16);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // the MFMAs of one K step: tap KX of image `img` against the weights at `wb`; issue(slot) is called after every group of NJ MFMAs
+    // (slot = MI g + i, 0 .. 4 MI - 1) so that the DMA pieces of later steps go out between them
+    auto mma = [&](auto kx_tag, const char* img, const char* wb, auto&& issue) {
+        constexpr int KX = decltype(kx_tag)::value;
+        f16x8 af[2][MI], bf[2][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(img + a_rd[KX][i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + j * 512);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f16x8*>(img + (a_rd[KX][i] ^ (unsigned)((g + 1) << 5)));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + (g + 1) * 2 * BKQ + j * 512);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(af[g & 1][i], bf[g & 1][j], acc[i][j]);
+                TD_SCHED_FENCE();
+                issue(MI * g + i);
+                TD_SCHED_FENCE();
+            }
+        }
+    };
+
+    if constexpr (NBB == 6) {
+        // ---- one barrier per SUPER-step (small tiles: a K step of 512 MFMA cycles paid ~450 cycles of barrier, wait and fragment
+        // pipeline restart).  Weight buffers (u & 1) 3 + kx; the image and the three weight steps of super-step u + 1 are issued in the
+        // first groups of super-step u (12 MI issue slots), everything is waited for at its end.
+        auto tap = [&](auto kx_tag, int u) {
+            constexpr int KX = decltype(kx_tag)::value;
+            mma(kx_tag, smem + (u & 1) * G3::IMG_BYTES, wbase + ((u & 1) * 3 + KX) * G::B_BYTES, [&](int slot) {
+                const int q = KX * 4 * MI + slot;                      // compile-time after unrolling
+#pragma unroll
+                for (int pc = 0; pc < 3 * NBW + NAP; ++pc)
+                    if (pc == q) {
+                        if (pc < 3 * NBW) issue_weight_piece(3 * (u + 1) + pc / NBW, ((u + 1) & 1) * 3 + pc / NBW, pc % NBW);
+                        else issue_image_piece(u + 1, pc - 3 * NBW);
+                    }
+            });
+        };
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) issue_image_piece(0, j);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int jb = 0; jb < NBW; ++jb) issue_weight_piece(t, t, jb);
+        TD_WAIT_VM_PIECES(0);
+        TD_BARRIER_RAW();
+        for (int u = 0; u < nsuper; ++u) {
+            tap(std::integral_constant<int, 0>{}, u);
+            tap(std::integral_constant<int, 1>{}, u);
+            tap(std::integral_constant<int, 2>{}, u);
+            TD_WAIT_VM_PIECES(0);
+            TD_BARRIER_RAW();
+        }
+    } else if constexpr (NBB == 4) {
+        // ---- data lands one step EARLY, so the fragment pipeline never drains at the barrier.  The barrier that ends step s also says
+        // "everybody's pieces of step s + 2 have landed"; step s + 1 may therefore read the first fragments of step s + 2 BEFORE its own
+        // end barrier, under its last MFMAs -- a step no longer starts with a cold ds_read after the barrier (measured on the per-step
+        // form: MFMA pipes 39 % busy, waves 39 % waiting, LDS 29 % busy: nothing saturated, a dependency chain).  Weights: ring of four,
+        // step s issues step s + 3.  Image of super-step u + 1: shares in the steps kx = 0 and kx = 1 of super-step u, complete at the end
+        // of kx = 1 (in kx = 1 the image pieces go first so that the counted wait covers them and lets the newest weights fly).
+        f16x8 af[2][MI], bf[2][NJ];                                   // fragment double buffer, live across steps
+        auto frag0 = [&](auto kx_tag, int u, int step) {              // the k-group-0 fragments of (tap kx, image u & 1, weights step & 3) into slot 0
+            constexpr int kx = decltype(kx_tag)::value;
+            const char* img = smem + (u & 1) * G3::IMG_BYTES;
+            const char* wb = wbase + (step & 3) * G::B_BYTES;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(img + a_rd[kx][i]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + j * 512);
+        };
+        auto compute = [&](auto kx_tag, int u, int step) {
+            constexpr int KX = decltype(kx_tag)::value;
+            constexpr int SHARE = KX == 0 ? SH0 : KX == 1 ? SH1 : 0, J0 = KX == 0 ? 0 : SH0;
+            const char* img = smem + (u & 1) * G3::IMG_BYTES;
+            const char* wb = wbase + (step & 3) * G::B_BYTES;
+            const int ibuf = (step + 3) & 3;                           // the buffer of step - 1
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f16x8*>(img + (a_rd[KX][i] ^ (unsigned)((g + 1) << 5)));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + (g + 1) * 2 * BKQ + j * 512);
+                } else {
+                    if constexpr (KX == 2) frag0(std::integral_constant<int, 0>{}, u + 1, step + 1);    // landed since the previous barrier
+                    else frag0(std::integral_constant<int, KX + 1>{}, u, step + 1);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(af[g & 1][i], bf[g & 1][j], acc[i][j]);
+                    TD_SCHED_FENCE();
+                    const int slot = MI * g + i;
+#pragma unroll
+                    for (int pc = 0; pc < NBW + SHARE; ++pc)
+                        if (pc == slot) {
+                            const bool image_first = KX == 1;
+                            const bool is_image = image_first ? pc < SHARE : pc >= NBW;
+                            if (is_image) issue_image_piece(u + 1, J0 + (image_first ? pc : pc - NBW));
+                            else issue_weight_piece(step + 3, ibuf, image_first ? pc - SHARE : pc);
+                        }
+                    TD_SCHED_FENCE();
+                }
+            }
+            if constexpr (KX == 0) TD_WAIT_VM_PIECES(NBW + SH0); else TD_WAIT_VM_PIECES(NBW);
+            TD_BARRIER_RAW();
+        };
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) issue_image_piece(0, j);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int jb = 0; jb < NBW; ++jb) issue_weight_piece(b, b, jb);
+        TD_WAIT_VM_PIECES(NBW);                                       // image 0 and the weights of steps 0 and 1
+        TD_BARRIER_RAW();
+        frag0(std::integral_constant<int, 0>{}, 0, 0);
+        for (int u = 0; u < nsuper; ++u) {
+            compute(std::integral_constant<int, 0>{}, u, 3 * u);
+            compute(std::integral_constant<int, 1>{}, u, 3 * u + 1);
+            compute(std::integral_constant<int, 2>{}, u, 3 * u + 2);
+        }
+    } else {
+        // one K step: this step issues the weights of step + NBB - 1 and, for KX < 2, a share of the next super-step's image
+        auto compute = [&](auto kx_tag, int u, int step) {
+            constexpr int KX = decltype(kx_tag)::value;
+            constexpr int SHARE = KX == 0 ? SH0 : KX == 1 ? SH1 : 0, J0 = KX == 0 ? 0 : SH0;
+            const int wbuf = NBB == 3 ? KX : ((u + KX) & 1);           // step = 3 u + KX
+            const int ibuf = NBB == 3 ? (KX + 2) % 3 : (wbuf ^ 1);      // the buffer of step - 1, free since the last barrier
+            mma(kx_tag, smem + (u & 1) * G3::IMG_BYTES, wbase + wbuf * G::B_BYTES, [&](int slot) {
+#pragma unroll
+                for (int pc = 0; pc < NBW + SHARE; ++pc)
+                    if (pc == slot) {
+                        if (pc < NBW) issue_weight_piece(step + NBB - 1, ibuf, pc);
+                        else issue_image_piece(u + 1, J0 + pc - NBW);
+                    }
+            });
+            TD_WAIT_VM_PIECES((NBB - 2) * NBW + SHARE);
+            TD_BARRIER_RAW();
+        };
+        // prologue: the first image, the first NBB - 1 weight steps
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) issue_image_piece(0, j);
+#pragma unroll
+        for (int b = 0; b < NBB - 1; ++b)
+#pragma unroll
+            for (int jb = 0; jb < NBW; ++jb) issue_weight_piece(b, b, jb);
+        TD_WAIT_VM_PIECES((NBB - 2) * NBW);
+        TD_BARRIER_RAW();
+        for (int u = 0; u < nsuper; ++u) {
+            compute(std::integral_constant<int, 0>{}, u, 3 * u);
+            compute(std::integral_constant<int, 1>{}, u, 3 * u + 1);
+            compute(std::integral_constant<int, 2>{}, u, 3 * u + 2);
+        }
+    }
+    TD_WAIT_VM_PIECES(0);                                             // the surplus (zero-fill) pieces must not land in an LDS that has been handed on
+
+    if constexpr (NB == 1) {
+        td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    } else if constexpr (MI == 2) {
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) {
+            f32x16 part[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) part[i][nt] = acc[i][2 * sb + nt];
+            td_store_acc_h<2, 2, OUT16 != 0, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane);
+        }
+    }
+}
+// slots an image needs for BM-pixel tiles of a W-wide map at dilation d (the kernel computes the same S)
+static inline int conv_dma3_slots(int BM, int W, int d) { return BM + 2 * d * ((BM - 2) / W + 2); }
+template <int RH, int NB, int MI, int NBB, int SH0, int SH1>
+static inline bool conv_launch_dma3_t(const ConvArgs& a, bool out16, hipStream_t s) {
+    using G = ConvDmaGeom<RH, NB, MI>;
+    using G3 = ConvDma3Geom<RH, NB, MI, NBB, SH0, SH1>;
+    if (conv_dma3_slots(G::BM, a.W, a.dil) > G3::CAP) return false;
+    const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
+    if (out16) TD_LAUNCH((k_conv_dma_h3<RH, 1, NB, MI, NBB, SH0, SH1>), dim3(grid), dim3(64 * G::NW), G3::LDS_BYTES, s, a);
+    else TD_LAUNCH((k_conv_dma_h3<RH, 0, NB, MI, NBB, SH0, SH1>), dim3(grid), dim3(64 * G::NW), G3::LDS_BYTES, s, a);
+    return true;
+}
+// the row-image kernel for the tile code rh of conv_launch_dma, where the conv qualifies (3x3, stride 1, padding = dilation, the halo fits);
+// false = not launched, use conv_launch_dma
+static inline bool conv_launch_dma3(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
+    if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
+    a.tiles_n = a.CoutPad / (rh == 8 ? 256 : 128);
+    if (rh == 8) return conv_launch_dma3_t<4, 2, 2, 2, 3, 2>(a, out16, s);
+    // 256 x 128, 192 x 128, 128 x 128 (eight waves): the early-landing form (four weight buffers) where its image buffer holds the halo,
+    // the per-step form with three otherwise.  rh = 13 / 14 / 15: the early form only; 11 / 12: 192 / 128 rows, per-step form only;
+    // 10 / 9: one barrier per super-step (probes and tests)
+    if (rh == 4 || rh == 13) {
+        if (conv_launch_dma3_t<4, 1, 2, 4, 3, 2>(a, out16, s)) return true;
+        if (rh == 13) return false;
+        return conv_launch_dma3_t<4, 1, 2, 3, 3, 3>(a, out16, s);
+    }
+    if (rh == 10) return conv_launch_dma3_t<3, 1, 2, 6, 3, 2>(a, out16, s);
+    if (rh == 3 || rh == 14) {
+        if (conv_launch_dma3_t<3, 1, 2, 4, 3, 3>(a, out16, s)) return true;
+        if (rh == 14) return false;
+    }
+    if (rh == 3 || rh == 11) return conv_launch_dma3_t<3, 1, 2, 3, 3, 3>(a, out16, s);
+    if (rh == 9) return conv_launch_dma3_t<2, 1, 1, 6, 2, 1>(a, out16, s);
+    // 128 rows, eight waves: per-step, super-step and early forms all take 22.5-23.3 us at 720x960 / 256 channels (profiles/r03w_*):
+    // the plain per-step form is the default, the others stay for the probes
+    if (rh == 15) return conv_launch_dma3_t<2, 1, 1, 4, 2, 2>(a, out16, s);
+    if (rh == 7 || rh == 12 || (rh == 2 && (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS)) return conv_launch_dma3_t<2, 1, 1, 3, 2, 2>(a, out16, s);
+    return false;
+}
+
 // Tile for an output of M pixels x Cout channels.  Returns 4 / 3 / 2 (64 rh rows x 128 channels), 8 (256 x 256; needs CoutPad % 256 == 0:
 // the caller says so), or 0 = leave the conv on the register-staged kernel with its 64 x 128 tiles (many small workgroups).
 // Cost = what the busiest CU has to do: ceil(tiles / 256 CUs) tiles of rh x nb units, divided by the tile's relative throughput --
 // measured on MI355X at 1024x2048 (profiles/r03d_*): 256 x 256 1070 TFLOP/s, 256 x 128 950, the register-staged 128 x 128 930; the
 // smaller ones estimated from their bytes per MFMA.  At 720x960 (10800 pixels) this sends the 128-channel layers to the old 64 x 128
 // tiles (169 workgroups instead of 57), the 256-channel ones to 128 x 128 (170) and the 512-channel ones to 192 x 128 (228).
-constexpr int TD_CUS = 256;                                            // MI355X: 8 XCDs x 32 CUs
 static inline int conv_dma_pick_rh(long M, int Cout, bool allow256 = true) {
     static const struct { int code, rows, nb; double eff; } cand[5] = {{4, 4, 1, 1.00}, {3, 3, 1, 0.95}, {2, 2, 1, 0.85}, {8, 4, 2, 1.13}, {0, 1, 1, 0.60}};
     int best = 4;
@@ -263,6 +585,9 @@ static inline void conv_launch_dma_t(const ConvArgs& a, int KS, bool out16, hipS
 // take 64 KB at 256 B/clk = 256 more, against 512 cycles of MFMAs -- only the 256 x 256 tile (1024 + 768 against 2048) is MFMA-bound.
 // rh = 5 / 6 / 7 force two buffers / four buffers with four waves / four buffers with eight waves (probes and tests).
 static inline void conv_launch_dma(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
+    if (rh == 9 || rh == 12 || rh == 15) rh = 7;                      // codes of conv_launch_dma3's forms: the same tile here
+    if (rh == 10 || rh == 11 || rh == 14) rh = 3;
+    if (rh == 13) rh = 4;
     a.tiles_n = a.CoutPad / (rh == 8 ? 256 : 128);
     if (rh == 8) conv_launch_dma_t<4, 2, 2>(a, KS, out16, s);
     else if (rh == 4) conv_launch_dma_t<4, 3, 1>(a, KS, out16, s);

@@ -126,6 +126,7 @@ struct ConvLayer {
     bool in16 = false, out16 = false;                                  // h16 only: the input (+ residual) / output map is stored as fp16 in HBM
     int rh = 0;                                                        // h16 + in16: != 0 -> the LDS-DMA kernel with 64 rh rows per tile (td_conv_hd.h); M_out: its output pixels
     long M_out = 0;
+    bool rowimg_off = false;                                           // tdnet_opts.fusion bit 2048: keep the tap-by-tap LDS-DMA kernel
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
@@ -177,6 +178,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     L.Cin = stem ? 4 : Cin; L.Cout = Cout; L.KS = KS; L.stride = stride; L.dil = dil; L.act = act; L.stem = stem;
     L.pad = stem ? KS / 2 : dil * (KS / 2);
     L.M_out = M;
+    L.rowimg_off = (o.fusion & 2048) != 0;
     L.pers = o.gemm_persistent; L.stagger = o.stagger;
     const bool deep = o.pipeline != 0;
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
@@ -940,7 +942,9 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || L.rh) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
-    else if (L.h16 && L.rh) conv_launch_dma(a, L.rh, L.KS, L.out16, s);
+    else if (L.h16 && L.rh) {                                           // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
+        if (L.rowimg_off || !conv_launch_dma3(a, L.rh, L.KS, L.out16, s)) conv_launch_dma(a, L.rh, L.KS, L.out16, s);
+    }
     else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
@@ -1671,10 +1675,14 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (KS != 1 && KS != 3) return td_fail("tdnet_op_conv2d_f16io: KS must be 1 or 3");
     if (Cin % 64) return td_fail("tdnet_op_conv2d_f16io: Cin must be a multiple of 64");
     // tile 16 / 17 / 18 / 19: the LDS-DMA kernel with 128 / 192 / 256-row tiles, 256 x 256 (td_conv_hd.h); 20 / 21: 128 rows on a ring of
-    // four / two LDS buffers whatever the grid (16 chooses by the grid); -1: the heuristic (DMA kernel where it applies)
-    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : tile == 20 ? 6 : tile == 21 ? 5 : tile == 22 ? 7 : 0;   // 19: 256 x 256 (Cout % 256 == 0); 20 / 21: 128 x 128 on four / two LDS buffers
+    // four / two LDS buffers whatever the grid (16 chooses by the grid); 22: 128 rows, eight waves; 23 / 26: the same on row images with one
+    // barrier per super-step / per K step only; 24 / 25: 192 rows likewise; 27 / 28 / 29: 256 / 192 / 128 rows in the early-landing form
+    // only; -1: the heuristic (DMA kernel where it applies)
+    const bool no_rowimg = tile >= 48;                                 // 48 + code: the same tile, tap-by-tap staging (k_conv_dma_h) instead of row images
+    if (no_rowimg) tile -= 32;
+    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : tile == 20 ? 6 : tile == 21 ? 5 : tile == 22 ? 7 : tile >= 23 && tile <= 29 ? tile - 14 : 0;   // 19: 256 x 256 (Cout % 256 == 0); 20 / 21: 128 x 128 on four / two LDS buffers
     if (force_rh) tile = CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..22", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..29 (+ 32)", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;
@@ -1685,6 +1693,7 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     const int Ho = out_size(H, KS, stride, dil, pad), Wo = out_size(W, KS, stride, dil, pad);
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
     L.in16 = L.out16 = true;
+    L.rowimg_off = no_rowimg;
     if (force_rh == 8 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
     if (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile)) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: this shape cannot run on the LDS-DMA kernel"); }
     if (force_rh) L.rh = force_rh;

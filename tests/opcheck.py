@@ -70,7 +70,7 @@ def conv(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed
     return err
 
 
-def conv_f16io(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed=0, tol=4e-3):
+def conv_f16io(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None, seed=0, tol=4e-3, want_out=False):
     """The fp16-storage conv of tdnet_opts.precision = 1 (input / residual / output maps fp16 in HBM, fp16 MFMA, fp32 accumulate)
     against an fp64 evaluation on the fp16-rounded operands; what is left is fp32 summation order and the output's own rounding to
     fp16 (2^-11 relative)."""
@@ -97,7 +97,7 @@ def conv_f16io(lib, mem, H, W, Cin, Cout, KS, stride, dil, act, resid, tile=None
     got = mem.get(out)
     err = float((np.abs(got - ref) / np.maximum(1.0, np.abs(ref))).max())
     assert err <= tol, ("conv_f16io", H, W, Cin, Cout, KS, stride, dil, act, resid, tile, err)
-    return err
+    return (err, got) if want_out else err
 
 
 def stem(lib, mem, H, W, seed=0, tol=1e-4, opts=None):

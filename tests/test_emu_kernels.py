@@ -250,6 +250,16 @@ def test_fp16_conv_on_lds_dma(lib):
         opcheck.conv_f16io(lib, MEM, 12, 17, 64, 128, 3, 2, 1, 1, False, tile)       # stride-2 3x3
         opcheck.conv_f16io(lib, MEM, 10, 14, 128, 256, 3, 1, 4, 1, True, tile)       # dilation 4: most taps padded
         opcheck.conv_f16io(lib, MEM, 20, 23, 64, 128, 3, 1, 2, 0, False, tile)       # 460 pixels: several M tiles, ragged last one
+    # k_conv_dma_h3 (one LDS image per kernel row, the row's three taps read it at shifted slots): every 3x3 stride-1 case above ran on
+    # it; tile + 32 keeps the tap-by-tap kernel, and the two must agree BIT FOR BIT (same products, same summation order).  Tiles that
+    # span one, two and three image rows, halos of 1 .. 16 columns, a map narrower than the halo, rows past the map, a dilation whose
+    # halo does not fit the image buffer (falls back to the tap-by-tap kernel by itself)
+    for tile in (16, 17, 18, 19, 20, 22, 23, 24, 25, 26, 27, 28, 29):                 # 23 / 24: one barrier per super-step (128 / 192 rows); 25 / 26: per K step; 27-29: early landing
+        for H, W, Cin, Cout, dil in [(13, 21, 128, 256, 1), (10, 14, 128, 256, 4), (5, 300, 64, 256, 2), (3, 130, 64, 256, 8),
+                                     (40, 7, 64, 256, 3), (9, 40, 192, 256, 16), (2, 2, 64, 256, 1)]:
+            _, a = opcheck.conv_f16io(lib, MEM, H, W, Cin, Cout, 3, 1, dil, 1, True, tile, want_out=True)
+            _, b = opcheck.conv_f16io(lib, MEM, H, W, Cin, Cout, 3, 1, dil, 1, True, tile + 32, want_out=True)
+            assert np.array_equal(a, b), (tile, H, W, Cin, Cout, dil, np.abs(a - b).max())
 
 
 def test_winograd_conv_and_pipeline(lib, golden_dir):

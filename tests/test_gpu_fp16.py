@@ -56,6 +56,15 @@ def test_fp16_kernels():
         opcheck.conv_f16io(lib, mem, 97, 193, 256, 256, 3, 1, 2, 1, True, tile)
         opcheck.conv_f16io(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, tile)     # the dominant layer4 shape
         opcheck.conv_f16io(lib, mem, 90, 120, 512, 512, 3, 1, 8, 1, True, tile)      # 720x960: 57 x 4 tiles of 192 rows
+    for tile, a in [(19, (128, 256, 512, 512, 4)), (18, (128, 256, 256, 256, 2)), (17, (90, 120, 512, 512, 16)), (22, (90, 120, 256, 256, 2)),
+                    (17, (97, 193, 512, 512, 4)), (22, (128, 256, 512, 128, 1)), (19, (97, 193, 512, 512, 4)),
+                    (23, (90, 120, 256, 256, 2)), (24, (90, 120, 512, 512, 8)), (25, (90, 120, 512, 512, 16)), (26, (128, 256, 128, 128, 1)), (24, (97, 193, 256, 256, 2)),
+                    (27, (128, 256, 256, 256, 2)), (28, (90, 120, 512, 512, 8)), (29, (90, 120, 256, 256, 2)), (28, (97, 193, 512, 512, 4)), (29, (128, 256, 512, 128, 1))]:
+        # k_conv_dma_h3 (one LDS image per kernel row) against the tap-by-tap kernel (tile + 32): bit for bit, on the real DMA engine
+        H, W, Cin, Cout, dil = a
+        _, x = opcheck.conv_f16io(lib, mem, H, W, Cin, Cout, 3, 1, dil, 1, True, tile, want_out=True)
+        _, y = opcheck.conv_f16io(lib, mem, H, W, Cin, Cout, 3, 1, dil, 1, True, tile + 32, want_out=True)
+        assert np.array_equal(x, y), (tile, a, float(np.abs(x - y).max()))
     _conv16(lib, mem, 128, 256, 512, 512, 3, 1, 4, 3)               # the dominant layer4 shape
     opcheck.conv_f16io(lib, mem, 128, 256, 512, 512, 3, 1, 4, 1, True, 3)
     opcheck.conv_f16io(lib, mem, 90, 120, 512, 512, 3, 1, 16, 1, True)             # resnet34 multi-grid 16 at 720x960

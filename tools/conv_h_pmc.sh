@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU-box probe: PMC passes over isolated launches of the fp16 conv kernels on the dominant layer4 shape (128x256x512 -> 512, 3x3 d4) --
 # the LDS-DMA kernel with 256x256 / 256x128 tiles (tile codes 19 / 18) and the register-staged 128x128 kernel (3): where do the cycles go?
+# Other shapes / tiles: CH_SHAPE=H,W,Cin,Cout,dil CH_TILES=a,b,c (tile codes of tdnet_op_conv2d_f16io).
 cd "$GRAFT_REPO_ROOT" || exit 1
 R="$GRAFT_REPO_ROOT/gpurun_out/${1:-convh_pmc}"; rm -rf $R; mkdir -p $R
 cat > /tmp/ch.py <<'PY'
@@ -8,14 +9,15 @@ import sys, ctypes, os; sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np, torch
 from tdnet_amd import _capi
 lib = _capi.lib()
-H, W, Cin, Cout = 128, 256, 512, 512
+H, W, Cin, Cout, DIL = [int(v) for v in os.environ.get("CH_SHAPE", "128,256,512,512,4").split(",")]
+TILES = [int(v) for v in os.environ.get("CH_TILES", "19,18,3").split(",")]
 g = np.random.default_rng(0)
 x = torch.from_numpy(g.standard_normal((H, W, Cin)).astype(np.float32)).cuda()
 w = (g.standard_normal((Cout, Cin, 3, 3)) / 68).astype(np.float32); b = np.zeros(Cout, np.float32)
 out = torch.empty(H, W, Cout, device="cuda")
-for tile in (19, 18, 3):
+for tile in TILES:
     for _ in range(4):
-        lib.check(lib.tdnet_op_conv2d_f16io(x.data_ptr(), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, 3, 1, 4, None, 1, tile, out.data_ptr(), None))
+        lib.check(lib.tdnet_op_conv2d_f16io(x.data_ptr(), H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, 3, 1, DIL, None, 1, tile, out.data_ptr(), None))
 torch.cuda.synchronize()
 PY
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box probe: the fp16 LDS-DMA conv at the shapes whose grid does not fill the chip (720x960: 10800 pixels; 1024x2048 layer2: 256
-# workgroups) -- ring depth (tile codes 21 / 20 = 128 x 128 on two / four LDS buffers), 192- and 256-row tiles, the register-staged kernel.
+# workgroups) and the dominant ones -- tile codes of tdnet_op_conv2d_f16io (16 .. 22; + 32 = tap-by-tap staging instead of row images).
 # Kernel durations from a rocprofv3 kernel trace, launches matched by order.
 cd "$GRAFT_REPO_ROOT" || exit 1
 R="$GRAFT_REPO_ROOT/gpurun_out/${1:-ring}"; rm -rf $R; mkdir -p $R
@@ -10,13 +10,18 @@ import numpy as np, torch
 from tdnet_amd import _capi
 lib = _capi.lib()
 g = np.random.default_rng(0)
-cases = [("720x960 layer3 256ch d2", 90, 120, 256, 256, 2, (21, 20, 22)),
-         ("720x960 layer4 512ch d4", 90, 120, 512, 512, 4, (17, 20, 22)),
-         ("720x960 layer2 128ch d1", 90, 120, 128, 128, 1, (1, 20, 22)),
-         ("1024x2048 layer2 128ch d1", 128, 256, 128, 128, 1, (20, 22)),
-         ("1024x2048 head 512->128", 128, 256, 512, 128, 1, (20, 22)),
-         ("769x1537 layer3 256ch d2", 97, 193, 256, 256, 2, (17, 20, 22)),
-         ("769x1537 layer2 128ch d1", 97, 193, 128, 128, 1, (1, 20, 22))]
+cases = [("1024x2048 layer3 256ch d2", 128, 256, 256, 256, 2, (50, 27)),
+         ("1024x2048 layer4 512ch d4", 128, 256, 512, 512, 4, (19, 27)),
+         ("1024x2048 layer2 128ch d1", 128, 256, 128, 128, 1, (26, 29)),
+         ("1024x2048 head 512->128", 128, 256, 512, 128, 1, (26, 29)),
+         ("720x960 layer3 256ch d2", 90, 120, 256, 256, 2, (26, 29)),
+         ("720x960 layer2 128ch d1", 90, 120, 128, 128, 1, (1, 26, 29)),
+         ("720x960 layer4 512ch d4", 90, 120, 512, 512, 4, (25, 24, 28)),
+         ("720x960 layer4 512ch d8", 90, 120, 512, 512, 8, (25, 28)),
+         ("720x960 layer4 512ch d16", 90, 120, 512, 512, 16, (25, 28)),
+         ("769x1537 layer3 256ch d2", 97, 193, 256, 256, 2, (25, 24, 28)),
+         ("769x1537 layer4 512ch d4", 97, 193, 512, 512, 4, (25, 24, 28, 19)),
+         ("769x1537 layer2 128ch d1", 97, 193, 128, 128, 1, (26, 29))]
 order = []
 for name, H, W, Cin, Cout, d, tiles in cases:
     x = torch.from_numpy(g.standard_normal((H, W, Cin)).astype(np.float32)).cuda()
