@@ -2,6 +2,7 @@
 #include "td_device.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -205,7 +206,13 @@ static void run_block(Worker* wk, const std::function<void()>& body, int nthread
     cur = nullptr;
 }
 
+// TDEMU_PROF=<file>: one line per launch (geometry, wall seconds) appended to the file -- where does a test's time go?
 void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes) {
+    static const char* prof = getenv("TDEMU_PROF");
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Done { const char* f; std::chrono::steady_clock::time_point t0; dim3 g, b; size_t l; ~Done() { if (!f) return;
+        if (FILE* o = fopen(f, "a")) { fprintf(o, "grid %ux%ux%u block %u lds %zu\t%.6f\n", g.x, g.y, g.z, b.x, l,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); fclose(o); } } } done{prof, t0, grid, block, lds_bytes};
     const int nthreads = (int)(block.x * block.y * block.z);
     const long nblocks = (long)grid.x * grid.y * grid.z;
     if (nthreads > MAX_THREADS || lds_bytes > LDS_BYTES || block.y != 1 || block.z != 1) {
