@@ -290,8 +290,8 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
            "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1)}
     if dom_n > 0 and dom_ms > 0:
         ach = dom_fl / (dom_ms * 1e-3) / 1e12
-        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA)" if precision == "fp16"
-                           else "k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
+        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA)" if precision == "fp16"
+                           else "k_gemm_dma<0> / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / (2 * P)}
     if cpu_frames > 0:
@@ -299,6 +299,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         par, cpu_t, _ = parity_sample(m, ref, clip, P, P, cpu_frames, precision == "fp32", torch, np, tdnet_ref)
         leg["parity"] = par
         leg["cpu_baseline"] = {"value": round(cpu_frames / cpu_t, 4), "unit": "frames/s", "kind": "port", "sample": "%d steady-state frames" % cpu_frames}
+    eng.close()
     del m
     return leg
 
@@ -538,12 +539,13 @@ def main():
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             if opts["precision"]:
-                kname, dom_regex = ("k_conv_dma_h<RH,3,OUT16,NBUF,NB> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
-                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
+                kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
+                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h3<|k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:
-                    gk, dom_regex = "k_gemm_persistent<*,*,*,*,ROLE=1>", r"k_gemm_persistent<\d+, \d+, \d+, \d+, 1>"
+                    gk, dom_regex = ("k_gemm_dma<0> (LDS-DMA-fed, tdnet_opts.overlap bit 8) / k_gemm_persistent<*,*,*,*,ROLE=1>",
+                                     r"k_gemm_dma<0>|k_gemm_persistent<\d+, \d+, \d+, \d+, 1>")
                 else:
                     gk, dom_regex = "k_conv_igemm<.,.,.,.,1> (batched)", r"k_conv_igemm<\d+, \d+, \d+, \d+, 1, false"
                 kname = (gk + ": the %d batched GEMMs of the Winograd F(%s,3x3) convs of layers %s + head, fp32 MFMA; FLOP = executed "
@@ -576,6 +578,7 @@ def main():
                                                       "avg_launch_ms": round(acc_s[3][0] / acc_s[3][2], 4), "launches_per_frame": acc_s[3][2] / nprof,
                                                       "note": "the same kernel on a handle with kernel_opts overlap=0 (one launch at a time, whole convs): "
                                                               "its own rate; in the default configuration two launches run concurrently and share the CUs"}
+            ms_.engine.close()                                          # streams of a handle are hardware queues: release them now
             del ms_
         exec_gflop = (acc[0][1] + acc[1][1]) / nprof / 1e9           # conv/GEMM (executed: Winograd GEMM FLOP) + attention matmuls
         single_fps = C * args.steps / tmax                            # this GPU's frames/s
@@ -603,6 +606,7 @@ def main():
                                           "frac_of_roof": round(gflop * dfps / 1e3 / peak, 4),
                                           "note": "same frame with every conv as a direct implicit GEMM (kernel_opts winograd=0): executed "
                                                   "FLOP = algorithmic FLOP"}
+            md.engine.close()
             del md
 
         # ---- HBM traffic from live PMC passes (N = 1 only; each pass re-runs a short bench under rocprofv3) ----------------
@@ -642,6 +646,11 @@ def main():
         default_workload = args.model == "td4" and args.backbone == "resnet18" and (H, W) == (1024, 2048) and args.precision == "fp32" and C == 1
         if world == 1 and pp is None and default_workload and not args.no_other_configs:
             ncpu = 0 if args.no_cpu_baseline else 2
+            # the main handle is done: release its streams before the legs create theirs (a process has few hardware queues; with the
+            # streams of three handles alive the second leg's two chains shared one queue -- 228 frames/s in the leg against 333 alone)
+            for m_ in models:
+                if m_.engine is not None:
+                    m_.engine.close()
             res["other_configs"] = [
                 other_config_leg("configs[1]", "td2", "resnet18", (1024, 2048), "fp32", 40, ncpu, dev, sync,
                                  "td2_psp50(backbone='resnet18', path_num=2), Testing/model/pspnet/td2_psp50.py:52-58"),

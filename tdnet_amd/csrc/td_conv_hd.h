@@ -220,15 +220,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
 }
 
 // ---- 3x3, stride 1, "same" padding: the three taps of a kernel ROW read one LDS image ------------------------------------------------
-// k_conv_dma_h stages the activation operand once per TAP: the same input pixels travel global -> LDS nine times per 64 channels,
-// and the LDS port -- not the matrix pipe -- paces every tile but 256 x 256 (DMA writes + fragment reads, 768 cycles
-// against 512 of MFMAs for 128 x 128).  Here a "super-step" (64 input channels, one kernel row ky) stages ONE image: the input pixels
+// k_conv_dma_h stages the activation operand once per TAP: the same input pixels travel global -> LDS nine times per 64 channels.
+// Here a "super-step" (64 input channels, one kernel row ky) stages ONE image: the input pixels
 // of row offset (ky - 1) dil under the tile's BM consecutive output pixels, in a linear order WITH a horizontal halo of dil zero
 // columns on either side of every image row (halo-linear index gs = iy' (W + 2 dil) + ix + dil); the tap kx of output pixel (oy, ox)
 // is then slot (oy W' + ox - gs0) + kx dil of the same image, for all three kx.  A tile of BM pixels spans R <= (BM - 2) / W + 2 image
 // rows, so the image has S = BM + 2 dil R slots instead of 3 BM: the activation traffic (L2 -> CU and LDS writes) of a 3x3 conv
-// drops to a third plus the halo.  Slots are XOR-swizzled by (slot >> 1) & 7 like the rows of k_conv_dma_h (conflict-free fragment
-// reads; image rows meet at an even distance 2 dil).
+// drops to a third plus the halo.  Slots are XOR-swizzled by (slot >> 1) & 7 like the rows of k_conv_dma_h; a fragment whose 32 rows
+// straddle two image rows jumps by 2 dil slots there (measured: bank conflicts 6 % of the LDS cycles, 0 in k_conv_dma_h).
 //   * two images (super-step u + 1 is staged during the steps kx = 0 and kx = 1 of super-step u: SH0 / SH1 pieces per wave), a ring
 //     of NBB weight buffers as before; per step the weight pieces are issued first and the counted wait lets this step's image
 //     pieces fly: vmcnt((NBB - 2) NBW + share(kx)).
@@ -580,9 +579,9 @@ static inline void conv_launch_dma_t(const ConvArgs& a, int KS, bool out16, hipS
 // CUs, and a ring of FOUR (128 KB) when it has not -- a lone workgroup of four waves issues the last piece of step s + 1 at the end of
 // step s and then waits for it: every step paid a full memory latency (measured at 720x960, 256 channels, 170 workgroups: 36 steps in
 // 35.6 us = 1 us per step for 0.25 us of MFMAs).  The four-buffer form runs as EIGHT waves of 32 x 64 (two per SIMD; 3-5 % faster than
-// four of 64 x 64, tools/conv_h_ring_probe.sh).  What paces a step then is the LDS port (tools/conv_dma_trace.hip: 1000 cycles per
-// step whatever the wave shape): the DMA writes 32 KB per step at 64 B/clk (tools/lds_dma_bw.hip) = 512 cycles and the fragment reads
-// take 64 KB at 256 B/clk = 256 more, against 512 cycles of MFMAs -- only the 256 x 256 tile (1024 + 768 against 2048) is MFMA-bound.
+// four of 64 x 64, tools/conv_h_ring_probe.sh).  A step still takes ~1000 cycles for 512 of MFMAs whatever the wave shape, the barrier
+// placement or the activation bytes (pipes 39 % busy, LDS 29 %, waves waiting 39 %) -- a dependency chain that one
+// workgroup per CU cannot overlap with anything.
 // rh = 5 / 6 / 7 force two buffers / four buffers with four waves / four buffers with eight waves (probes and tests).
 static inline void conv_launch_dma(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
     if (rh == 9 || rh == 12 || rh == 15) rh = 7;                      // codes of conv_launch_dma3's forms: the same tile here

@@ -98,3 +98,23 @@ def test_bench_two_ranks_one_perturbed_rank_fails():
     assert r.returncode != 0, out[-3000:]
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["rank_check"]["ranks_agree"] is False and line["rank_check"]["FAILED"] is True
+
+
+def test_bench_line_carries_measured_hbm_traffic_of_the_dominant_kernel():
+    """`roofline.traffic` comes from live rocprofv3 counter passes matched to the dominant kernel BY NAME: when the default GEMM kernel
+    changed (k_gemm_persistent -> k_gemm_dma) the pattern went stale and the field silently became null.  A quarter-size frame, both legs:
+    the default fp32 path and the fp16 mode; the traffic must be there, positive, and of the order of the launch's algorithmic bytes."""
+    import json, shutil, subprocess, sys
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in ([], ["--precision", "fp16"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "6", "--size", "513x1025", "--no-cpu-baseline",
+                            "--no-direct-line", "--no-other-configs"] + extra, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, out[-3000:]
+        line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        roof = line["roofline"]
+        assert roof["traffic"] is not None and roof["traffic"] > 0, (extra, roof)
+        assert line["frame"].get("hbm_bytes_all_kernels", 0) > roof["traffic"], (extra, line["frame"])
