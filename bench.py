@@ -646,8 +646,8 @@ def main():
         default_workload = args.model == "td4" and args.backbone == "resnet18" and (H, W) == (1024, 2048) and args.precision == "fp32" and C == 1
         if world == 1 and pp is None and default_workload and not args.no_other_configs:
             ncpu = 0 if args.no_cpu_baseline else 2
-            # the main handle is done: release its streams before the legs create theirs (a process has few hardware queues; with the
-            # streams of three handles alive the second leg's two chains shared one queue -- 228 frames/s in the leg against 333 alone)
+            # the main handle is done: release it (and its internal streams) before the legs create theirs -- with the idle handles
+            # of the earlier legs alive the first leg measured 228 frames/s against 333 alone (HIP maps streams onto few hardware queues)
             for m_ in models:
                 if m_.engine is not None:
                     m_.engine.close()

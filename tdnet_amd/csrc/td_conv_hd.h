@@ -24,6 +24,25 @@
 // MI = 32-row accumulator blocks per wave: 2 = waves of 64 x 64 (2 RH waves), 1 = waves of 32 x 64 (4 RH waves: two per SIMD at RH = 2,
 // for the grids that put a single workgroup on a CU -- a wave's DMA issue is then covered by the other wave of its SIMD).
 constexpr int TD_CUS = 256;                                            // MI355X: 8 XCDs x 32 CUs
+// Tile / K-loop form of the LDS-DMA conv kernels (ConvLayer::rh).  The model uses NONE, 128, 192, 256 and 256x256 (conv_dma_pick_rh);
+// the others force one form for the probes and tests (tile code 16 + ... of tdnet_op_conv2d_f16io, see there).
+enum ConvDmaCode {
+    CD_NONE = 0,          // not on these kernels
+    CD_128 = 2,           // 128 x 128: buffers and waves by the grid (see conv_launch_dma)
+    CD_192 = 3,           // 192 x 128
+    CD_256 = 4,           // 256 x 128
+    CD_128_2BUF = 5,      // 128 x 128, two LDS buffers, four waves (two workgroups per CU)
+    CD_128_4BUF = 6,      // 128 x 128, ring of four, four waves of 64 x 64
+    CD_128_8W = 7,        // 128 x 128, ring of four, eight waves of 32 x 64
+    CD_256x256 = 8,       // 256 x 256 (Cout padded to a multiple of 256)
+    CD_128_SUPER = 9,     // row-image kernel, 128 rows: one barrier per super-step
+    CD_192_SUPER = 10,    // ... 192 rows
+    CD_192_STEP = 11,     // row-image kernel, 192 rows: one barrier per K step, three weight buffers
+    CD_128_STEP = 12,     // ... 128 rows
+    CD_256_EARLY = 13,    // row-image kernel, 256 rows: four weight buffers, data lands one step early
+    CD_192_EARLY = 14,    // ... 192 rows
+    CD_128_EARLY = 15     // ... 128 rows
+};
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
     static constexpr int BM = 64 * RH, BN = 128 * NB, NW = 2 * RH * (2 / MI);
@@ -516,39 +535,38 @@ static inline bool conv_launch_dma3_t(const ConvArgs& a, bool out16, hipStream_t
 // false = not launched, use conv_launch_dma
 static inline bool conv_launch_dma3(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
     if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
-    a.tiles_n = a.CoutPad / (rh == 8 ? 256 : 128);
-    if (rh == 8) return conv_launch_dma3_t<4, 2, 2, 2, 3, 2>(a, out16, s);
-    // 256 x 128, 192 x 128, 128 x 128 (eight waves): the early-landing form (four weight buffers) where its image buffer holds the halo,
-    // the per-step form with three otherwise.  rh = 13 / 14 / 15: the early form only; 11 / 12: 192 / 128 rows, per-step form only;
-    // 10 / 9: one barrier per super-step (probes and tests)
-    if (rh == 4 || rh == 13) {
-        if (conv_launch_dma3_t<4, 1, 2, 4, 3, 2>(a, out16, s)) return true;
-        if (rh == 13) return false;
-        return conv_launch_dma3_t<4, 1, 2, 3, 3, 3>(a, out16, s);
+    a.tiles_n = a.CoutPad / (rh == CD_256x256 ? 256 : 128);
+    switch (rh) {
+        case CD_256x256: return conv_launch_dma3_t<4, 2, 2, 2, 3, 2>(a, out16, s);
+        // 256 x 128 and 192 x 128: the early-landing form where its (smaller) image buffer holds the halo, else one barrier per K step
+        case CD_256: return conv_launch_dma3_t<4, 1, 2, 4, 3, 2>(a, out16, s) || conv_launch_dma3_t<4, 1, 2, 3, 3, 3>(a, out16, s);
+        case CD_192: return conv_launch_dma3_t<3, 1, 2, 4, 3, 3>(a, out16, s) || conv_launch_dma3_t<3, 1, 2, 3, 3, 3>(a, out16, s);
+        // 128 rows, eight waves, where the grid leaves one workgroup per CU: per-step, super-step and early forms all take 22.5-23.3 us
+        // at 720x960 / 256 channels (profiles/r03w_*); the plain per-step form (largest image buffer) is the default
+        case CD_128:
+            if ((long)((a.M + 127) / 128) * a.tiles_n > TD_CUS) return false;           // larger grids: two workgroups per CU on the tap-by-tap kernel
+            [[fallthrough]];
+        case CD_128_8W: case CD_128_STEP: return conv_launch_dma3_t<2, 1, 1, 3, 2, 2>(a, out16, s);
+        // single forms, for the probes and tests
+        case CD_256_EARLY: return conv_launch_dma3_t<4, 1, 2, 4, 3, 2>(a, out16, s);
+        case CD_192_EARLY: return conv_launch_dma3_t<3, 1, 2, 4, 3, 3>(a, out16, s);
+        case CD_192_STEP: return conv_launch_dma3_t<3, 1, 2, 3, 3, 3>(a, out16, s);
+        case CD_192_SUPER: return conv_launch_dma3_t<3, 1, 2, 6, 3, 2>(a, out16, s);
+        case CD_128_EARLY: return conv_launch_dma3_t<2, 1, 1, 4, 2, 2>(a, out16, s);
+        case CD_128_SUPER: return conv_launch_dma3_t<2, 1, 1, 6, 2, 1>(a, out16, s);
+        default: return false;
     }
-    if (rh == 10) return conv_launch_dma3_t<3, 1, 2, 6, 3, 2>(a, out16, s);
-    if (rh == 3 || rh == 14) {
-        if (conv_launch_dma3_t<3, 1, 2, 4, 3, 3>(a, out16, s)) return true;
-        if (rh == 14) return false;
-    }
-    if (rh == 3 || rh == 11) return conv_launch_dma3_t<3, 1, 2, 3, 3, 3>(a, out16, s);
-    if (rh == 9) return conv_launch_dma3_t<2, 1, 1, 6, 2, 1>(a, out16, s);
-    // 128 rows, eight waves: per-step, super-step and early forms all take 22.5-23.3 us at 720x960 / 256 channels (profiles/r03w_*):
-    // the plain per-step form is the default, the others stay for the probes
-    if (rh == 15) return conv_launch_dma3_t<2, 1, 1, 4, 2, 2>(a, out16, s);
-    if (rh == 7 || rh == 12 || (rh == 2 && (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS)) return conv_launch_dma3_t<2, 1, 1, 3, 2, 2>(a, out16, s);
-    return false;
 }
 
-// Tile for an output of M pixels x Cout channels.  Returns 4 / 3 / 2 (64 rh rows x 128 channels), 8 (256 x 256; needs CoutPad % 256 == 0:
-// the caller says so), or 0 = leave the conv on the register-staged kernel with its 64 x 128 tiles (many small workgroups).
+// Tile for an output of M pixels x Cout channels: CD_256 / CD_192 / CD_128 (256 / 192 / 128 rows x 128 channels), CD_256x256 (needs CoutPad
+// % 256 == 0: the caller says so), or CD_NONE = leave the conv on the register-staged kernel with its 64 x 128 tiles (many small workgroups).
 // Cost = what the busiest CU has to do: ceil(tiles / 256 CUs) tiles of rh x nb units, divided by the tile's relative throughput --
 // measured on MI355X at 1024x2048 (profiles/r03d_*): 256 x 256 1070 TFLOP/s, 256 x 128 950, the register-staged 128 x 128 930; the
 // smaller ones estimated from their bytes per MFMA.  At 720x960 (10800 pixels) this sends the 128-channel layers to the old 64 x 128
 // tiles (169 workgroups instead of 57), the 256-channel ones to 128 x 128 (170) and the 512-channel ones to 192 x 128 (228).
 static inline int conv_dma_pick_rh(long M, int Cout, bool allow256 = true) {
-    static const struct { int code, rows, nb; double eff; } cand[5] = {{4, 4, 1, 1.00}, {3, 3, 1, 0.95}, {2, 2, 1, 0.85}, {8, 4, 2, 1.13}, {0, 1, 1, 0.60}};
-    int best = 4;
+    static const struct { int code, rows, nb; double eff; } cand[5] = {{CD_256, 4, 1, 1.00}, {CD_192, 3, 1, 0.95}, {CD_128, 2, 1, 0.85}, {CD_256x256, 4, 2, 1.13}, {CD_NONE, 1, 1, 0.60}};
+    int best = CD_256;
     double best_cost = 0.0;
     for (int i = 0; i < 5; ++i) {
         if (cand[i].nb == 2 && (!allow256 || Cout % 256)) continue;
@@ -574,7 +592,7 @@ static inline void conv_launch_dma_t(const ConvArgs& a, int KS, bool out16, hipS
     else if (out16) TD_LAUNCH((k_conv_dma_h<RH, 1, true, NBUF, NB, MI>), dim3(grid), dim3(64 * G::NW), lds, s, a);
     else TD_LAUNCH((k_conv_dma_h<RH, 1, false, NBUF, NB, MI>), dim3(grid), dim3(64 * G::NW), lds, s, a);
 }
-// rh: 4 / 3 (three LDS buffers, one workgroup per CU), 2 (128 x 128), 8 = 256 rows x 256 channels (two buffers, one per CU).
+// CD_256 / CD_192: three LDS buffers, one workgroup per CU; CD_128: see below; CD_256x256: two buffers, one workgroup per CU.
 // 128 x 128 has two forms: two buffers (64 KB: two workgroups per CU cover each other's waits) when the grid has more workgroups than
 // CUs, and a ring of FOUR (128 KB) when it has not -- a lone workgroup of four waves issues the last piece of step s + 1 at the end of
 // step s and then waits for it: every step paid a full memory latency (measured at 720x960, 256 channels, 170 workgroups: 36 steps in
@@ -582,16 +600,16 @@ static inline void conv_launch_dma_t(const ConvArgs& a, int KS, bool out16, hipS
 // four of 64 x 64, tools/conv_h_ring_probe.sh).  A step still takes ~1000 cycles for 512 of MFMAs whatever the wave shape, the barrier
 // placement or the activation bytes (pipes 39 % busy, LDS 29 %, waves waiting 39 %) -- a dependency chain that one
 // workgroup per CU cannot overlap with anything.
-// rh = 5 / 6 / 7 force two buffers / four buffers with four waves / four buffers with eight waves (probes and tests).
 static inline void conv_launch_dma(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
-    if (rh == 9 || rh == 12 || rh == 15) rh = 7;                      // codes of conv_launch_dma3's forms: the same tile here
-    if (rh == 10 || rh == 11 || rh == 14) rh = 3;
-    if (rh == 13) rh = 4;
-    a.tiles_n = a.CoutPad / (rh == 8 ? 256 : 128);
-    if (rh == 8) conv_launch_dma_t<4, 2, 2>(a, KS, out16, s);
-    else if (rh == 4) conv_launch_dma_t<4, 3, 1>(a, KS, out16, s);
-    else if (rh == 3) conv_launch_dma_t<3, 3, 1>(a, KS, out16, s);
-    else if (rh == 7 || (rh == 2 && (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS)) conv_launch_dma_t<2, 4, 1, 1>(a, KS, out16, s);
-    else if (rh == 6) conv_launch_dma_t<2, 4, 1>(a, KS, out16, s);
+    if (rh == CD_128_SUPER || rh == CD_128_STEP || rh == CD_128_EARLY) rh = CD_128_8W;   // forms of the row-image kernel: the same tile here
+    if (rh == CD_192_SUPER || rh == CD_192_STEP || rh == CD_192_EARLY) rh = CD_192;
+    if (rh == CD_256_EARLY) rh = CD_256;
+    a.tiles_n = a.CoutPad / (rh == CD_256x256 ? 256 : 128);
+    const bool one_per_cu = (long)((a.M + 127) / 128) * a.tiles_n <= TD_CUS;
+    if (rh == CD_256x256) conv_launch_dma_t<4, 2, 2>(a, KS, out16, s);
+    else if (rh == CD_256) conv_launch_dma_t<4, 3, 1>(a, KS, out16, s);
+    else if (rh == CD_192) conv_launch_dma_t<3, 3, 1>(a, KS, out16, s);
+    else if (rh == CD_128_8W || (rh == CD_128 && one_per_cu)) conv_launch_dma_t<2, 4, 1, 1>(a, KS, out16, s);
+    else if (rh == CD_128_4BUF) conv_launch_dma_t<2, 4, 1>(a, KS, out16, s);
     else conv_launch_dma_t<2, 2, 1>(a, KS, out16, s);
 }

@@ -1680,7 +1680,9 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     // only; -1: the heuristic (DMA kernel where it applies)
     const bool no_rowimg = tile >= 48;                                 // 48 + code: the same tile, tap-by-tap staging (k_conv_dma_h) instead of row images
     if (no_rowimg) tile -= 32;
-    const int force_rh = tile >= 16 && tile <= 18 ? tile - 14 : tile == 19 ? 8 : tile == 20 ? 6 : tile == 21 ? 5 : tile == 22 ? 7 : tile >= 23 && tile <= 29 ? tile - 14 : 0;   // 19: 256 x 256 (Cout % 256 == 0); 20 / 21: 128 x 128 on four / two LDS buffers
+    static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
+                                         CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
+    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : 0;
     if (force_rh) tile = CT_128x128_DEEP;
     if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..29 (+ 32)", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
@@ -1694,7 +1696,7 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
     L.in16 = L.out16 = true;
     L.rowimg_off = no_rowimg;
-    if (force_rh == 8 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
+    if (force_rh == CD_256x256 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
     if (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile)) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: this shape cannot run on the LDS-DMA kernel"); }
     if (force_rh) L.rh = force_rh;
     else if (tile < 0 && conv_dma_supports(Cin, Cout, KS, L.tile)) L.rh = conv_dma_pick_rh((long)Ho * Wo, Cout, L.CoutPad % 256 == 0);
