@@ -72,7 +72,9 @@ typedef struct tdnet_opts {
                                      256-channel slices per launch, twice the workgroups),
                                 1024 = precision 1 only: no 256 x 256 tiles in the LDS-DMA conv kernel (A/B),
                                 2048 = precision 1 only: the LDS-DMA conv stages its activation operand tap by tap (k_conv_dma_h) instead of
-                                     one LDS image per kernel row shared by the row's three taps (k_conv_dma_h3) -- A/B                      */
+                                     one LDS image per kernel row shared by the row's three taps (k_conv_dma_h3) -- A/B,
+                                4096 = precision 1 only: the 64 -> 64-channel 3x3 convs (ResNet layer1) on persistent workgroups with the weights
+                                     resident in LDS (k_conv_dma_w64; measured no faster than the per-tile kernel: one wave per SIMD)           */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
                                 1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -789,8 +789,11 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             }
             // fp16 maps in, Cout >= 128: the LDS-DMA kernel (td_conv_hd.h), unless fusion bit 128 keeps the register-staged one
             auto dma = [&](ConvLayer& c) {
-                if (c.h16 && c.in16 && !c.stem && !(n->opts.fusion & 128) && c.Cout >= 128 && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile))
+                if (!c.h16 || !c.in16 || c.stem || (n->opts.fusion & 128)) return;
+                if (c.Cout >= 128 && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile))
                     c.rh = conv_dma_pick_rh(c.M_out, c.Cout, c.CoutPad % 256 == 0 && !(n->opts.fusion & 1024));
+                else if ((n->opts.fusion & 4096) && conv_dma_w64_supports(c.Cin, c.Cout, c.CoutPad, c.KS, c.stride, c.dil, c.pad))
+                    c.rh = CD_W64;                                      // layer1: weights resident in LDS (k_conv_dma_w64; measured no faster, opt-in)
             };
             if (n->deep) dma(L.stem3);
             for (auto& B : L.blocks) { dma(B.c1); dma(B.c2); if (B.bott) dma(B.c3); if (B.has_ds) dma(B.ds); }
@@ -940,9 +943,11 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
-    prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || L.rh) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
+    prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || (L.rh && L.rh != CD_W64)) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
-    else if (L.h16 && L.rh) {                                           // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
+    else if (L.h16 && L.rh == CD_W64) {                                 // 64 -> 64 channels: persistent workgroups with the weights resident in LDS
+        if (!conv_launch_dma_w64(a, L.out16, s)) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
+    } else if (L.h16 && L.rh) {                                         // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
         if (L.rowimg_off || !conv_launch_dma3(a, L.rh, L.KS, L.out16, s)) conv_launch_dma(a, L.rh, L.KS, L.out16, s);
     }
     else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
@@ -1682,9 +1687,9 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (no_rowimg) tile -= 32;
     static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
                                          CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
-    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : 0;
-    if (force_rh) tile = CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..29 (+ 32)", CT_COUNT);
+    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : 0;            // 30: the weights-resident 64 -> 64 kernel
+    if (force_rh) tile = force_rh == CD_W64 ? CT_128x64 : CT_128x128_DEEP;
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..30 (+ 32)", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;
@@ -1697,9 +1702,12 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     L.in16 = L.out16 = true;
     L.rowimg_off = no_rowimg;
     if (force_rh == CD_256x256 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
-    if (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile)) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: this shape cannot run on the LDS-DMA kernel"); }
+    if (force_rh == CD_W64 ? !conv_dma_w64_supports(Cin, Cout, L.CoutPad, KS, stride, dil, pad) : (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile))) {
+        free_conv_layer(L);
+        return td_fail("tdnet_op_conv2d_f16io: this shape cannot run on the LDS-DMA kernel");
+    }
     if (force_rh) L.rh = force_rh;
-    else if (tile < 0 && conv_dma_supports(Cin, Cout, KS, L.tile)) L.rh = conv_dma_pick_rh((long)Ho * Wo, Cout, L.CoutPad % 256 == 0);
+    else if (tile < 0 && Cout >= 128 && conv_dma_supports(Cin, Cout, KS, L.tile)) L.rh = conv_dma_pick_rh((long)Ho * Wo, Cout, L.CoutPad % 256 == 0);
     _Float16 *hin = nullptr, *hres = nullptr, *hout = nullptr;
     const long nin = (long)H * W * Cin, nout = (long)Ho * Wo * Cout;
     auto cleanup = [&]() {                                             // one release path, also for the error returns

@@ -262,6 +262,20 @@ def test_fp16_conv_on_lds_dma(lib):
             assert np.array_equal(a, b), (tile, H, W, Cin, Cout, dil, np.abs(a - b).max())
 
 
+def test_fp16_conv_64_channels_weights_resident(lib):
+    """td_conv_hd.h k_conv_dma_w64 (ResNet layer1 in the fp16 mode): persistent workgroups, the 72 KB of packed weights loaded into LDS once,
+    row images streamed through a ring of four across tile boundaries.  Against fp64 on fp16-rounded operands and BIT FOR BIT against the
+    per-tile register-staged kernel (tile code 2: same products, same order): one tile, several tiles per workgroup (more tiles than
+    the 256 workgroups of a launch), tiles spanning three image rows, ragged last tile, fewer than 64 output channels, dilation, residual
+    / activation variants.  (Opt-in: tdnet_opts.fusion bit 4096 -- measured no faster on the GPU.)"""
+    for H, W, Cout, dil, act, res in [(13, 21, 64, 1, 1, True), (20, 23, 64, 2, 0, False), (5, 300, 64, 1, 2, True), (40, 7, 48, 1, 1, False),
+                                      (190, 180, 64, 1, 1, True), (9, 40, 64, 4, 1, True)]:
+        _, a = opcheck.conv_f16io(lib, MEM, H, W, 64, Cout, 3, 1, dil, act, res, 30, want_out=True)
+        _, b = opcheck.conv_f16io(lib, MEM, H, W, 64, Cout, 3, 1, dil, act, res, 2, want_out=True)
+        assert np.array_equal(a, b), (H, W, Cout, dil, float(np.abs(a - b).max()))
+    opcheck.conv_f16io(lib, MEM, 9, 40, 64, 64, 3, 1, 16, 1, True, 30)                # the halo does not fit: the per-tile kernel by itself
+
+
 def test_winograd_conv_and_pipeline(lib, golden_dir):
     """Winograd F(2x2,3x3) mode (td_wino.h): every dilation, ragged sizes, then the td4 pipeline with layers 3-4 on it."""
     if True:

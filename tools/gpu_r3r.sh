@@ -12,10 +12,10 @@ run() { timeout 300 python bench.py --steps 60 $1 > $R/v.log 2>&1
 try:
     d=json.loads(sys.stdin.read()); print(d["value"], "fps", d["ms_per_step"], "ms", d.get("breakdown_ms_per_frame"), d.get("roofline",{}).get("frac"), d.get("roofline",{}).get("avg_launch_ms"), d.get("parity",{}).get("max_abs_dlogit"), d.get("parity",{}).get("flips_outside_tie_band"))
 except Exception as e: print("FAILED", e)')" | tee -a $R/summary.txt; tail -4 $R/v.log | head -3 | cut -c1-300 >> $R/errs.txt; }
-run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"
+run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"; run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16 --fusion 2054"
 run "--quick --model td4 --size 1024x2048 --precision fp16"
 run "--quick --model td4 --size 769x1537 --precision fp16"; run "--no-pmc --no-direct-line --no-other-configs --cpu-frames 2 --model td4 --size 1024x2048 --precision fp16"
-run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"
+run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"; run "--quick --model td2 --backbone resnet34 --size 720x960 --precision fp16 --fusion 2054"
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 6 --quick --model td2 --backbone resnet34 --size 720x960 --precision fp16"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$R/prof" -o r1 -- $B > "$GRAFT_REPO_ROOT/$R/prof.log" 2>&1
