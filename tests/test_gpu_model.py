@@ -267,3 +267,29 @@ def test_properties_determinism_labels_reset():
     m2.load_state_dict(weights.synth_state_dict(spec, 97, 193, 0))
     with pytest.raises(RuntimeError):
         m2(frames[0], pos_id=0)
+
+
+def test_every_schedule_option_reproduces_the_default_bit_for_bit():
+    """tdnet_opts.overlap / fusion choose WHEN and on which kernel variant the same products are summed in the same order: no chains
+    (round 2's schedule), chains with 1 / 4 channels per lane, the persistent or the LDS-DMA-fed Winograd GEMM, transforms riding in
+    the GEMM's matrix waves, the next frame's cache-only chain launched at the end of the frame; in the fp16 mode the tap-by-tap or
+    the row-image conv kernel, layer1 on the weights-resident kernel.  On the real streams and DMA engines (the emulator runs them
+    in issue order) every variant must give the default's logits bit for bit, frame by frame, through warm-up and steady state --
+    including a repeated pos_id, which the pre-launched chain mispredicts."""
+    H, W = 257, 513
+    frames = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, 8, seed=11)]
+    pos = [0, 1, 2, 3, 0, 0, 1, 2]
+    with torch.no_grad():
+        for base, variants in (({}, [{"overlap": 0}, {"overlap": 1}, {"overlap": 33}, {"overlap": 8}, {"overlap": 1 | 8 | 64 | 32}, {"overlap": 41 | 128}]),
+                               ({"precision": 1}, [{"fusion": 6 | 2048}, {"fusion": 6 | 4096}, {"fusion": 6 | 1024}, {"overlap": 128}])):
+            m = make_model("td4", "resnet18", seed=3, kernel_opts=dict(base))
+            ref = [m(x, pos_id=p).clone() for x, p in zip(frames, pos)]
+            m.engine.close()
+            for v in variants:
+                mv = make_model("td4", "resnet18", seed=3, kernel_opts=dict(base, **v))
+                for t, (x, p) in enumerate(zip(frames, pos)):
+                    out = mv(x, pos_id=p)
+                    assert torch.equal(out, ref[t]), (base, v, t, float((out - ref[t]).abs().max()))
+                for k, val in v.items():
+                    assert mv.engine.opts()[k] == val
+                mv.engine.close()
