@@ -24,7 +24,7 @@ def build(force=False):
     except (OSError, StopIteration):
         flags = set()
     isa = [f for f, need in (("-mfma", "fma"), ("-mavx2", "avx2"), ("-mf16c", "f16c")) if need in flags]
-    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-ffp-contract=off", "-Wno-psabi"] + isa + [
+    cmd = [CXX, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-ffp-contract=off", "-Wno-psabi"] + isa + [
            "-include", os.path.join(HERE, "td_device.h"),
            "-x", "c++", os.path.join(ROOT, "tdnet_amd", "csrc", "td_model.hip"), os.path.join(HERE, "tdemu.cpp"), "-o", OUT]
     subprocess.run(cmd, check=True)

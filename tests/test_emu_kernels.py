@@ -352,8 +352,9 @@ def test_winograd_chunked_low_register_transforms(lib):
 
 
 @pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 41}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
-                                          ("td2", "resnet18", {"overlap": 3 | 32 | 4}),
-                                          ("td2", "resnet18", {"overlap": 1 | 8 | 64, "gemm_persistent": 5})])
+                                          ("td2", "resnet18", {"overlap": 3 | 32 | 4}), ("td4", "resnet18", {"overlap": 1 | 8 | 64 | 32}),
+                                          ("td2", "resnet18", {"overlap": 1 | 8 | 64, "gemm_persistent": 5}), ("td4", "resnet18", {"overlap": 41 | 128}),
+                                          ("td2", "resnet18", {"overlap": 128})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     """tdnet_opts.overlap: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows), 1 / 2 /
     4 channels per lane in the transforms, the LDS-DMA-fed GEMM (bit 8; 41 = the library default), the staggered start (bit 4) and the
@@ -366,8 +367,7 @@ def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=opts)
     assert e.opts()["overlap"] == opts["overlap"]
     e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
-    T = 2 if bb == "resnet34" else spec.path_num + 1                              # the chains are backbone work: every frame runs them
-    for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
+    for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 1, seed=1)):
         out = np.full((1, 19, H, W), 7e7, np.float32)
         e.forward(x, t % spec.path_num, out)
         if "f%d_c4" % t in g.files:
@@ -407,16 +407,16 @@ def test_prelaunched_chain_falls_back_when_the_next_call_is_not_the_predicted_on
     """tdnet_opts.overlap bit 128: the cache-only attention chain of frame t + 1 is launched at the end of frame t for pos_id + 1 on
     the FIFO as it stands.  Any other next call -- a repeated or skipped pos_id, a reset, a split encode / propagate, an entry pushed
     from outside -- must give exactly what a handle without the pre-launch gives (bit for bit: same kernels, same data)."""
-    H, W = 17, 33
-    spec = arch.model_spec("td2", 19, "resnet18")                                  # two paths: steady state from the third frame on
+    H, W = 33, 65
+    spec = arch.model_spec("td4", 19, "resnet18")
     h, w = arch.feat_size(H), arch.feat_size(W)
     sd = weights.synth_state_dict(spec, h, w, 0)
-    frames = weights.synth_video(H, W, 8, seed=5)
-    a = Engine(2, 18, 19, H, W, 0, lib=lib, opts={"overlap": 41})
-    b = Engine(2, 18, 19, H, W, 0, lib=lib, opts={"overlap": 41 | 128})
+    frames = weights.synth_video(H, W, 12, seed=5)
+    a = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"overlap": 41})
+    b = Engine(4, 18, 19, H, W, 0, lib=lib, opts={"overlap": 41 | 128})
     a.load_state_dict(sd); b.load_state_dict(sd)
     lk, dk, dv = a.cache_dims()
-    seq = [0, 1, 0, 0, "push", 1]                                                 # predicted, repeated pos_id, pushed entry
+    seq = [0, 1, 2, 3, 0, 2, 2, 3, 0, 1, "reset", 0, 1, 2, 3, "split", 1, "push", 2, 3]
     t = 0
     for step in seq:
         if step == "reset":
