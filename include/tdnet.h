@@ -40,7 +40,7 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 6
+#define TDNET_FUSION_DEFAULT 38   /* 2 | 4 | 32; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*) */
 #define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
@@ -54,7 +54,7 @@ typedef struct tdnet_opts {
                                 0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */
     int32_t stagger;         /* start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups                      */
     int32_t attention;       /* 0 = exact two-pass softmax (row maxima first), 1 = single pass, lazily moved reference, 2 (default) = the same pipelined to one barrier per key tile        */
-    int32_t fusion;          /* bit mask of launch-level fusions / overlaps, each measured on its own; default 2|4 = the two
+    int32_t fusion;          /* bit mask of launch-level fusions / overlaps, each measured on its own; default 2|4|32 = the three
                                 that pay on MI355X (1, 8, 16 measured neutral to slightly negative and stay off):
                                 1 = Encoding's q / k projections (w_qs, w_ks: small, latency-bound) on the side stream beside w_vs,
                                 2 = LayerNorm strip statistics written by the attention epilogue (no separate pass over the map),

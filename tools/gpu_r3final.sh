@@ -18,7 +18,7 @@ run ""; run "--overlap 0"; run ""
 run "--model td2 --size 1024x2048"; run "--model td4 --size 769x1537"; run "--model td2 --backbone resnet50 --size 769x1537"
 run "--model psp --size 769x1537"; run "--model td4 --backbone resnet34 --size 1024x2048"; run "--model td4 --backbone resnet50 --size 769x1537"
 run "--model td2 --backbone resnet34 --size 720x960"; run "--model td2 --backbone resnet34 --size 720x960 --precision fp16"; run "--model td4 --size 1024x2048 --precision fp16"
-run "--model td4 --size 769x1537 --precision fp16"; run "--model td2 --size 1024x2048 --precision fp16"; run "--model td2 --backbone resnet34 --size 720x960 --precision fp16 --fusion 2054"; run "--model td4 --size 1024x2048 --precision fp16 --fusion 2054"
+run "--model td4 --size 769x1537 --precision fp16"; run "--model td2 --size 1024x2048 --precision fp16"; run "--model td2 --backbone resnet34 --size 720x960 --precision fp16 --fusion 2086"; run "--model td4 --size 1024x2048 --precision fp16 --fusion 2086"; run "--fusion 6"; run ""
 cd /tmp && export TMPDIR=/tmp
 prof() { timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$R/$1" -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 6 --quick $2 > "$GRAFT_REPO_ROOT/$R/$1.log" 2>&1
   cp $(find $GRAFT_REPO_ROOT/$R/$1 -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$R/kernel_stats_$1.csv 2>/dev/null; }
