@@ -112,7 +112,8 @@ def test_layernorm_ppm_upsample(lib):
         opcheck.upsample(lib, MEM, c, h, w, H, W)
 
 
-CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet50", 33, 65)]
+CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet50", 33, 65), ("td2", "resnet34", 33, 65), ("td2", "resnet18", 49, 81),
+         ("td4", "resnet34", 33, 65), ("td4", "resnet50", 33, 65), ("td4", "resnet18", 65, 129)]
 
 
 @pytest.mark.parametrize("name,bb,H,W", CASES)
@@ -132,15 +133,21 @@ def test_full_pipeline_against_reference_goldens(lib, golden_dir, name, bb, H, W
         e.forward(x, t % spec.path_num, out)
         assert e.fifo_len() == min(t + 1, spec.fifo)
         for st, shp in shapes.items():
+            if "f%d_%s" % (t, st) not in g.files:                               # the larger goldens keep logits and a few stages only
+                continue
             ref = g["f%d_%s" % (t, st)]
             got = e.stage(st, shp)
             assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (t, st)
         ref = g["f%d_logits" % t]
-        assert np.abs(out - ref).max() <= 1e-3                                   # north_star: logits within 1e-3 fp32
-        assert (out[0].argmax(0) == ref[0].argmax(0)).all()
+        err = float(np.abs(out - ref).max())
+        assert err <= 1e-3                                                       # north_star: logits within 1e-3 fp32
+        bad = out[0].argmax(0) != ref[0].argmax(0)
+        if bad.any():                                                            # label flips only inside the reference's top-2 tie band
+            top2 = np.sort(ref[0], axis=0)[-2:]
+            assert ((top2[1] - top2[0])[bad] <= 2 * err).all(), (t, int(bad.sum()))
         lab = np.zeros((H, W), np.int32)
         e.argmax(out, lab)
-        assert (lab == ref[0].argmax(0)).all()
+        assert (lab == out[0].argmax(0)).all()                                   # the argmax kernel on the kernels' own logits: first max wins
     # forward_labels == argmax(forward) on a fresh stream of the same frames
     e.reset()
     assert e.fifo_len() == 0
