@@ -23,16 +23,110 @@ def env_world():
 
 
 def init_distributed(backend=None):
+    """One process per GPU; rendezvous from the launcher's environment (torch.distributed.run / bench.py's self-launch).  There is
+    no default port: two jobs on one node falling back to the same fixed port would join each other's rendezvous or fail to bind."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            raise RuntimeError("tdnet_amd.parallel.init_distributed: WORLD_SIZE=%d but MASTER_PORT is not set -- start the ranks with "
+                               "`python -m torch.distributed.run --master-addr 127.0.0.1 --master-port <free port> ...` or "
+                               "`python bench.py --gpus N` (which picks a free port itself)" % world)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(device_index, sysfs="/sys"):
+    """NUMA node of the GPU behind HIP ordinal `device_index` (PCI address from the device properties ->
+    /sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node), or -1 when the platform does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")) as f:
+            return int(f.read().strip())
+    except Exception:
+        return -1
+
+
+def plan_affinity(local_rank, local_world, node_of_rank, allowed, node_cpus):
+    """Pure planning (tested on the CPU): the CPUs rank `local_rank` should run on.  Ranks whose GPUs share a NUMA node split that
+    node's allowed CPUs evenly, in rank order; a rank whose node is unknown (-1) or has no allowed CPU shares ALL allowed CPUs
+    evenly with the other such ranks.  Every rank gets at least one CPU; the sets of two ranks are disjoint whenever there are
+    at least as many CPUs as ranks in the group."""
+    allowed = sorted(allowed)
+    node = node_of_rank[local_rank]
+    pool = [c for c in node_cpus.get(node, []) if c in set(allowed)] if node >= 0 else []
+    if pool:
+        group = [r for r in range(local_world) if node_of_rank[r] == node]
+    else:
+        node = -1
+        group = [r for r in range(local_world) if node_of_rank[r] < 0 or not [c for c in node_cpus.get(node_of_rank[r], []) if c in set(allowed)]]
+        pool = allowed
+    i, n = group.index(local_rank), len(group)
+    lo, hi = i * len(pool) // n, (i + 1) * len(pool) // n
+    mine = pool[lo:hi] or [pool[min(lo, len(pool) - 1)]]
+    return node, mine
+
+
+def pin_rank(local_rank, local_world, device_indices=None, sysfs="/sys", apply=True):
+    """Pins this process to the cores next to its GPU (8 launcher processes, each issuing ~25 k kernel launches per
+    second, must not migrate across sockets or sit on each other's cores) and sets the intra-op thread count to match
+    (torch.distributed.run exports OMP_NUM_THREADS=1 to every rank).  Returns what was done, for the bench line."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:                                             # not Linux
+        return {"pinned": False, "why": "sched_getaffinity unavailable"}
+    dev = list(range(local_world)) if device_indices is None else list(device_indices)
+    nodes = [gpu_numa_node(d, sysfs) if torch.cuda.is_available() else -1 for d in dev]
+    node_cpus = {}
+    for nd in set(nodes):
+        if nd >= 0:
+            try:
+                with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % nd)) as f:
+                    node_cpus[nd] = _parse_cpulist(f.read())
+            except OSError:
+                node_cpus[nd] = []
+    node, cpus = plan_affinity(local_rank, local_world, nodes, allowed, node_cpus)
+    info = {"pinned": False, "numa_node": node, "cpus": "%d-%d" % (cpus[0], cpus[-1]) if cpus == list(range(cpus[0], cpus[-1] + 1)) else ",".join(map(str, cpus)),
+            "n_cpus": len(cpus)}
+    if apply:
+        try:
+            os.sched_setaffinity(0, cpus)
+            info["pinned"] = True
+        except OSError as e:
+            info["why"] = str(e)
+    nthr = max(1, min(len(cpus), 32))
+    os.environ["OMP_NUM_THREADS"] = str(nthr)
+    try:
+        torch.set_num_threads(nthr)
+    except RuntimeError:
+        pass
+    info["omp_num_threads"] = nthr
+    return info
+
+
+def gather_strings(text, world, device):
+    """Every rank contributes a short ASCII string; every rank returns the list (fixed 256-byte rows through one all-reduce)."""
+    row = torch.zeros(world, 256, dtype=torch.int64, device=device)
+    b = text.encode("ascii", "replace")[:256]
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    row[rank, :len(b)] = torch.tensor(list(b), dtype=torch.int64)
+    row = allreduce_sum(row).cpu()
+    return [bytes(int(v) for v in r if v).decode("ascii") for r in row]
 
 
 def clips_of_rank(n_clips, rank, world):

@@ -84,3 +84,25 @@ def test_single_rank_line_and_no_gpu_refusal():
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         out = r.stdout.decode(errors="replace")
         assert r.returncode != 0 and "refusing" in out and not [l for l in out.splitlines() if l.startswith("{")]
+
+
+def test_eight_ranks_the_size_of_the_scaling_run():
+    """the first time this code meets 8 ranks must not be the driver's RCCL run.  The same dry run at world_size 8
+    (the line carries every rank's CPU placement and host launch cost), and a perturbed LAST rank must fail all eight."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    line = _last_json(out)
+    assert line["n_gpus"] == 8 and line["world_size_seen"] == 8 and line["backend"] == "gloo"
+    assert len(line["per_rank_fps"]) == 8 and len(line["init_s_per_rank"]) == 8
+    assert len(line["host_launch_us_per_frame"]) == 8 and all(v >= 0 for v in line["host_launch_us_per_frame"])
+    assert isinstance(line["cpu_affinity"], list) and len(line["cpu_affinity"]) == 8 and all("cpus" in s for s in line["cpu_affinity"])
+    assert line["omp_num_threads"] >= 1
+    assert line["rank_check"]["ranks_agree"] is True
+    assert sum(1 for l in out.splitlines() if l.startswith("{")) == 1
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--perturb-rank", "7"],
+                       env=_env(), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode != 0, out[-2000:]
+    assert _last_json(out)["rank_check"]["ranks_agree"] is False

@@ -139,3 +139,70 @@ def test_path_parallel_schedule_matches_sequential():
             assert sorted(res[r]) == list(range(r, T, W))              # rank g serves t = g mod W
             merged.update(res[r])
         assert merged == _pp_sequential(T, P, depth)                   # every rank's FIFO went through the sequential states
+
+
+# ---- world_size 8: the size the driver's scaling run uses first ------------------------------------
+def test_eight_rank_gloo_collectives_and_path_parallel():
+    """The same plumbing at world_size 8: weight broadcast into 8 processes, clip sharding, the confusion-matrix / timing reductions,
+    gather_strings, and the path-parallel schedule with world 8 > FIFO depth + 1 (every entry a frame needs comes from peers that are
+    more than a FIFO away in rank order) incl. a stream shorter than one round and a ragged last round."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in ps)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert sorted(c for r in res for c in r[2]) == [0, 1, 2, 3, 4]                  # 5 clips on 8 ranks: every clip exactly once, 3 ranks idle
+    assert all(r[3] == sum(10 + k for k in range(8)) for r in res)
+    assert all(r[4] == 8.0 for r in res)
+    for (W, T, P, depth) in ((8, 19, 4, 3), (8, 5, 4, 3), (8, 16, 2, 1)):
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_pp_worker, args=(r, W, port, q, T, P, depth)) for r in range(W)]
+        for p in ps:
+            p.start()
+        out = dict(q.get(timeout=600) for _ in ps)
+        for p in ps:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        merged = {}
+        for r in range(W):
+            assert sorted(out[r]) == list(range(r, T, W))
+            merged.update(out[r])
+        assert merged == _pp_sequential(T, P, depth)
+
+
+def test_init_distributed_has_no_default_port(monkeypatch):
+    """A fixed fallback port (29500 until round 3) lets two jobs on one node meet in each other's rendezvous: without MASTER_PORT the
+    call must fail loudly, before any process group exists."""
+    for k in ("MASTER_PORT", "MASTER_ADDR"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        parallel.init_distributed("gloo")
+    assert not dist.is_initialized()
+
+
+def test_affinity_plan():
+    """plan_affinity: ranks split the CPUs of their GPU's NUMA node in rank order, disjointly; unknown nodes share what is allowed."""
+    node_cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    got = [parallel.plan_affinity(r, 8, nodes, range(128), node_cpus) for r in range(8)]
+    assert [g[0] for g in got] == nodes
+    assert all(len(g[1]) == 16 for g in got)
+    assert sorted(c for g in got for c in g[1]) == list(range(128))                # disjoint and complete
+    assert set(got[5][1]) <= set(node_cpus[1])
+    # a cgroup that allows only part of node 0, nothing of node 1: ranks on node 1 fall back to sharing the allowed set
+    got = [parallel.plan_affinity(r, 8, nodes, range(8), node_cpus) for r in range(8)]
+    assert all(len(g[1]) >= 1 and set(g[1]) <= set(range(8)) for g in got)
+    assert sorted(c for g in got[:4] for c in g[1]) == list(range(8))
+    assert [g[0] for g in got[4:]] == [-1] * 4
+    # no NUMA information at all, fewer CPUs than ranks: everyone still gets a CPU
+    got = [parallel.plan_affinity(r, 8, [-1] * 8, range(4), {}) for r in range(8)]
+    assert all(len(g[1]) == 1 for g in got)
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
