@@ -9,6 +9,12 @@ Differences from the reference, on purpose:
   * a missing checkpoint file is an ERROR unless `synthetic_seed` is given (the reference prints and silently keeps
     random init, td4_psp18.py:239-240);
   * `reset()` empties the K/Q/V FIFO so a second clip can be fed (the reference has no reset);
+  * a batch of N > 1 frames is N independent video streams in the reference too (every cached tensor, LayerNorm plane and softmax is
+    per sample; td4_psp18.py:123-154 with [N, Lk, 64] queue entries): here sample i runs on its own handle (own FIFO), created the
+    first time a batch that large arrives.  Like the reference's queues, the batch size must not change while frames are cached;
+  * `load_state_dict(strict=False)` drops unexpected keys and reports missing ones like nn.Module does, but a missing tensor has no
+    "constructor initialisation" to fall back on here: it is taken from the seeded synthetic generator when `synthetic_seed` is given
+    and is an error at the first frame otherwise;
   * td4 accepts all three backbones the reference's constructor accepts (td4_psp18.py:52-66), including the never-shipped
     resnet50 (d_model = d_v = 2048): its attention runs as four 512-channel launches.
 """
@@ -47,7 +53,13 @@ class _TDNetBase(nn.Module):
         self._state = None
         self._engine = None
         self._engine_key = None
+        self._init_batch_state()
         self.pretrained_mp_load()
+
+    def _init_batch_state(self):
+        self._extra_engines = []                                       # handles of the batch samples 1 .. N-1 (own FIFO each)
+        self._missing_keys = []
+        self._batch = None                                             # batch size of the frames currently cached
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def pretrained_mp_load(self):
@@ -61,10 +73,28 @@ class _TDNetBase(nn.Module):
                                         "synthetic weights)".format(self.psp_path))
 
     def load_state_dict(self, state_dict, strict=True):
-        """Strict key/shape check against the reference inventory happens in the C library at finalize time."""
-        self._state = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in state_dict.items()}
-        self._engine = None
-        return self
+        """strict=True (td4_psp18.py:237): the key/shape check against the reference inventory happens in the C library at finalize
+        time and raises RuntimeError.  strict=False: unexpected keys are dropped and missing ones recorded, as nn.Module does; the
+        result is nn.Module's (missing_keys, unexpected_keys) tuple.  Tensors of the wrong size raise in both modes, like torch."""
+        from torch.nn.modules.module import _IncompatibleKeys
+        st = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in state_dict.items()}
+        missing, unexpected = [], []
+        if not strict:
+            known = arch.state_dict_shapes(self.spec, 1, 1)                # the key inventory does not depend on the feature size
+            unexpected = [k for k in st if k not in known]
+            missing = [k for k in known if k not in st and not k.endswith("num_batches_tracked")
+                       and not (k.startswith("pretrained") and (k.endswith(".fc.weight") or k.endswith(".fc.bias")))]
+            st = {k: v for k, v in st.items() if k in known}
+        self._state = st
+        self._missing_keys = missing
+        self._close_engines()
+        return _IncompatibleKeys(missing, unexpected)
+
+    def _close_engines(self):
+        for e in [self._engine] + list(getattr(self, "_extra_engines", [])):
+            if e is not None:
+                e.close()
+        self._engine, self._engine_key, self._extra_engines, self._batch = None, None, [], None
 
     def state_dict(self, *a, **k):
         """{name: CPU tensor} with the reference's keys, so torch.save(model.state_dict()) round-trips like the reference's
@@ -80,6 +110,19 @@ class _TDNetBase(nn.Module):
     def _get_engine(self, img):
         n, c, H, W = img.shape
         return self._engine_for(H, W, img.device.index or 0, n)
+
+    def _engines_for_batch(self, img):
+        """One handle per batch sample: sample 0 on the model's own handle, sample i > 0 on its own (same weights, own FIFO)."""
+        n, c, H, W = img.shape
+        first = self._engine_for(H, W, img.device.index or 0, n)
+        if self._batch is not None and n != self._batch and first.fifo_len() > 0:
+            # the reference's queues hold [N, Lk, .] tensors: a frame with another N fails in torch.bmm (transformer.py:133)
+            raise RuntimeError("Expected batch size %d (the batch size of the cached frames), got %d: reset() the model before feeding "
+                               "streams of another batch size" % (self._batch, n))
+        self._batch = n
+        while len(self._extra_engines) < n - 1:
+            self._extra_engines.append(self._build_engine(H, W, img.device.index or 0, n))
+        return [first] + self._extra_engines[:n - 1]
 
     def ensure_engine(self, H, W, device):
         """Build the handle (weights, workspace, FIFO) from the stream geometry alone, before any frame is seen.  A path-parallel rank
@@ -97,6 +140,10 @@ class _TDNetBase(nn.Module):
         if self._engine is not None:
             raise RuntimeError("input size/device changed from %s to %s: one model instance serves one stream geometry"
                                % (self._engine_key, key))
+        self._engine, self._engine_key = self._build_engine(H, W, dev, n), key
+        return self._engine
+
+    def _build_engine(self, H, W, dev, n=1):
         h, w = arch.feat_size(H), arch.feat_size(W)
         sd = self._state
         if sd is None:
@@ -104,8 +151,15 @@ class _TDNetBase(nn.Module):
                 raise RuntimeError("no weights loaded: give model_path or synthetic_seed (the HIP path never runs on "
                                    "unspecified random init)")
             sd = weights.synth_state_dict(self.spec, h, w, self.synthetic_seed)
-        if self._model_id == 1:
-            sd = {k: v for k, v in sd.items()}
+        if self._missing_keys:                                           # load_state_dict(strict=False) left these without values
+            if self.synthetic_seed is None:
+                raise RuntimeError("load_state_dict(strict=False) left %d tensor(s) without values (first: %s); the reference would run them at "
+                                   "their random initialisation, which this path refuses -- pass synthetic_seed=... to fill them from the "
+                                   "seeded generator" % (len(self._missing_keys), self._missing_keys[0]))
+            fill = weights.synth_state_dict(self.spec, h, w, self.synthetic_seed)
+            sd = dict(sd)
+            for k in self._missing_keys:
+                sd[k] = fill[k]
         ln = sd.get("layer_norm1.ln.weight")
         if ln is not None and tuple(ln.shape) != (h, w):
             # same failure the reference raises from nn.LayerNorm (td4_psp18.py:107-110 hard-codes [97,193])
@@ -116,7 +170,6 @@ class _TDNetBase(nn.Module):
             eng.load_state_dict(sd)
         except TdnetError as e:
             raise RuntimeError("Error(s) in loading state_dict for %s:\n\t%s" % (type(self).__name__, e))
-        self._engine, self._engine_key = eng, key
         return eng
 
     # ---- nn.Module surface used by Testing/test.py:40-41,53 ------------------------------------------------------
@@ -125,32 +178,38 @@ class _TDNetBase(nn.Module):
             raise RuntimeError("expected an image tensor [1,3,H,W]")
         if img.device.type != "cuda":
             raise TdnetError("tdnet_amd runs on MI355X only: got a %s tensor (no CPU fallback)" % img.device.type)
-        if img.shape[0] != 1:
-            raise RuntimeError("batch size must be 1: the K/Q/V FIFO holds one video stream (test.py feeds [1,3,H,W])")
+        if img.shape[0] < 1:
+            raise RuntimeError("expected an image tensor [N,3,H,W] with N >= 1")
         if pos_id not in range(self.path_num):
             raise RuntimeError("pos_id must be t mod %d" % self.path_num)
 
     def forward(self, img, pos_id=0):
         self._check_frame(img, pos_id)
         img = img.contiguous().float()
-        eng = self._get_engine(img)
-        out = torch.empty((1, self.nclass, img.shape[2], img.shape[3]), device=img.device, dtype=torch.float32)
-        eng.forward(img.data_ptr(), pos_id, out.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
+        N = img.shape[0]
+        out = torch.empty((N, self.nclass, img.shape[2], img.shape[3]), device=img.device, dtype=torch.float32)
+        s = torch.cuda.current_stream(img.device).cuda_stream
+        for i, eng in enumerate(self._engines_for_batch(img)):          # N = 1 (test.py:46-53): one handle, one call
+            eng.forward(img[i].data_ptr(), pos_id, out[i].data_ptr(), s)
         return out
 
     def forward_labels(self, img, pos_id=0):
         """model(img,pos_id).max(1)[1] without materialising the full-resolution logits; int32 [1,H,W]."""
         self._check_frame(img, pos_id)
         img = img.contiguous().float()
-        eng = self._get_engine(img)
-        out = torch.empty((1, img.shape[2], img.shape[3]), device=img.device, dtype=torch.int32)
-        eng.forward_labels(img.data_ptr(), pos_id, out.data_ptr(), torch.cuda.current_stream(img.device).cuda_stream)
+        N = img.shape[0]
+        out = torch.empty((N, img.shape[2], img.shape[3]), device=img.device, dtype=torch.int32)
+        s = torch.cuda.current_stream(img.device).cuda_stream
+        for i, eng in enumerate(self._engines_for_batch(img)):
+            eng.forward_labels(img[i].data_ptr(), pos_id, out[i].data_ptr(), s)
         return out
 
     # ---- split frame + cache transport (path-parallel single stream: parallel.PathParallelStream) ------------------
     def encode(self, img, pos_id=0):
         """First half of forward(): backbone + pyramid slice + Encoding; the frame's cache entry is left pending."""
         self._check_frame(img, pos_id)
+        if img.shape[0] != 1:
+            raise RuntimeError("encode(): the split frame serves ONE stream (batch size 1)")
         img = img.contiguous().float()
         eng = self._get_engine(img)
         self._pending_shape = (img.shape[2], img.shape[3], img.device)
@@ -194,8 +253,10 @@ class _TDNetBase(nn.Module):
         self._engine.cache_push(q.data_ptr(), k.data_ptr(), v.data_ptr(), torch.cuda.current_stream(q.device).cuda_stream)
 
     def reset(self):
-        if self._engine is not None:
-            self._engine.reset()
+        for e in [self._engine] + list(self._extra_engines):
+            if e is not None:
+                e.reset()
+        self._batch = None
 
     @property
     def engine(self):

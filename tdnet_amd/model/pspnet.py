@@ -32,6 +32,7 @@ class pspnet(_TDNetBase):
         self._state = None
         self._engine = None
         self._engine_key = None
+        self._init_batch_state()
         self.pretrained_mp_load()
 
     def forward(self, x, pos_id=None):

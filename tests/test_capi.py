@@ -114,8 +114,10 @@ def test_model_classes_mirror_reference_api():
         m(torch.zeros(1, 3, 33, 65), pos_id=0)
     with pytest.raises(_capi.TdnetError):
         m.forward_labels(torch.zeros(1, 3, 33, 65), pos_id=0)
-    with pytest.raises(RuntimeError):                            # forward_labels validates like forward: batch, pos_id, tensor
+    with pytest.raises(_capi.TdnetError):                        # a batch is N streams (td4_psp18.py:216-229) -- and still needs the GPU
         m.forward_labels(torch.zeros(2, 3, 33, 65), pos_id=0)
+    with pytest.raises(RuntimeError):                            # forward_labels validates like forward: batch, pos_id, tensor
+        m.forward_labels(torch.zeros(0, 3, 33, 65), pos_id=0)
     with pytest.raises(RuntimeError):
         m.forward_labels(torch.zeros(1, 3, 33, 65), pos_id=7)
     with pytest.raises(RuntimeError):
@@ -136,3 +138,15 @@ def test_model_classes_mirror_reference_api():
     buf.seek(0)
     back = torch.load(buf)
     assert all(np.array_equal(back[k].numpy(), np.asarray(sd[k])) for k in sd)
+    # load_state_dict(strict=False): nn.Module's bookkeeping -- unexpected keys dropped, missing ones reported (not the unused
+    # pretrainedN.fc.* / num_batches_tracked the library ignores anyway); strict=True keeps everything for the library's strict check
+    part = {k: v for k, v in sd.items() if not k.startswith("enc2.")}
+    part["not.in.the.reference"] = np.zeros(2, np.float32)
+    res = m2.load_state_dict(part, strict=False)
+    assert res.unexpected_keys == ["not.in.the.reference"]
+    assert res.missing_keys and all(k.startswith("enc2.") and not k.endswith("num_batches_tracked") for k in res.missing_keys)
+    assert "not.in.the.reference" not in m2.state_dict()
+    res = m2.load_state_dict(sd, strict=False)
+    assert res.missing_keys == [] and res.unexpected_keys == []
+    res = m2.load_state_dict(part)                                # strict: kept as given; the C library rejects it when the handle is built
+    assert "not.in.the.reference" in m2.state_dict()

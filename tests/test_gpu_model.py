@@ -293,3 +293,42 @@ def test_every_schedule_option_reproduces_the_default_bit_for_bit():
                 for k, val in v.items():
                     assert mv.engine.opts()[k] == val
                 mv.engine.close()
+
+
+def test_batch_of_streams_and_non_strict_loading():
+    """nn.Module contract edges.  (1) A batch of N frames is N independent streams in the reference (queue entries
+    are [N, Lk, .], every plane LayerNorm / softmax is per sample: td4_psp18.py:123-154,216-229): sample i of model(batch) must be bit
+    for bit what a model of its own computes on stream i, through warm-up and steady state; the batch size cannot change while frames
+    are cached.  (2) load_state_dict(strict=False) drops unexpected keys, reports missing ones, and the missing tensors come from the
+    seeded generator (without a seed the first frame raises instead of running on unspecified values)."""
+    H, W, T = 65, 129, 6
+    a = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, T, seed=21)]
+    b = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, T, seed=22)]
+    with torch.no_grad():
+        ma, mb, m2 = make_model("td4", "resnet18", seed=4), make_model("td4", "resnet18", seed=4), make_model("td4", "resnet18", seed=4)
+        for t in range(T):
+            ra, rb = ma(a[t], pos_id=t % 4), mb(b[t], pos_id=t % 4)
+            out = m2(torch.cat([a[t], b[t]], 0), pos_id=t % 4)
+            assert out.shape == (2, 19, H, W)
+            assert torch.equal(out[0:1], ra) and torch.equal(out[1:2], rb), t
+        lab = m2.forward_labels(torch.cat([a[0], b[0]], 0), pos_id=(T % 4))
+        assert lab.shape == (2, H, W)
+        with pytest.raises(RuntimeError, match="batch size"):
+            m2(a[0], pos_id=0)                                          # frames of a 2-stream batch are cached
+        m2.reset()
+        assert torch.equal(m2(a[0], pos_id=0), make_model("td4", "resnet18", seed=4)(a[0], pos_id=0))
+        # strict=False
+        spec = arch.model_spec("td4", 19, "resnet18")
+        sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 4)
+        part = {k: v for k, v in sd.items() if not k.startswith("head3.")}
+        part["module.extra"] = np.zeros(3, np.float32)
+        m3 = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None, synthetic_seed=4).eval().to("cuda")
+        res = m3.load_state_dict(part, strict=False)
+        assert res.unexpected_keys == ["module.extra"] and res.missing_keys and all(k.startswith("head3.") for k in res.missing_keys)
+        assert torch.equal(m3(a[0], pos_id=0), make_model("td4", "resnet18", seed=4)(a[0], pos_id=0))   # the seeded generator filled head3.*
+        m4 = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None).eval().to("cuda")
+        m4.load_state_dict(part, strict=False)
+        with pytest.raises(RuntimeError, match="strict=False"):
+            m4(a[0], pos_id=0)
+        with pytest.raises(RuntimeError):
+            m4.load_state_dict(part, strict=True); m4(a[0], pos_id=0)   # strict: the unexpected / missing keys are errors (td4_psp18.py:237)
