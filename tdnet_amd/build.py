@@ -1,6 +1,7 @@
 """Build libtdnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-The library is STAMPED with a hash of the sources it was built from (every file under csrc/ + include/tdnet.h): the hash is
+The library is STAMPED with a hash of what it was built from (every *.h / *.hip under csrc/ + include/tdnet.h + the compile flags + the
+ROCm release): the hash is
 compiled into tdnet_version(), build() rebuilds whenever the stamp of the existing .so differs from the sources on disk (mtimes are
 not trusted: the prebuilt .so travels to the GPU box with the tree), and smoke() / tests/test_gpu_harness.py assert that the
 library a GPU process loaded carries the hash of the shipped sources -- so a green GPU run proves it ran HEAD's kernels.
@@ -18,13 +19,29 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "tdnet.h")
 STAMP_MARK = b"tdnet-src-hash:"
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off"]
+
+
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*"))) + [HEADER]
+    """The regular *.h / *.hip files of csrc/ + the C-ABI header: an editor backup, a stray directory or a build product next to them
+    neither changes the stamp nor breaks the hash."""
+    return sorted(p for p in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(p) and p.endswith((".h", ".hip"))) + [HEADER]
+
+
+def toolchain_id():
+    """ROCm release of the image (the compiler that turns the sources into the .so); the same file on the GPU box."""
+    try:
+        with open("/opt/rocm/.info/version") as f:
+            return f.read().strip()
+    except OSError:
+        return "unknown"
 
 
 def source_hash():
-    """sha256 over (file name, content) of every source, 16 hex digits."""
+    """sha256 over (file name, content) of every source + the compile flags + the ROCm release, 16 hex digits: a change of
+    -ffp-contract or of the target arch rebuilds like a change of a kernel does."""
     h = hashlib.sha256()
+    h.update((" ".join(FLAGS) + "\0" + toolchain_id() + "\0").encode())
     for p in sources():
         h.update(os.path.basename(p).encode() + b"\0")
         with open(p, "rb") as f:
@@ -48,8 +65,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
-           '-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, "td_model.hip"), "-o", OUT]
+    cmd = [hipcc] + FLAGS + ['-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, "td_model.hip"), "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

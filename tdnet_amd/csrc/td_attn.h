@@ -438,7 +438,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention(AttnArgs p) {
                 f32x4 o = {acc[0][r] * inv, acc[1][r] * inv, acc[NT - 2][r] * inv, acc[NT - 1][r] * inv};
                 o = o + bv;
                 o = o + rv[i];
-                td_buf_st4(out_buf, off, 0u, o);
+                td_buf_st4(out_buf, off, o);
                 if (ln && live) { const f32x4 d = o - kshift; s1 = s1 + d; s2 = s2 + d * d; }
             } else {
                 f32x2 o = {acc[0][r] * inv + bv[0], acc[1][r] * inv + bv[1]};

@@ -131,7 +131,7 @@ TD_DEV void td_store_acc16(const f32x16 (&acc)[MT][2], float* out, const float* 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = td_activate(v[e], slope);
             }
-            td_buf_st4(out_buf, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes, 0u, v);
+            td_buf_st4(out_buf, base + (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes, v);
             TD_SCHED_FENCE();                                       // one row pair at a time (bounds the live registers)
         }
     }

@@ -99,7 +99,7 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
 #pragma unroll
                     for (int e = 0; e < 4; ++e) oh[e] = (_Float16)v[e];
                     td_buf_st2(out_buf, base_o + rows * EO, 0u, __builtin_bit_cast(f32x2, oh));
-                } else td_buf_st4(out_buf, base_o + rows * EO, 0u, v);
+                } else td_buf_st4(out_buf, base_o + rows * EO, v);
                 TD_SCHED_FENCE();
             }
         }

@@ -734,7 +734,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 1) k_conv_dma_w64(ConvArgs p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) oh[e] = (_Float16)v[e];
                     td_buf_st2(out_buf, base_o + rows * EO, 0u, __builtin_bit_cast(f32x2, oh));
-                } else td_buf_st4(out_buf, base_o + rows * EO, 0u, v);
+                } else td_buf_st4(out_buf, base_o + rows * EO, v);
             }
         } else {
             td_store_acc_h<1, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, tile * G::BM + wave * 32, 0, lane);

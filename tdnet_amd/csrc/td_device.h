@@ -42,10 +42,17 @@ TD_DEV f32x4 td_buf_ld4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
 TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b.r, voff_bytes, soff_bytes, 0));
 }
-// 16-byte store; dropped by the hardware when voff_bytes is outside the buffer (the range check ignores soffset, as for loads)
-TD_DEV void td_buf_st4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x4 v) {
+// 16-byte store; dropped by the hardware when voff_bytes is outside the buffer.  There is deliberately NO soffset parameter: a buffer
+// store of more than 64 bits keeps reading its data VGPRs after issue, and a VALU write to them in the next cycles corrupts the
+// stored value.  LLVM's hazard recognizer inserts the wait state only when the soffset field is NOT a register
+// (GCNHazardRecognizer::createsVALUHazard: "this hazard only exists if the instruction is not using a register in the soffset field"),
+// which does not hold on gfx950: with the wave-uniform address part in an SGPR soffset, k_wino4_out_c<4> stored wrong odd dwords in
+// lanes 12-15 of every 16, non-deterministically (tools/wino_vw_probe.py, profiles/r03d_wino_vw4_fix_probe.txt; 4- and 8-byte stores
+// and the emulator are right, a pause BEFORE the store does not help).  With the literal 0 the compiler sees the hazard and spaces the
+// overwrite; a wave-uniform offset belongs in voff_bytes.
+TD_DEV void td_buf_st4(TdBuf b, unsigned voff_bytes, f32x4 v) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b.r, voff_bytes, soff_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b.r, voff_bytes, 0, 0);
 }
 TD_DEV void td_buf_st2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x2 v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

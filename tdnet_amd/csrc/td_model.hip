@@ -292,6 +292,7 @@ struct tdnet {
     // classifier / upsample instead of beside the next frame's stem and layer1): a second V' buffer, and what the launch assumed
     float* vp2 = nullptr;
     float* vp_read = nullptr;                                          // the V' the final attention of the current frame reads
+    bool chain_stale = false;                                          // a pre-launched chain was abandoned and may still be reading cache slots
     bool pre_valid = false;                                            // a chain was pre-launched ...
     int pre_pos = -1;                                                  // ... for this pos_id ...
     unsigned pre_epoch = 0, fifo_epoch = 0;                            // ... with the FIFO as it was at this epoch (reset / external pushes bump it)
@@ -653,9 +654,16 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     }
     const int C = n->C, DV = n->DV, FS = C / (2 * 4), NC = n->cfg.nclass;
     plan_chains(n);
-    n->paths.resize(n->P);
     char b[160];
-    for (int p = 0; p < n->P; ++p) {
+    // The row-parity plan (plan_chains / conv_chainable) and the per-layer decision (make_conv_layer: Winograd F(4x4) + chunkable) are two
+    // predicates over the same facts.  Should they ever disagree, the chains are a schedule, not a requirement: the layers are rebuilt
+    // unchained (attempt 1) instead of failing the load.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    bool plan_mismatch = false;
+    for (auto& pl : n->paths) free_path(pl);
+    n->paths.clear();
+    n->paths.resize(n->P);
+    for (int p = 0; p < n->P && !plan_mismatch; ++p) {
         PathLayers& L = n->paths[p];
         L.pid = p & 1;                                                 // td4_psp18.py:80-83 / td2_psp50.py:76-77
         snprintf(b, sizeof(b), "pretrained%d", p + 1);
@@ -692,7 +700,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
                 if (make_conv_layer(B.c1, f1.w, f1.b, s.cout, s.cin, 3, s.stride, s.dil1, 1, false, M, n->opts, -1, k1)) return -1;
                 Folded f2 = fold(n, bp + ".conv2.weight", "", bp + ".bn2", s.cout);
                 if (make_conv_layer(B.c2, f2.w, f2.b, s.cout, s.cout, 3, 1, s.dil2, 1, false, M, n->opts, -1, k2)) return -1;
-                if ((k1 > 1 && B.c1.chunks != k1) || (k2 > 1 && B.c2.chunks != k2)) return td_fail("internal: chain plan and conv layers disagree");
+                if ((k1 > 1 && B.c1.chunks != k1) || (k2 > 1 && B.c2.chunks != k2)) plan_mismatch = true;
             }
             B.has_ds = s.ds;
             if (s.ds) {
@@ -701,7 +709,9 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             }
             L.blocks.push_back(B);
             ch = oh; cw = ow;
+            if (plan_mismatch) break;
         }
+        if (plan_mismatch) break;
         if (ch != n->h || cw != n->w) return td_fail("internal: feature size mismatch %dx%d vs %dx%d", ch, cw, n->h, n->w);
         if (n->cfg.model == 1) {                                       // PSPHead (pspnet.py:102-115): full pyramid, conv3x3, classifier
             const int F4 = C / 4;
@@ -760,6 +770,10 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         if (make_conv_layer(L.head3, fh.w, fh.b, n->MID, DV, 3, 1, 1, 1, false, n->Lq, n->opts)) return -1;
         if (upload(&L.d_cls_w, T(n, hp + ".4.weight")) || upload(&L.d_cls_b, T(n, hp + ".4.bias"))) return -1;
         (void)NC;
+    }
+    if (!plan_mismatch) break;
+    if (attempt == 1) return td_fail("internal: conv layers ask for row-parity chunks without a chain plan");
+    n->seg_block = -1; n->seg_conv = 0;                                 // rebuild every layer with chunks = 1
     }
     // precision = 1: every map between two convs of the backbone is stored as fp16 (half the conv input / output bytes; td_conv_h.h).
     // The rim: the 7x7 stem runs on the fp16 MFMA from the fp32 image and writes an fp16 map (the 3x3 deep stem's first conv stays an
@@ -1348,17 +1362,22 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s, int
         TD_HIP(hipMemcpyAsync(n->feat, n->v_cur, (size_t)n->Lq * DV * sizeof(float), hipMemcpyDeviceToDevice, s));
         feat = n->feat;
     }
-    // FIFO push (td4_psp18.py:153-154, :123-134): host bookkeeping only -- the entry's data was written by encode_frame
-    {
+    // FIFO push (td4_psp18.py:153-154, :123-134): host bookkeeping only -- the entry's data was written by encode_frame.  It is the
+    // LAST thing a frame does (a frame whose head fails to launch is not in the FIFO), except with overlap bit 128, whose pre-launched
+    // chain needs the FIFO as the next frame will see it: there the commit precedes the head.
+    auto commit = [&]() {
+        if (n->pending_slot < 0) return;
         const int slot = n->pending_slot;
         n->pending_slot = -1;
         fifo_commit(n, slot);
-    }
+    };
+    const bool prelaunch = prelaunch_pos >= 0 && (n->opts.overlap & 128) && n->vp2;
+    if (prelaunch) commit();
     // overlap bit 128: the NEXT frame's cache-only chain starts here, when this frame's final attention is done -- beside the HBM-bound
     // rest of this frame (matrix pipes idle) instead of beside the next frame's stem and layer1, which it slowed by 20-50 %.  It assumes
     // the next call is pos_id + 1 on an untouched FIFO; forward_lowres checks and falls back to launching the chain itself.
     n->pre_valid = false;
-    if (prelaunch_pos >= 0 && (n->opts.overlap & 128) && n->vp2 && (int)n->fifo.size() >= n->FIFO) {
+    if (prelaunch && (int)n->fifo.size() >= n->FIFO) {
         float* target = n->vp_read == n->vp ? n->vp2 : n->vp;
         if (launch_chain(n, n->paths[prelaunch_pos], s, target, n->fifo[0], n->P == 4 ? n->fifo[1] : -1, n->P == 4 ? n->fifo[2] : -1)) return -1;
         n->pre_valid = true; n->pre_pos = prelaunch_pos; n->pre_epoch = n->fifo_epoch; n->pre_vp = target;
@@ -1375,7 +1394,18 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s, int
     } else
     TD_TRY(run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s));
     TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
-    return n->failed ? -1 : 0;
+    if (n->failed) return -1;
+    commit();
+    return 0;
+}
+
+// overlap bit 128: a pre-launched chain that will never be used (reset, an external cache push) may still be READING cache slots on the
+// side stream; whoever writes slots next -- the next frame's Encoding, a pushed entry -- first waits for it on its own stream.
+static int retire_stale_chain(tdnet* n, hipStream_t s) {
+    if (!n->chain_stale) return 0;
+    n->chain_stale = false;
+    TD_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
+    return 0;
 }
 
 static int frame_checks(tdnet* n, int pos_id, const char* who) {
@@ -1397,7 +1427,7 @@ static void rejoin_streams(tdnet* n, hipStream_t s) {
 static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s);
 static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
     const int rc = forward_lowres_impl(n, img, pos_id, s);
-    if (rc && n && n->finalized) rejoin_streams(n, s);
+    if (rc && n && n->finalized) { rejoin_streams(n, s); n->pending_slot = -1; }   // the failed frame is dropped: it never reaches the FIFO
     return rc;
 }
 static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s) {
@@ -1406,6 +1436,7 @@ static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream
     PathLayers& L = n->paths[pos_id];
     n->nrec = 0;
     n->failed = false;
+    TD_TRY(retire_stale_chain(n, s));
     const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
     if (steady) {
         if (n->pre_valid && n->pre_pos == pos_id && n->pre_epoch == n->fifo_epoch) n->vp_read = n->pre_vp;   // launched at the end of the previous frame
@@ -1459,6 +1490,7 @@ extern "C" int tdnet_encode(tdnet_t* n, const float* img, int pos_id, void* stre
     if (n->pending_slot >= 0) return td_fail("tdnet_encode: the previous encoded frame has not been propagated");
     n->nrec = 0;
     n->failed = false;
+    TD_TRY(retire_stale_chain(n, (hipStream_t)stream));
     if (encode_frame(n, n->paths[pos_id], img, (hipStream_t)stream)) { rejoin_streams(n, (hipStream_t)stream); return -1; }
     n->pending_pos = pos_id;
     TD_HIP(hipGetLastError());
@@ -1469,7 +1501,7 @@ static int propagate_lowres(tdnet* n, hipStream_t s) {
     PathLayers& L = n->paths[n->pending_pos];
     const bool steady = (int)n->fifo.size() >= n->FIFO;
     n->pre_valid = false;
-    if ((steady && launch_chain_now(n, L, s)) || finish_frame(n, L, steady, s)) { rejoin_streams(n, s); return -1; }
+    if ((steady && launch_chain_now(n, L, s)) || finish_frame(n, L, steady, s)) { rejoin_streams(n, s); n->pending_slot = n->pending_pos = -1; return -1; }
     return 0;
 }
 extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
@@ -1518,6 +1550,8 @@ extern "C" int tdnet_cache_push(tdnet_t* n, const float* q, const float* k, cons
     if (slot < 0) return td_fail("internal: no free cache slot");
     const CacheSlot& c = n->slots[slot];
     hipStream_t s = (hipStream_t)stream;
+    if (n->pre_valid) { n->chain_stale = true; n->pre_valid = false; }  // the FIFO changes behind a pre-launched chain's back
+    TD_TRY(retire_stale_chain(n, s));
     TD_HIP(hipMemcpyAsync(c.q, q, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     TD_HIP(hipMemcpyAsync(c.k, k, (size_t)n->Lk * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     TD_HIP(hipMemcpyAsync(c.v, v, (size_t)n->Lk * n->DV * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1528,6 +1562,7 @@ extern "C" int tdnet_cache_push(tdnet_t* n, const float* q, const float* k, cons
 extern "C" int tdnet_reset(tdnet_t* n) {
     if (!n) return td_fail("tdnet_reset: null handle");
     n->fifo_epoch++;
+    if (n->pre_valid) n->chain_stale = true;                           // it may still be reading slots: the next writer waits (retire_stale_chain)
     n->pre_valid = false;
     n->fifo.clear();
     n->last_slot = -1;

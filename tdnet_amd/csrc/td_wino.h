@@ -163,7 +163,7 @@ TD_KERNEL void k_wino_out(WinoArgs p) {
                 o = o + rs[r][c];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
-                td_buf_st4(wb.out, off[r][c], 0u, o);
+                td_buf_st4(wb.out, off[r][c], o);
             }
         }
     }
@@ -275,7 +275,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out(WinoArgs p) {
                 o = o + rs[r][c];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
-                td_buf_st4(wb.out, (oky[r] && okx[c]) ? offy[r] + offx[c] : TD_BUF_OOB, 0u, o);
+                td_buf_st4(wb.out, (oky[r] && okx[c]) ? offy[r] + offx[c] : TD_BUF_OOB, o);
             }
         }
     }
@@ -302,26 +302,13 @@ template <> struct WinoVec<2> {
     TD_DEV_MEMBER void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st2(b, v, s, x); }
     TD_DEV_MEMBER T act(T x, float slope) { x[0] = td_activate(x[0], slope); x[1] = td_activate(x[1], slope); return x; }
 };
-#ifndef TD_VW4_FIX
-#define TD_VW4_FIX 1
-#endif
 template <> struct WinoVec<4> {
     typedef f32x4 T;
-    // TD_VW4_FIX bit 1: the wave-uniform part of the address is added into the per-lane offset instead of riding in the SGPR offset
-    // of a 16-byte buffer access (tools/wino_vw_probe.py: with soffset, this kernel's results were wrong on MI355X in the odd dwords
-    // of lanes 12-15 of every 16 -- non-deterministically, never in the emulator, never with 4- or 8-byte accesses); bit 2: a pause
-    // between the arithmetic that produces a vector and the store that reads it.
-    TD_DEV_MEMBER T ld(TdBuf b, unsigned v, unsigned s) {
-        if (TD_VW4_FIX & 1) return td_buf_ld4(b, v == TD_BUF_OOB ? v : v + s, 0u);
-        return td_buf_ld4(b, v, s);
-    }
-    TD_DEV_MEMBER void st(TdBuf b, unsigned v, unsigned s, T x) {
-#if (TD_VW4_FIX & 2) && !defined(TD_EMU)
-        asm volatile("s_nop 7" : "+v"(x));
-#endif
-        if (TD_VW4_FIX & 1) td_buf_st4(b, v == TD_BUF_OOB ? v : v + s, 0u, x);
-        else td_buf_st4(b, v, s, x);
-    }
+    // The wave-uniform part of the address is added into the per-lane offset: a 16-byte buffer STORE must not carry it in the SGPR
+    // soffset (td_device.h td_buf_st4: the >64-bit store-data hazard the compiler does not see behind a register soffset).  The load
+    // does the same -- not known to be needed, but it is the form that was verified on MI355X together with the store.
+    TD_DEV_MEMBER T ld(TdBuf b, unsigned v, unsigned s) { return td_buf_ld4(b, v == TD_BUF_OOB ? v : v + s, 0u); }
+    TD_DEV_MEMBER void st(TdBuf b, unsigned v, unsigned s, T x) { td_buf_st4(b, v == TD_BUF_OOB ? v : v + s, x); }
     TD_DEV_MEMBER T act(T x, float slope) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = td_activate(x[e], slope);

@@ -125,11 +125,8 @@ TD_DEV f32x2 td_buf_ld2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes) {
     return v;
 }
 
-TD_DEV void td_buf_st4(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x4 v) {
-    if ((unsigned long long)voff_bytes + 16 <= b.bytes) {
-        if ((unsigned long long)voff_bytes + soff_bytes + 16 > b.bytes) abort();
-        memcpy(const_cast<char*>(b.p) + soff_bytes + voff_bytes, &v, 16);
-    }
+TD_DEV void td_buf_st4(TdBuf b, unsigned voff_bytes, f32x4 v) {      // no soffset: see csrc/td_device.h
+    if ((unsigned long long)voff_bytes + 16 <= b.bytes) memcpy(const_cast<char*>(b.p) + voff_bytes, &v, 16);
 }
 TD_DEV void td_buf_st2(TdBuf b, unsigned voff_bytes, unsigned soff_bytes, f32x2 v) {
     if ((unsigned long long)voff_bytes + 8 <= b.bytes) {
