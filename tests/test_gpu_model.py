@@ -193,7 +193,10 @@ def test_uncalibrated_reference_init(wino):
     must pass: Winograd's extra rounding error is a constant factor (measured on the CPU model of the kernels,
     tests/numerics_winograd.py reference-init: rms 1.0x / 2.3x, max 1.8x / 3.0x the direct path's), not something the calibrated
     weights were hiding."""
-    H, W, T = 129, 257, 5
+    _reference_init_stress(129, 257, 5, wino)
+
+
+def _reference_init_stress(H, W, T, wino, gc_bound=None):
     spec = arch.model_spec("td4", 19, "resnet18")
     sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0, init="reference")
     ref32 = tdnet_ref.TDNetRef(spec, sd)
@@ -202,6 +205,8 @@ def test_uncalibrated_reference_init(wino):
     m.load_state_dict(sd)
     tdnet_ref.tune_threads()
     e_gpu, e_cpu, s_gpu, s_cpu, n, tmax, e_gc = 0.0, 0.0, 0.0, 0.0, 0, 0.0, 0.0
+    edges = np.array([0.0, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, np.inf])
+    gap_hist, flip_hist, flips_gc = np.zeros(6, np.int64), np.zeros(6, np.int64), 0
     with torch.no_grad():
         for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
             xt = torch.from_numpy(x)
@@ -213,14 +218,33 @@ def test_uncalibrated_reference_init(wino):
             tmax = max(tmax, float(np.abs(truth).max()))
             e_gpu, e_cpu = max(e_gpu, float(np.abs(dg).max())), max(e_cpu, float(np.abs(dc).max()))
             s_gpu, s_cpu, n = s_gpu + float((dg ** 2).sum()), s_cpu + float((dc ** 2).sum()), n + dg.size
+            top2 = np.sort(truth[0], axis=0)[-2:]
+            gap = top2[1] - top2[0]
             bad = out[0].argmax(0) != truth[0].argmax(0)
+            gap_hist += np.histogram(gap, edges)[0]
+            flip_hist += np.histogram(gap[bad], edges)[0]
+            flips_gc += int((out[0].argmax(0) != cpu[0].argmax(0)).sum())
             if bad.any():
-                top2 = np.sort(truth[0], axis=0)[-2:]
-                assert ((top2[1] - top2[0])[bad] <= 2 * float(np.abs(dg).max())).all(), (wino, t, "label flip outside the tie band")
+                assert (gap[bad] <= 2 * float(np.abs(dg).max())).all(), (wino, t, "label flip outside the tie band")
     r_gpu, r_cpu = (s_gpu / n) ** 0.5, (s_cpu / n) ** 0.5
-    print("reference init, winograd=%d: max|truth| %.1f; max err gpu %.2e (%.1e of max|truth|) vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f); max|gpu - cpu| %.2e"
-          % (wino, tmax, e_gpu, e_gpu / tmax, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu, e_gc))
+    print("reference init %dx%d, winograd=%d, %d frames: max|truth| %.1f; max err gpu %.2e (%.1e of max|truth|) vs cpu-fp32 %.2e (x%.2f); rms gpu %.2e vs cpu-fp32 %.2e (x%.2f); max|gpu - cpu| %.2e (x%.2f of the cpu's own error)"
+          % (H, W, wino, T, tmax, e_gpu, e_gpu / tmax, e_cpu, e_gpu / e_cpu, r_gpu, r_cpu, r_gpu / r_cpu, e_gc, e_gc / e_cpu))
+    print("  top-2 gap of the fp64 truth, pixels per decade [0,1e-4) [1e-4,1e-3) [1e-3,1e-2) [1e-2,1e-1) [1e-1,1) [1,inf): %s; labels differing from the truth per decade: %s; labels differing from the fp32 CPU path: %d of %d"
+          % (gap_hist.tolist(), flip_hist.tolist(), flips_gc, int(gap_hist.sum())))
     assert e_gpu <= 4.0 * e_cpu and r_gpu <= 3.0 * r_cpu, (wino, tmax, e_gpu, e_cpu, r_gpu, r_cpu)
+    if gc_bound is not None:
+        assert e_gc <= gc_bound * e_cpu, (e_gc, e_cpu)
+    return e_gpu, e_cpu, e_gc
+
+
+def test_reference_init_at_the_checkpoints_geometry_769x1537():
+    """The same stress where a real checkpoint lives: td4-psp18 at 769x1537 with the [97,193] LayerNorm affine
+    (td4_psp18.py:107-110), SURVEY 8d's un-calibrated init (resnet.py:162-165), P + 2 frames, the default conv algorithm (Winograd
+    F(4x4)).  Same relative gate (4x max / 3x rms of the fp32 CPU path's own distance to an fp64 evaluation, flips only in the tie band),
+    plus the distance to the CPU path itself: max|gpu - cpu| <= 3 x max|cpu - truth| (the triangle inequality alone allows 5 x; 2.0 x
+    was measured at 129x257).  The printed histogram says how many pixels sit in which decade of the truth's top-2 gap and how many of
+    them the GPU labels differently: "labels differ only inside the tie band", quantified at real logit magnitudes."""
+    _reference_init_stress(769, 1537, 6, 3, gc_bound=3.0)
 
 
 def test_two_models_with_different_kernel_options_in_one_process():
