@@ -76,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--fusion", type=int, default=None, help="bit mask of launch-level fusions (include/tdnet.h tdnet_opts.fusion)")
     ap.add_argument("--gemm-persistent", type=int, default=None, help="tuning: 1 persistent GEMM on a full wave of workgroups (default), 0 one tile per workgroup, n > 1 grid forced to n")
     ap.add_argument("--overlap", type=int, default=None, help="bit mask (include/tdnet.h tdnet_opts.overlap): 1 = layers 3-4 as two row-parity chains on two streams, 2 = low-register Winograd transforms everywhere, bits 4-5 = channels per lane")
+    ap.add_argument("--cu-reserve", type=int, default=None, help="tdnet_opts.cu_reserve: CUs reserved for the Winograd transforms of layers 3-4 (the GEMMs get the rest; 0 = off)")
+    ap.add_argument("--cu-mode", type=int, default=None, help="tdnet_opts.cu_mode (1 = transform stream unmasked, 2 = per-XCD mask layout)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16 MFMA, fp32 accumulate (BASELINE "
                          "config 5); parity vs the fp32 CPU path is gated at 3e-2 / 99.5 % of the labels / mIoU 0.99 (tests/test_gpu_fp16.py)")
@@ -354,7 +356,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     kopts = {"winograd": args.winograd, "pipeline": args.conv_pipeline, "attention": args.attention, "fusion": args.fusion, "stagger": args.stagger, "overlap": args.overlap, "gemm_persistent": args.gemm_persistent,
-             "precision": 1 if args.precision == "fp16" else None}
+             "cu_reserve": args.cu_reserve, "cu_mode": args.cu_mode, "precision": 1 if args.precision == "fp16" else None}
     kopts = {k: v for k, v in kopts.items() if v is not None}
     if args.backbone is None:
         args.backbone = "resnet101" if args.model == "psp" else "resnet18"
@@ -668,7 +670,7 @@ def main():
             psteps, pwarm = 4, P + 2
             child = ["--pmc-child", "--steps", str(psteps), "--warmup", str(pwarm), "--no-cpu-baseline", "--no-pmc", "--model", args.model,
                      "--backbone", args.backbone, "--size", args.size, "--precision", args.precision, "--clips-per-gpu", "1"]
-            for k_, v_ in (("--winograd", args.winograd), ("--conv-pipeline", args.conv_pipeline), ("--attention", args.attention), ("--fusion", args.fusion), ("--stagger", args.stagger), ("--overlap", args.overlap), ("--gemm-persistent", args.gemm_persistent)):
+            for k_, v_ in (("--winograd", args.winograd), ("--conv-pipeline", args.conv_pipeline), ("--attention", args.attention), ("--fusion", args.fusion), ("--stagger", args.stagger), ("--overlap", args.overlap), ("--gemm-persistent", args.gemm_persistent), ("--cu-reserve", args.cu_reserve), ("--cu-mode", args.cu_mode)):
                 if v_ is not None:
                     child += [k_, str(v_)]
             per_launch, per_frame, detail = measure_traffic(child, dom_regex, psteps + pwarm)

@@ -91,7 +91,16 @@ typedef struct tdnet_opts {
                                       this frame, beside the HBM-bound LayerNorm / head / classifier / upsample, assuming pos_id + 1 on an
                                       untouched FIFO (checked at the next call; otherwise the chain is launched again as before),
                                 bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
-    int32_t reserved[8];     /* must be 0                                                                                        */
+    int32_t cu_reserve;      /* > 0, with overlap bit 1: the chip is PARTITIONED for the run of row-parity convs (round 4).  The Winograd GEMMs of both
+                                chains go to one HIP stream whose queue is restricted (hipExtStreamCreateWithCUMask) to all but `cu_reserve` CUs,
+                                the HBM-bound transforms of both chains to a second stream restricted to the reserved CUs (cu_reserve / 8 per
+                                XCD), software-pipelined with events: out(E,i), in(E,i+1) run while G(O,i) holds the matrix pipes, and so on.  The
+                                workgroup dispatcher does not admit a kernel that ARRIVES beside a persistent one; two queues
+                                with disjoint CU sets do not need it to.  0 (default) = off; a multiple of 8 in 8..128                        */
+    int32_t cu_mode;         /* bits, with cu_reserve: 1 = the transform stream is NOT masked (may also use what the GEMM leaves),
+                                2 = mask words laid out per XCD (bits [32 x, 32 x + cu_reserve / 8) of XCD x) instead of the low cu_reserve bits
+                                    (the driver interleaves mask bit i onto XCD i mod 8; tools/cu_mask_probe.hip checks which holds)             */
+    int32_t reserved[6];     /* must be 0                                                                                        */
 } tdnet_opts;
 void tdnet_opts_default(tdnet_opts* o);
 

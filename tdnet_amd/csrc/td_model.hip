@@ -167,6 +167,10 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
     d.overlap = d.overlap < 0 ? 0 : d.overlap & 0xff;
     if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
+    d.cu_reserve = d.cu_reserve < 0 ? 0 : d.cu_reserve > 128 ? 128 : (d.cu_reserve / 8) * 8;
+    d.cu_mode &= 3;
+    if (!d.cu_reserve) d.cu_mode = 0;
+    for (int& r : d.reserved) r = 0;
     return d;
 }
 
@@ -322,6 +326,11 @@ struct tdnet {
     hipEvent_t ev_cfork = nullptr, ev_cjoin = nullptr, ev_cstag = nullptr;
     float *wino_v2 = nullptr, *wino_m2 = nullptr;
     std::vector<float*> seg_t, seg_r, seg_x;
+    // tdnet_opts.cu_reserve: the run on a partitioned chip -- part_g (GEMMs of both chains) on all but cu_reserve CUs, part_t (their
+    // transforms) on the reserved ones; ev_in[c][i] / ev_g[c][i]: "input transform / GEMMs of chunk c of conv i done"
+    hipStream_t part_g = nullptr, part_t = nullptr;
+    std::vector<hipEvent_t> ev_in[2], ev_g[2];
+    int part_grid = 0;                                                 // persistent GEMM grid on part_g: 3 workgroups per CU it may use
     float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
     bool act16 = false;                                               // precision = 1: the maps between the backbone's convs are fp16 in HBM
     _Float16* vt16 = nullptr;                                         // fp16 attention: V' transposed [DV][LkPad]
@@ -481,6 +490,9 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     for (float* q : {n->wino_v2, n->wino_m2}) if (q) hipFree(q);
     for (auto* v : {&n->seg_t, &n->seg_r, &n->seg_x}) for (float* q : *v) if (q) hipFree(q);
     if (n->chain2) hipStreamDestroy(n->chain2);
+    if (n->part_g) hipStreamDestroy(n->part_g);
+    if (n->part_t) hipStreamDestroy(n->part_t);
+    for (auto* v : {&n->ev_in[0], &n->ev_in[1], &n->ev_g[0], &n->ev_g[1]}) for (hipEvent_t e : *v) if (e) hipEventDestroy(e);
     if (n->ev_cfork) hipEventDestroy(n->ev_cfork);
     if (n->ev_cjoin) hipEventDestroy(n->ev_cjoin);
     if (n->ev_cstag) hipEventDestroy(n->ev_cstag);
@@ -823,6 +835,31 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         int least = 0, greatest = 0;
         TD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         TD_HIP(hipStreamCreateWithPriority(&n->side, hipStreamNonBlocking, least));
+    }
+    if (n->seg_block >= 0 && n->opts.cu_reserve > 0 && !((n->opts.overlap & 64) && (n->opts.overlap & 8))) {
+        // Two hardware queues with DISJOINT compute-unit sets.  A queue's CU mask is a bit vector over the device's CUs; the driver deals
+        // bit i to XCD i mod 8 (then round-robin over that XCD's shader engines), so the low R bits are R / 8 CUs of every XCD.
+        int ncu = 0;
+        TD_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, n->cfg.device));
+        const int R = n->opts.cu_reserve, words = (ncu + 31) / 32;
+        if (ncu < 64 || R >= ncu) return td_fail("cu_reserve %d on a device with %d compute units", R, ncu);
+        std::vector<uint32_t> mt((size_t)words, 0u), mg((size_t)words, 0u);
+        for (int i = 0; i < ncu; ++i) {
+            const bool reserved = (n->opts.cu_mode & 2) ? (i % 32) < R / 8 && i / 32 < 8 : i < R;
+            (reserved ? mt : mg)[i / 32] |= 1u << (i % 32);
+        }
+        TD_HIP(hipExtStreamCreateWithCUMask(&n->part_g, (uint32_t)words, mg.data()));
+        if (n->opts.cu_mode & 1) TD_HIP(hipStreamCreateWithFlags(&n->part_t, hipStreamNonBlocking));
+        else TD_HIP(hipExtStreamCreateWithCUMask(&n->part_t, (uint32_t)words, mt.data()));
+        n->part_grid = 3 * (ncu - R);
+        const size_t nev = 2 * n->bspec.size() + 2;
+        for (int c = 0; c < 2; ++c) {
+            n->ev_in[c].assign(nev, nullptr); n->ev_g[c].assign(nev, nullptr);
+            for (size_t i = 0; i < nev; ++i) {
+                TD_HIP(hipEventCreateWithFlags(&n->ev_in[c][i], hipEventDisableTiming));
+                TD_HIP(hipEventCreateWithFlags(&n->ev_g[c][i], hipEventDisableTiming));
+            }
+        }
     }
     if (n->seg_block >= 0) {
         TD_HIP(hipStreamCreateWithFlags(&n->chain2, hipStreamNonBlocking));
@@ -1228,8 +1265,94 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
 // under it, and a chain's GEMM workgroups start as the other's retire.  Host enqueue order alternates between the chains so that
 // neither stream runs dry while the other's launches are being issued.
 static int run_parity_chains_riders(tdnet* n, PathLayers& L, int h, int w, hipStream_t s);
+
+// The run on a PARTITIONED chip (tdnet_opts.cu_reserve, round 4).  Every earlier schedule asked the workgroup dispatcher to co-run an
+// HBM-bound transform beside a persistent GEMM on the same CUs, which it does not do for a kernel that arrives later.
+// Here the GEMMs of BOTH chains run back to back on part_g -- a queue that owns all but R CUs -- and the transforms of both chains on
+// part_t, a queue that owns the other R: while G(O,i) holds the matrix pipes of its CUs, out(E,i) and in(E,i+1) stream through the
+// reserved ones, so that G(E,i+1) finds its operand ready when G(O,i) retires:
+//     part_t:  in(E,0) in(O,0) | out(E,0) in(E,1) | out(O,0) in(O,1) | out(E,1) in(E,2) | ...
+//     part_g:          G(E,0)  |      G(O,0)      |      G(E,1)      |      G(O,1)      | ...
+// ev_in[c][i]: part_g waits for it before G(c,i); ev_g[c][i]: part_t waits for it before out(c,i).  The host enqueues in a
+// topological order of these dependencies (the emulator, which runs launches in issue order, checks exactly that).
+static int run_parity_chains_partitioned(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
+    const int sb = n->seg_block, nblk = (int)L.blocks.size();
+    hipStream_t G = n->part_g, T = n->part_t;
+    {
+        BlockLayers& B = L.blocks[sb];
+        if (n->seg_conv == 1) TD_TRY(run_conv(n, B.c1, n->bx, h, w, nullptr, n->seg_t[sb], s));
+        if (B.has_ds) TD_TRY(run_conv(n, B.ds, n->bx, h, w, nullptr, n->seg_r[sb], s));
+    }
+    struct Job { const ConvLayer* L; WinoArgs wa[2]; const ConvLayer* ds_after; const float* ds_in; float* ds_out; };
+    std::vector<Job> jobs;
+    float* Vw[2] = {n->wino_v, n->wino_v2};
+    float* Mw[2] = {n->wino_m, n->wino_m2};
+    for (int b = sb; b < nblk; ++b) {
+        BlockLayers& B = L.blocks[b];
+        const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
+        if (!(b == sb && n->seg_conv == 1)) {
+            Job j; j.L = &B.c1;
+            // the block's 1x1 downsample (rows of one parity, GemmArgs.wshare) follows conv1's GEMMs of that parity on part_g: its input
+            // -- the previous block's output rows -- is complete (in(c, conv1) read them), its output is conv2's residual
+            j.ds_after = (B.has_ds && b > sb) ? &B.ds : nullptr; j.ds_in = xin; j.ds_out = n->seg_r[b];
+            for (int c = 0; c < 2; ++c) { WinoChunk ck; ck.ny = 2; ck.cy = c; j.wa[c] = wino_chunk_args(B.c1, xin, h, w, nullptr, n->seg_t[b], ck, Vw[c], Mw[c]); }
+            jobs.push_back(j);
+        }
+        Job j; j.L = &B.c2; j.ds_after = nullptr; j.ds_in = nullptr; j.ds_out = nullptr;
+        for (int c = 0; c < 2; ++c) {
+            WinoChunk ck; ck.ny = 2; ck.cy = c;
+            j.wa[c] = wino_chunk_args(B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], ck, Vw[c], Mw[c]);
+        }
+        jobs.push_back(j);
+    }
+    const int nj = (int)jobs.size();
+    if ((size_t)nj + 1 > n->ev_in[0].size()) return td_fail("internal: partitioned run has more convs than events");
+    for (auto& j : jobs) if (j.L->wino != 4 || !j.L->vw) return td_fail("internal: partitioned run on a conv without chunked F(4x4) transforms");
+    TD_HIP(hipEventRecord(n->ev_cfork, s));
+    TD_HIP(hipStreamWaitEvent(T, n->ev_cfork, 0));
+    TD_HIP(hipStreamWaitEvent(G, n->ev_cfork, 0));
+    auto gemms = [&](const Job& J, int c) {
+        const ConvLayer& C = *J.L;
+        const WinoArgs& wa = J.wa[c];
+        GemmArgs ga;
+        ga.a = wa.V; ga.wp = C.d_wp; ga.bias = C.d_zero; ga.resid = nullptr; ga.out = const_cast<float*>(wa.Mb);
+        ga.M = wa.Tc; ga.N = C.Cout; ga.NPad = C.CoutPad; ga.K = C.Cin; ga.nbatch = 36; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = wa.TP; ga.stagger = 0;
+        prof_begin(n, 0, 2, 2.0 * 36 * wa.Tc * (double)C.Cin * C.Cout, G);
+        const int cap = C.pers > 1 ? C.pers : n->part_grid;
+        if (C.gdma && gemm_dma_supports(C.Cin, C.Cout, C.tile)) gemm_dma_launch(ga, nullptr, cap, G);
+        else gemm_launch(ga, C.tile, C.pers > 1 ? C.pers : n->part_grid * gemm_blocks_per_cu(C.tile) / 3, G);
+        prof_end(n, G);
+    };
+    for (int c = 0; c < 2; ++c) {
+        wino_transform_alone(n, *jobs[0].L, jobs[0].wa[c], false, T);
+        TD_HIP(hipEventRecord(n->ev_in[c][0], T));
+    }
+    for (int i = 0; i < nj; ++i) {
+        const Job& J = jobs[i];
+        for (int c = 0; c < 2; ++c) {
+            TD_HIP(hipStreamWaitEvent(G, n->ev_in[c][i], 0));
+            gemms(J, c);
+            TD_HIP(hipEventRecord(n->ev_g[c][i], G));
+            if (J.ds_after) TD_TRY(run_ds_rows(n, *J.ds_after, J.ds_in, h, w, J.ds_out, 2, c, G));
+        }
+        for (int c = 0; c < 2; ++c) {
+            TD_HIP(hipStreamWaitEvent(T, n->ev_g[c][i], 0));
+            wino_transform_alone(n, *J.L, J.wa[c], true, T);
+            if (i + 1 < nj) {
+                wino_transform_alone(n, *jobs[i + 1].L, jobs[i + 1].wa[c], false, T);
+                TD_HIP(hipEventRecord(n->ev_in[c][i + 1], T));
+            }
+        }
+    }
+    // part_t ends with out(O, last); everything on part_g precedes it through ev_g -- except a trailing downsample, which the last job has not
+    TD_HIP(hipEventRecord(n->ev_cjoin, T));
+    TD_HIP(hipStreamWaitEvent(s, n->ev_cjoin, 0));
+    return 0;
+}
+
 static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
     if ((n->opts.overlap & 64) && (n->opts.overlap & 8)) return run_parity_chains_riders(n, L, h, w, s);
+    if (n->part_g) return run_parity_chains_partitioned(n, L, h, w, s);
     const int sb = n->seg_block, nblk = (int)L.blocks.size();
     hipStream_t st[2] = {s, n->chain2};
     float* Vw[2] = {n->wino_v, n->wino_v2};
@@ -1417,7 +1540,7 @@ static int frame_checks(tdnet* n, int pos_id, const char* who) {
 // Error path of a frame: whatever the internal streams (cache-only attention chain, second row-parity chain) were given before the
 // failure is joined back into the caller's stream, so that a failed call leaves no work of this handle running unordered behind it.
 static void rejoin_streams(tdnet* n, hipStream_t s) {
-    for (hipStream_t c : {n->side, n->chain2}) {
+    for (hipStream_t c : {n->side, n->chain2, n->part_g, n->part_t}) {
         if (!c) continue;
         hipEvent_t& e = c == n->side ? n->ev_join : n->ev_cjoin;
         if (e && hipEventRecord(e, c) == hipSuccess) (void)hipStreamWaitEvent(s, e, 0);

@@ -46,6 +46,8 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
@@ -53,6 +55,7 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hip
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)0x1; return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = (hipStream_t)0x1; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

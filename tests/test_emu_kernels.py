@@ -361,18 +361,22 @@ def test_winograd_chunked_low_register_transforms(lib):
 @pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 41}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
                                           ("td2", "resnet18", {"overlap": 3 | 32 | 4}), ("td4", "resnet18", {"overlap": 1 | 8 | 64 | 32}),
                                           ("td2", "resnet18", {"overlap": 1 | 8 | 64, "gemm_persistent": 5}), ("td4", "resnet18", {"overlap": 41 | 128}),
-                                          ("td2", "resnet18", {"overlap": 128})])
+                                          ("td2", "resnet18", {"overlap": 128}),
+                                          ("td4", "resnet18", {"overlap": 41, "cu_reserve": 32}), ("td4", "resnet34", {"overlap": 33, "cu_reserve": 48, "cu_mode": 3}),
+                                          ("td2", "resnet18", {"overlap": 1, "cu_reserve": 16, "cu_mode": 1})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     """tdnet_opts.overlap: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows), 1 / 2 /
     4 channels per lane in the transforms, the LDS-DMA-fed GEMM (bit 8; 41 = the library default), the staggered start (bit 4) and the
     single-stream schedule with the transforms riding in the GEMM's matrix waves (bit 64, also with several tiles per workgroup) against
-    the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd."""
+    the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd.
+    cu_reserve (round 4): the partitioned-chip schedule -- GEMMs of both chains on one stream, transforms on another, event-ordered; the
+    emulator runs launches in ISSUE order, so this checks that the host enqueues in a topological order of the dependencies."""
     H, W = 33, 65
     spec = arch.model_spec(name, 19, bb)
     h, w = arch.feat_size(H), arch.feat_size(W)
     g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
     e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=opts)
-    assert e.opts()["overlap"] == opts["overlap"]
+    assert e.opts()["overlap"] == opts["overlap"] and e.opts()["cu_reserve"] == opts.get("cu_reserve", 0)
     e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
     for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 1, seed=1)):
         out = np.full((1, 19, H, W), 7e7, np.float32)
