@@ -99,7 +99,8 @@ typedef struct tdnet_opts {
                                 with disjoint CU sets do not need it to.  0 (default) = off; a multiple of 8 in 8..128                        */
     int32_t cu_mode;         /* bits, with cu_reserve: 1 = the transform stream is NOT masked (may also use what the GEMM leaves),
                                 2 = mask words laid out per XCD (bits [32 x, 32 x + cu_reserve / 8) of XCD x) instead of the low cu_reserve bits
-                                    (the driver interleaves mask bit i onto XCD i mod 8; tools/cu_mask_probe.hip checks which holds)             */
+                                    (the driver interleaves mask bit i onto XCD i mod 8; tools/cu_mask_probe.hip checks which holds),
+                                4 = diagnostic: the same event-ordered pipeline on two PLAIN streams (no CU masks at all)                          */
     int32_t reserved[6];     /* must be 0                                                                                        */
 } tdnet_opts;
 void tdnet_opts_default(tdnet_opts* o);

@@ -168,7 +168,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.overlap = d.overlap < 0 ? 0 : d.overlap & 0xff;
     if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
     d.cu_reserve = d.cu_reserve < 0 ? 0 : d.cu_reserve > 128 ? 128 : (d.cu_reserve / 8) * 8;
-    d.cu_mode &= 3;
+    d.cu_mode &= 7;
     if (!d.cu_reserve) d.cu_mode = 0;
     for (int& r : d.reserved) r = 0;
     return d;
@@ -848,8 +848,9 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             const bool reserved = (n->opts.cu_mode & 2) ? (i % 32) < R / 8 && i / 32 < 8 : i < R;
             (reserved ? mt : mg)[i / 32] |= 1u << (i % 32);
         }
-        TD_HIP(hipExtStreamCreateWithCUMask(&n->part_g, (uint32_t)words, mg.data()));
-        if (n->opts.cu_mode & 1) TD_HIP(hipStreamCreateWithFlags(&n->part_t, hipStreamNonBlocking));
+        if (n->opts.cu_mode & 4) TD_HIP(hipStreamCreateWithFlags(&n->part_g, hipStreamNonBlocking));   // diagnostic: the pipeline without masks
+        else TD_HIP(hipExtStreamCreateWithCUMask(&n->part_g, (uint32_t)words, mg.data()));
+        if (n->opts.cu_mode & 5) TD_HIP(hipStreamCreateWithFlags(&n->part_t, hipStreamNonBlocking));
         else TD_HIP(hipExtStreamCreateWithCUMask(&n->part_t, (uint32_t)words, mt.data()));
         n->part_grid = 3 * (ncu - R);
         const size_t nev = 2 * n->bspec.size() + 2;

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--sync-each", action="store_true", help="synchronise the device after every frame (latency mode: the host never runs ahead)")
     ap.add_argument("--json", default=None, help="also write the table as JSON lines to this file")
     ap.add_argument("variants", nargs="*", default=[""])
     a = ap.parse_args()
@@ -53,6 +54,7 @@ def main():
     base = {"precision": 1} if a.precision == "fp16" else {}
     variants = [parse_variant(v) for v in a.variants]
     fps = [[] for _ in variants]
+    host_us = [[] for _ in variants]
     ident = [None] * len(variants)
     ref_out = None
     for r in range(a.rounds):
@@ -73,19 +75,27 @@ def main():
                 for _ in range(P + 4):
                     m(clip[t % NF], pos_id=t % P); t += 1
                 torch.cuda.synchronize(dev)
+                th = time.perf_counter()
+                for _ in range(2):                                     # host cost of enqueueing a frame on an empty queue
+                    m(clip[t % NF], pos_id=t % P); t += 1
+                host_us[i].append((time.perf_counter() - th) / 2 * 1e6)
+                torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
                 for _ in range(a.steps):
                     m(clip[t % NF], pos_id=t % P); t += 1
+                    if a.sync_each:
+                        torch.cuda.synchronize(dev)
                 torch.cuda.synchronize(dev)
                 fps[i].append(a.steps / (time.perf_counter() - t0))
             m.engine.close()
             del m
-    print("%s-psp%s %dx%d %s, %d steps x %d rounds (interleaved), frames/s:" % (a.model, a.backbone[6:], H, W, a.precision, a.steps, a.rounds))
+    print("%s-psp%s %dx%d %s, %d steps x %d rounds (interleaved), frames/s:" % (a.model, a.backbone[6:], H, W, a.precision + (", device synchronised after every frame" if a.sync_each else ""), a.steps, a.rounds))
     rows = []
-    for v, f, idn in zip(a.variants, fps, ident):
+    for v, f, idn, hu in zip(a.variants, fps, ident, host_us):
         med = statistics.median(f)
-        rows.append({"variant": v or "(default)", "fps_median": round(med, 2), "fps_rounds": [round(x, 2) for x in f], "vs_first": idn})
-        print("  %-44s median %8.2f   rounds %s   %s" % (v or "(default)", med, " ".join("%.1f" % x for x in f), idn))
+        rows.append({"variant": v or "(default)", "fps_median": round(med, 2), "fps_rounds": [round(x, 2) for x in f], "vs_first": idn,
+                     "host_enqueue_us_per_frame": round(statistics.median(hu), 1), "sync_each_frame": bool(a.sync_each)})
+        print("  %-44s median %8.2f   rounds %s   host enqueue %6.0f us/frame   %s" % (v or "(default)", med, " ".join("%.1f" % x for x in f), statistics.median(hu), idn))
     if a.json:
         with open(a.json, "a") as f:
             for row in rows:
