@@ -40,7 +40,8 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 38   /* 2 | 4 | 32; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*) */
+#define TDNET_FUSION_DEFAULT 8230   /* 2 | 4 | 32 | 8192; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+                                       bit 8192 (precision 1 only) since round 4: 1042 -> 1053 frames/s at 720x960 fp16, bit-identical (profiles/r04j_*) */
 #define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
@@ -74,7 +75,13 @@ typedef struct tdnet_opts {
                                 2048 = precision 1 only: the LDS-DMA conv stages its activation operand tap by tap (k_conv_dma_h) instead of
                                      one LDS image per kernel row shared by the row's three taps (k_conv_dma_h3) -- A/B,
                                 4096 = precision 1 only: the 64 -> 64-channel 3x3 convs (ResNet layer1) on persistent workgroups with the weights
-                                     resident in LDS (k_conv_dma_w64; measured no faster than the per-tile kernel: one wave per SIMD)           */
+                                     resident in LDS (k_conv_dma_w64; measured no faster than the per-tile kernel: one wave per SIMD),
+                                8192 = precision 1 only (default): the 128 / 192 x 128 tiles of the LDS-DMA conv with four dedicated LOADER waves per
+                                     workgroup (k_conv_dma_h3p: the matrix waves never issue vector memory inside the K loop); bit-identical,
+                                16384 = precision 1 only: loader and matrix waves with NO workgroup barrier in the K loop -- buffers change hands through
+                                     LDS flags, rings of 2-3 images and 4-5 weight steps (k_conv_dma_h3f); bit-identical.  Measured SLOWER (an LDS round
+                                     trip is 300-600 cycles on a CU whose LDS carries the DMA writes and twelve waves' reads: every hand-over
+                                     costs one; the 192 / 256-row forms spill): experiment, profiles/r04f_* .. r04j_*                          */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
                                 1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -42,7 +42,17 @@ enum ConvDmaCode {
     CD_256_EARLY = 13,    // row-image kernel, 256 rows: four weight buffers, data lands one step early
     CD_192_EARLY = 14,    // ... 192 rows
     CD_128_EARLY = 15,    // ... 128 rows
-    CD_W64 = 16           // 64 -> 64 channels: persistent workgroups, weights resident in LDS (k_conv_dma_w64)
+    CD_W64 = 16,          // 64 -> 64 channels: persistent workgroups, weights resident in LDS (k_conv_dma_w64)
+    CD_128_P = 17,        // row-image kernel with four dedicated loader waves (k_conv_dma_h3p): 128 rows, eight matrix waves of 32 x 64
+    CD_192_P = 18,        // ... 192 rows, six matrix waves of 64 x 64
+    CD_256_P = 19,        // ... 256 rows, eight matrix waves of 64 x 64
+    CD_128_P4 = 20,       // ... 128 rows, four matrix waves of 64 x 64
+    CD_128_PR = 21,       // CD_128_P with the K walk rotated per tile (experiment: L2 channel hot spots)
+    CD_192_PR = 22,       // CD_192_P likewise
+    CD_128_F = 23,        // loader + matrix waves handing buffers over through LDS flags, no barrier in the K loop (k_conv_dma_h3f): 128 rows, eight matrix waves
+    CD_192_F = 24,        // ... 192 rows
+    CD_256_F = 25,        // ... 256 rows
+    CD_128_F4 = 26        // ... 128 rows, four matrix waves of 64 x 64
 };
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
@@ -555,6 +565,489 @@ static inline bool conv_launch_dma3(ConvArgs a, int rh, int KS, bool out16, hipS
         case CD_192_SUPER: return conv_launch_dma3_t<3, 1, 2, 6, 3, 2>(a, out16, s);
         case CD_128_EARLY: return conv_launch_dma3_t<2, 1, 1, 4, 2, 2>(a, out16, s);
         case CD_128_SUPER: return conv_launch_dma3_t<2, 1, 1, 6, 2, 1>(a, out16, s);
+        default: return false;
+    }
+}
+
+// ---- the row-image kernel with DEDICATED LOADER WAVES (round 4) ------------------------------------------------------------------------------
+// Across the four tile shapes of k_conv_dma_h / _h3 a K step takes (pieces x 16 cycles) + (MFMA cycles of a SIMD), i.e. the LDS-DMA
+// time of the step's bytes at the CU's 64 B/clk PLUS its matrix time, as if the two never overlapped (128 x 128: 512 + 512 -> 0.56 us
+// measured 0.6; 192 x 128: 640 + 768 -> 0.81; 256 x 128: 768 + 1024 -> 0.98; profiles/r03w_*, r04c_*).  They do not overlap because the
+// wave that issues a `buffer_load ... lds` waits 100-185 cycles on it (MI355X_MICROARCH.md: "LDS-DMA piece issue cost") -- in the middle
+// of its own MFMA stream: every matrix wave spends as long issuing DMA as multiplying, and two such waves per SIMD interleave only
+// half of that away.  Here NP = 4 extra waves (one per SIMD) do NOTHING but issue the step's pieces back to back, wait for the
+// previous step's with a counted vmcnt and meet the barrier; the matrix waves read fragments and multiply and never touch vector
+// memory inside the K loop.  Same images, same weights ring (three buffers), same products in the same order as k_conv_dma_h3 <.., 3, ..>:
+// bit-identical results.  Image pieces: IP per loader and super-step (capacity IP * NP * 8 slots), issued in the steps kx = 0 and 1.
+template <int RH, int MI, int NP, int IP>
+struct ConvDmaPGeom {
+    using G = ConvDmaGeom<RH, 1, MI>;
+    static constexpr int NWC = G::NW;                               // matrix (consumer) waves
+    static constexpr int CAP = IP * NP * 8;                         // image capacity in slots (pixels)
+    static constexpr int IMG_BYTES = CAP * 128, NBB = 3, LDS_BYTES = 2 * IMG_BYTES + NBB * G::B_BYTES;
+    static constexpr int WPP = G::NPB / NP;                         // weight pieces per loader and step
+    static constexpr int SH0 = (IP + 1) / 2, SH1 = IP - SH0;
+    static_assert(G::NPB % NP == 0, "every loader stages the same number of weight pieces");
+    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
+};
+// ROT != 0 (experiment): the workgroups of a launch walk the K dimension from DIFFERENT starting super-steps (tile_m * ROT mod nsuper), so
+// that the CUs of an XCD do not all ask the L2 for the same weight lines at the same moment.  Changes the summation order (per tile): not
+// bit-identical to the other kernels, same error bound.
+#ifdef TD_P_TRACE      // tools/conv_h3p_trace.hip only: s_memtime stamps of workgroups 0..3, every wave (matrix and loader), the first 24 K steps:
+// matrix waves [0] step start, [1] first k-group's MFMAs issued, [2] all MFMAs issued, [3] after the barrier;
+// loader waves [0] step start, [1] pieces issued, [2] after the counted wait, [3] after the barrier
+#define TD_P_STAMP(st_, slot) do { if (blockIdx.x < 4 && (st_) < 24 && lane == 0) \
+    TD_P_TRACE[(((size_t)blockIdx.x * 12 + wave) * 24 + (st_)) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TD_P_STAMP(st_, slot) ((void)0)
+#endif
+template <int RH, int OUT16, int MI, int NP, int IP, int ROT = 0>
+TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p(ConvArgs p) {
+    using G = ConvDmaGeom<RH, 1, MI>;
+    using GP = ConvDmaPGeom<RH, MI, NP, IP>;
+    constexpr int NJ = 2, BM = G::BM, NWC = GP::NWC, WPP = GP::WPP;
+    TD_DYN_LDS(smem);
+    char* const wbase = smem + 2 * GP::IMG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
+    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * G::BN;
+    const int d = p.dil, Wh = p.W + 2 * d;
+    const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
+    const int gs0 = oy0 * Wh + ox0;                                   // halo-linear index of image slot 0
+    const int S = BM + 2 * d * ((BM - 2) / p.W + 2);                  // slots any tile can need
+    const int nsuper = p.nsteps / 3;
+
+    if (wave >= NWC) {
+        // =========================== loader wave pw: image pieces pw + NP j, weight pieces pw + NP jb ===========================
+        const int pw = wave - NWC;
+        unsigned a_base[IP], a_ok[IP];
+#pragma unroll
+        for (int j = 0; j < IP; ++j) {
+            const int sl = 8 * (pw + NP * j) + (lane >> 3);
+            const int gs = gs0 + sl;
+            const int r = gs / Wh, ix = gs - r * Wh - d;
+            const int kq = (lane & 7) ^ ((sl >> 1) & 7);
+            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+            const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
+            a_ok[j] = 0u;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
+        }
+        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
+        const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
+        const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
+        unsigned b_off[WPP];
+#pragma unroll
+        for (int jb = 0; jb < WPP; ++jb) {
+            const int pb = pw + NP * jb;                                // piece pb = 2 kq + q: 64 consecutive packed slots of k-group kq
+            b_off[jb] = (unsigned)((pb / 2) * p.CoutPad + n0 + (pb % 2) * 64 + lane) * 16u;
+        }
+        const int rot = ROT ? (tile_m * ROT + tile_n) % nsuper : 0;
+        auto issue_image_piece = [&](int u, int j) {                  // u: position in this workgroup's walk; ur: the super-step it multiplies there
+            int ur = u + rot;
+            if (ROT && ur >= nsuper) ur -= nsuper;
+            const int chunk = ur / 3, ky = ur - chunk * 3;
+            const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
+            const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
+            td_buf_ld16_lds(in_buf, smem + (u & 1) * GP::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
+        };
+        auto issue_weights = [&](int step, int buf) {
+            const bool live = step < p.nsteps;
+            int sr = step;
+            if (ROT && live) { sr = step + 3 * rot; if (sr >= p.nsteps) sr -= p.nsteps; }
+#pragma unroll
+            for (int jb = 0; jb < WPP; ++jb)
+                td_buf_ld16_lds(w_buf, wbase + buf * G::B_BYTES + (pw + NP * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB, (unsigned)(live ? sr : 0) * w_step_bytes);
+        };
+#pragma unroll
+        for (int j = 0; j < IP; ++j) issue_image_piece(0, j);
+        issue_weights(0, 0);
+        issue_weights(1, 1);
+        TD_WAIT_VM_PIECES(WPP);                                       // image 0 and the weights of step 0 (step 1's may fly)
+        TD_BARRIER_RAW();
+        for (int u = 0; u < nsuper; ++u) {
+            // kx = 0: weights of step 3 u + 2 into the buffer step 3 u - 1 left, the first share of the next image
+            TD_P_STAMP(3 * u, 0);
+            issue_weights(3 * u + 2, 2);
+#pragma unroll
+            for (int j = 0; j < GP::SH0; ++j) issue_image_piece(u + 1, j);
+            TD_P_STAMP(3 * u, 1);
+            TD_WAIT_VM_PIECES(WPP + GP::SH0);                         // the weights of step 3 u + 1 have landed; this step's issues may fly
+            TD_P_STAMP(3 * u, 2);
+            TD_BARRIER_RAW();
+            TD_P_STAMP(3 * u, 3);
+            TD_P_STAMP(3 * u + 1, 0);
+            issue_weights(3 * u + 3, 0);
+#pragma unroll
+            for (int j = GP::SH0; j < IP; ++j) issue_image_piece(u + 1, j);
+            TD_P_STAMP(3 * u + 1, 1);
+            TD_WAIT_VM_PIECES(WPP + GP::SH1);
+            TD_P_STAMP(3 * u + 1, 2);
+            TD_BARRIER_RAW();
+            TD_P_STAMP(3 * u + 1, 3);
+            TD_P_STAMP(3 * u + 2, 0);
+            issue_weights(3 * u + 4, 1);
+            TD_P_STAMP(3 * u + 2, 1);
+            TD_WAIT_VM_PIECES(WPP);                                   // the next image (both shares) and the weights of step 3 u + 3
+            TD_P_STAMP(3 * u + 2, 2);
+            TD_BARRIER_RAW();
+            TD_P_STAMP(3 * u + 2, 3);
+        }
+        TD_WAIT_VM_PIECES(0);                                         // the surplus (zero-fill) pieces must not land in an LDS that has been handed on
+        return;
+    }
+
+    // =========================================== matrix wave: fragments and MFMAs only ===========================================
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned a_rd[3][MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 32 * MI + 32 * i + l31;
+        const int oy = m / p.W, ox = m - oy * p.W;
+        const int sm = (oy - oy0) * Wh + ox - ox0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sl = sm + kx * d;
+            a_rd[kx][i] = (unsigned)(sl * 128 + (((half) ^ ((sl >> 1) & 7)) << 4));
+        }
+    }
+    constexpr int BKQ = G::BN * 16;
+    const unsigned b_rd = (unsigned)(half * BKQ + (wn * 64 + l31) * 16);
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma = [&](auto kx_tag, const char* img, const char* wb, int step) {
+        constexpr int KX = decltype(kx_tag)::value;
+        (void)step;
+        f16x8 af[2][MI], bf[2][NJ];
+        TD_P_STAMP(step, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const f16x8*>(img + a_rd[KX][i]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + j * 512);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[(g + 1) & 1][i] = *reinterpret_cast<const f16x8*>(img + (a_rd[KX][i] ^ (unsigned)((g + 1) << 5)));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[(g + 1) & 1][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + (g + 1) * 2 * BKQ + j * 512);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(af[g & 1][i], bf[g & 1][j], acc[i][j]);
+            if (g == 0) TD_P_STAMP(step, 1);
+        }
+        TD_P_STAMP(step, 2);
+    };
+    TD_BARRIER_RAW();                                                  // the loaders' prologue
+    for (int u = 0; u < nsuper; ++u) {
+        const char* img = smem + (u & 1) * GP::IMG_BYTES;
+        mma(std::integral_constant<int, 0>{}, img, wbase, 3 * u);
+        TD_BARRIER_RAW();
+        TD_P_STAMP(3 * u, 3);
+        mma(std::integral_constant<int, 1>{}, img, wbase + G::B_BYTES, 3 * u + 1);
+        TD_BARRIER_RAW();
+        TD_P_STAMP(3 * u + 1, 3);
+        mma(std::integral_constant<int, 2>{}, img, wbase + 2 * G::B_BYTES, 3 * u + 2);
+        TD_BARRIER_RAW();
+        TD_P_STAMP(3 * u + 2, 3);
+    }
+    td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+}
+template <int RH, int MI, int NP, int IP, int ROT = 0>
+static inline bool conv_launch_dma3p_t(const ConvArgs& a, bool out16, hipStream_t s) {
+    using G = ConvDmaGeom<RH, 1, MI>;
+    using GP = ConvDmaPGeom<RH, MI, NP, IP>;
+    if (conv_dma3_slots(G::BM, a.W, a.dil) > GP::CAP) return false;
+    const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
+    if (out16) TD_LAUNCH((k_conv_dma_h3p<RH, 1, MI, NP, IP, ROT>), dim3(grid), dim3(64 * (GP::NWC + NP)), GP::LDS_BYTES, s, a);
+    else TD_LAUNCH((k_conv_dma_h3p<RH, 0, MI, NP, IP, ROT>), dim3(grid), dim3(64 * (GP::NWC + NP)), GP::LDS_BYTES, s, a);
+    return true;
+}
+// rh: CD_128_P / CD_192_P / CD_256_P (x 128 channels); the smallest image buffer that holds the halo.  false = not launched.
+static inline bool conv_launch_dma3p(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
+    if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
+    a.tiles_n = a.CoutPad / 128;
+    switch (rh) {
+        case CD_128_P: return conv_launch_dma3p_t<2, 1, 4, 5>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 6>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 8>(a, out16, s);
+        case CD_128_P4: return conv_launch_dma3p_t<2, 2, 4, 5>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 6>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 8>(a, out16, s);
+        case CD_192_P: return conv_launch_dma3p_t<3, 2, 4, 7>(a, out16, s) || conv_launch_dma3p_t<3, 2, 4, 9>(a, out16, s);
+        case CD_256_P: return conv_launch_dma3p_t<4, 2, 4, 9>(a, out16, s) || conv_launch_dma3p_t<4, 2, 4, 11>(a, out16, s);
+        case CD_128_PR: return conv_launch_dma3p_t<2, 1, 4, 6, 5>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 8, 5>(a, out16, s);   // rotated K walk (experiment)
+        case CD_192_PR: return conv_launch_dma3p_t<3, 2, 4, 9, 5>(a, out16, s);
+        default: return false;
+    }
+}
+
+// ---- loader waves and matrix waves WITHOUT a workgroup barrier in the K loop: buffers change hands through LDS flags (round 4) ------------------
+// The in-kernel trace of k_conv_dma_h3p (tools/conv_h3p_trace.hip, profiles/r04e_*) shows what a barrier per K step costs once the roles are
+// separated: per 128 x 128 step the loaders need ~620 cycles to issue (the CU's LDS-DMA path takes a 1 KB piece every ~24 cycles with four
+// waves issuing and the matrix waves reading fragments) + ~130 to see the previous step land, the matrix waves ~220 to get their first
+// fragments after the barrier + ~400 to issue their MFMAs -- and then everybody waits for the slowest: a period of 1100 cycles for 512
+// of MFMAs and ~550 of DMA.  Here nobody waits for anybody who is not late:
+//   * weights live in a ring of NSW step buffers, images in a ring of NSI super-step buffers;
+//   * a loader wave walks the units I(u) W(3u) W(3u+1) W(3u+2) I(u+1) ... : wait until the unit's buffer was READ (free counter of its
+//     slot), issue its pieces, then a counted vmcnt tells it that the PREVIOUS unit has landed and it adds 1 to that unit's ready counter;
+//   * a matrix wave waits until a unit's ready counter says all NP loaders' pieces have landed, multiplies, and adds 1 to the free counter.
+// Counters only grow (use g of a slot is complete at NP (g + 1) resp. NWC (g + 1)): no reset, no ABA.  Same images, same weights, same
+// products in the same order as k_conv_dma_h3 / _h3p: bit-identical results.
+template <int RH, int MI, int NP, int IP, int NSI, int NSW>
+struct ConvDmaFGeom {
+    using G = ConvDmaGeom<RH, 1, MI>;
+    static constexpr int NWC = G::NW;
+    static constexpr int CAP = IP * NP * 8;
+    static constexpr int IMG_BYTES = CAP * 128, DATA_BYTES = NSI * IMG_BYTES + NSW * G::B_BYTES, LDS_BYTES = DATA_BYTES + 256;
+    static constexpr int WPP = G::NPB / NP;
+    static_assert(G::NPB % NP == 0, "every loader stages the same number of weight pieces");
+    static_assert(2 * (NSI + NSW) * 4 <= 256, "flag block");
+    static_assert(NSI >= 2 && NSW >= 2, "a unit's ready signal is given while the NEXT unit is in flight");
+    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
+};
+template <int RH, int OUT16, int MI, int NP, int IP, int NSI, int NSW>
+TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3f(ConvArgs p) {
+    using G = ConvDmaGeom<RH, 1, MI>;
+    using GF = ConvDmaFGeom<RH, MI, NP, IP, NSI, NSW>;
+    constexpr int NJ = 2, BM = G::BM, NWC = GF::NWC, WPP = GF::WPP;
+    TD_DYN_LDS(smem);
+    char* const wbase = smem + NSI * GF::IMG_BYTES;
+    td_flag_t* const iready = td_flag_ptr(smem + GF::DATA_BYTES);
+    td_flag_t* const ifree = iready + NSI;
+    td_flag_t* const wready = ifree + NSI;
+    td_flag_t* const wfree = wready + NSW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
+    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * G::BN;
+    const int d = p.dil, Wh = p.W + 2 * d;
+    const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
+    const int gs0 = oy0 * Wh + ox0;
+    const int S = BM + 2 * d * ((BM - 2) / p.W + 2);
+    const int nsuper = p.nsteps / 3;
+    if (tid < 2 * (NSI + NSW)) iready[tid] = 0u;
+    TD_BARRIER_RAW();                                                  // the only workgroup barrier of the kernel
+
+    if (wave >= NWC) {
+        // ======================================================== loader wave ========================================================
+        const int pw = wave - NWC;
+        unsigned a_base[IP], a_ok[IP];
+#pragma unroll
+        for (int j = 0; j < IP; ++j) {
+            const int sl = 8 * (pw + NP * j) + (lane >> 3);
+            const int gs = gs0 + sl;
+            const int r = gs / Wh, ix = gs - r * Wh - d;
+            const int kq = (lane & 7) ^ ((sl >> 1) & 7);
+            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+            const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
+            a_ok[j] = 0u;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
+        }
+        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
+        const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
+        const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
+        unsigned b_off[WPP];
+#pragma unroll
+        for (int jb = 0; jb < WPP; ++jb) {
+            const int pb = pw + NP * jb;
+            b_off[jb] = (unsigned)((pb / 2) * p.CoutPad + n0 + (pb % 2) * 64 + lane) * 16u;
+        }
+        // Units in issue order: I(u) W(3u) W(3u+1) W(3u+2) I(u+1) ...  A unit's "landed" signal is given TWO units later (after the next two
+        // units were issued, a counted vmcnt leaves exactly their pieces in flight): one unit of lag (4-5 pieces, ~400 cycles of issue) is
+        // shorter than the DMA latency under load and made every signal wait.  The free counter of a unit's slot is looked at one unit
+        // early (td_flag_peek) so that its LDS round trip is not on the issue path.
+        int islot = 0, igen = 0, wslot = 0, wgen = 0;                  // slot / use count of the NEXT image and weight unit
+        td_flag_t *pend1 = nullptr, *pend2 = nullptr;                  // ready flags of the last and the last-but-one unit issued
+        unsigned peek = 0u;                                            // free counter of the next unit's slot, read a unit ago
+        auto acquire = [&](td_flag_t* freeflag, int gen) {            // the slot's previous contents have been read by all matrix waves
+            if (gen > 0 && !td_flag_reached(peek, (unsigned)(NWC * gen))) {
+                // The ring is full: this loader is ahead and about to idle.  Whatever it has in flight is published first -- the units'
+                // signals must not wait for a FUTURE issue that itself waits for the matrix waves (first version: the matrix waves
+                // saw a unit ~550 cycles after it had landed, profiles/r04g_*).
+                TD_WAIT_VM_PIECES(0);
+                TD_LANES_ARRIVED();
+                if (pend2) td_flag_add(pend2);
+                if (pend1) td_flag_add(pend1);
+                pend1 = pend2 = nullptr;
+                td_flag_wait_ge(freeflag, (unsigned)(NWC * gen));
+            }
+        };
+        auto landed = [&](td_flag_t* mine) {                          // after the counted wait: the last-but-one unit is complete
+            if (pend2) { TD_LANES_ARRIVED(); td_flag_add(pend2); }
+            pend2 = pend1; pend1 = mine;
+        };
+        for (int u = 0; u < nsuper; ++u) {
+            {   // I(u)
+                acquire(ifree + islot, igen);
+                peek = td_flag_peek(wfree + wslot);
+                const int chunk = u / 3, ky = u - chunk * 3;
+                const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
+                char* img = smem + islot * GF::IMG_BYTES;
+#pragma unroll
+                for (int j = 0; j < IP; ++j) {
+                    const bool ok = ((a_ok[j] >> ky) & 1u) != 0u;
+                    td_buf_ld16_lds(in_buf, img + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
+                }
+                TD_WAIT_VM_PIECES(IP + WPP);                           // in flight: I(u) and W(3 u - 1)
+                landed(iready + islot);
+                if (++islot == NSI) { islot = 0; ++igen; }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {                           // W(3 u + kx)
+                TD_P_STAMP(3 * u + kx, 0);
+                acquire(wfree + wslot, wgen);
+                TD_P_STAMP(3 * u + kx, 1);
+                td_flag_t* const mine = wready + wslot;
+                const unsigned soff = (unsigned)(3 * u + kx) * w_step_bytes;
+                char* wb = wbase + wslot * G::B_BYTES;
+                if (++wslot == NSW) { wslot = 0; ++wgen; }
+                peek = kx == 2 ? td_flag_peek(ifree + islot) : td_flag_peek(wfree + wslot);
+#pragma unroll
+                for (int jb = 0; jb < WPP; ++jb) td_buf_ld16_lds(w_buf, wb + (pw + NP * jb) * 1024, b_off[jb], soff);
+                TD_P_STAMP(3 * u + kx, 2);
+                if (kx == 0) TD_WAIT_VM_PIECES(WPP + IP); else TD_WAIT_VM_PIECES(2 * WPP);
+                landed(mine);
+                TD_P_STAMP(3 * u + kx, 3);
+            }
+        }
+        TD_WAIT_VM_PIECES(WPP);
+        landed(nullptr);
+        TD_WAIT_VM_PIECES(0);
+        landed(nullptr);
+        return;
+    }
+
+    // ========================================================= matrix wave ==========================================================
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    unsigned a_rd[3][MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * 32 * MI + 32 * i + l31;
+        const int oy = m / p.W, ox = m - oy * p.W;
+        const int sm = (oy - oy0) * Wh + ox - ox0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int sl = sm + kx * d;
+            a_rd[kx][i] = (unsigned)(sl * 128 + (((half) ^ ((sl >> 1) & 7)) << 4));
+        }
+    }
+    constexpr int BKQ = G::BN * 16;
+    const unsigned b_rd = (unsigned)(half * BKQ + (wn * 64 + l31) * 16);
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // A matrix wave holds the fragments of TWO whole K steps: while the MFMAs of step s run from one set, all 4 (MI + NJ) fragment reads
+    // of step s + 1 are in flight into the other.  An LDS read on this CU takes 200-300 cycles (the queue carries the DMA writes and
+    // twelve waves' reads: tools/conv_h3p_trace.hip), a k-group of MFMAs 64-128: fetching one k-group ahead, the wave waited on the LDS
+    // before every group and again behind every flag (first version: 1650 cycles per step).  With a step of slack nothing on the wave's path
+    // waits for the LDS, and a slot is released as soon as its fragments sit in registers -- a step BEFORE its products are done.
+    f16x8 FA[2][4][MI], FB[2][4][NJ];
+    auto load = [&](auto kx_tag, auto set_tag, const char* img, const char* wb) {
+        constexpr int KX = decltype(kx_tag)::value, SET = decltype(set_tag)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) FA[SET][g][i] = *reinterpret_cast<const f16x8*>(img + (a_rd[KX][i] ^ (unsigned)(g << 5)));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) FB[SET][g][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + g * 2 * BKQ + j * 512);
+        }
+    };
+    auto fma = [&](auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(FA[SET][g][i], FB[SET][g][j], acc[i][j]);
+    };
+    int islot = 0, igen = 0, wslot = 0, wgen = 0;                      // slot / use of the unit whose fragments are fetched NEXT
+    int step = 0;
+    const char* img = smem;
+    td_flag_t* ifr = ifree;
+    unsigned wpeek = 0u, ipeek = 0u;
+    // fetch the fragments of step `step` (tap KX) into set SET: make sure its image (KX == 0) and weights have landed, read, look ahead
+    auto fetch = [&](auto kx_tag, auto set_tag) {
+        constexpr int KX = decltype(kx_tag)::value;
+        if (KX == 0) {
+            if (!td_flag_reached(ipeek, (unsigned)(NP * (igen + 1)))) td_flag_wait_ge(iready + islot, (unsigned)(NP * (igen + 1)));
+            img = smem + islot * GF::IMG_BYTES;
+            ifr = ifree + islot;
+            if (++islot == NSI) { islot = 0; ++igen; }
+        }
+        if (!td_flag_reached(wpeek, (unsigned)(NP * (wgen + 1)))) td_flag_wait_ge(wready + wslot, (unsigned)(NP * (wgen + 1)));
+        load(kx_tag, set_tag, img, wbase + wslot * G::B_BYTES);
+    };
+    // after TD_WAIT_LDS_READS(): the fragments of the fetched step are in registers -> its weight slot (and, with the image's last tap, its
+    // image slot) is free; then the ready counters of the step after it are looked at, a whole step before they are needed
+    auto release = [&](auto kx_tag) {
+        constexpr int KX = decltype(kx_tag)::value;
+        TD_LANES_ARRIVED();
+        td_flag_add(wfree + wslot);
+        if (KX == 2) td_flag_add(ifr);
+        if (++wslot == NSW) { wslot = 0; ++wgen; }
+        wpeek = td_flag_peek(wready + wslot);
+        if (KX == 2) ipeek = td_flag_peek(iready + islot);
+    };
+    // one K step: fetch step + 1 into the other set, multiply this step's set, release step + 1's buffers
+    auto kstep = [&](auto kx_tag, auto set_tag) {
+        constexpr int KX = decltype(kx_tag)::value, SET = decltype(set_tag)::value, KN = (KX + 1) % 3;
+        TD_P_STAMP(step, 0);
+        const bool more = step + 1 < p.nsteps;                         // wave-uniform
+        if (more) fetch(std::integral_constant<int, KN>{}, std::integral_constant<int, SET ^ 1>{});
+        TD_P_STAMP(step, 1);
+        fma(set_tag);
+        TD_P_STAMP(step, 2);
+        TD_WAIT_LDS_READS();
+        if (more) release(std::integral_constant<int, KN>{});
+        TD_P_STAMP(step, 3);
+        ++step;
+    };
+    wpeek = td_flag_peek(wready);
+    ipeek = td_flag_peek(iready);
+    fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    TD_WAIT_LDS_READS();
+    release(std::integral_constant<int, 0>{});
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+    int u = 0;
+    for (; u + 1 < nsuper; u += 2) {                                   // two super-steps: the fragment sets alternate 0 1 0 1 0 1
+        kstep(K0{}, K0{}); kstep(K1{}, K1{}); kstep(K2{}, K0{});
+        kstep(K0{}, K1{}); kstep(K1{}, K0{}); kstep(K2{}, K1{});
+    }
+    if (u < nsuper) { kstep(K0{}, K0{}); kstep(K1{}, K1{}); kstep(K2{}, K0{}); }
+    td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+}
+template <int RH, int MI, int NP, int IP, int NSI, int NSW>
+static inline bool conv_launch_dma3f_t(const ConvArgs& a, bool out16, hipStream_t s) {
+    using G = ConvDmaGeom<RH, 1, MI>;
+    using GF = ConvDmaFGeom<RH, MI, NP, IP, NSI, NSW>;
+    if (conv_dma3_slots(G::BM, a.W, a.dil) > GF::CAP) return false;
+    const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
+    if (out16) TD_LAUNCH((k_conv_dma_h3f<RH, 1, MI, NP, IP, NSI, NSW>), dim3(grid), dim3(64 * (GF::NWC + NP)), GF::LDS_BYTES, s, a);
+    else TD_LAUNCH((k_conv_dma_h3f<RH, 0, MI, NP, IP, NSI, NSW>), dim3(grid), dim3(64 * (GF::NWC + NP)), GF::LDS_BYTES, s, a);
+    return true;
+}
+// rh: CD_128_F / CD_192_F / CD_256_F; the smallest image buffers that hold the halo, as many ring slots as the LDS takes.  false = not launched.
+static inline bool conv_launch_dma3f(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
+    if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
+    a.tiles_n = a.CoutPad / 128;
+    switch (rh) {
+        case CD_128_F: return conv_launch_dma3f_t<2, 1, 4, 5, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 1, 4, 6, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 1, 4, 8, 2, 5>(a, out16, s);
+        case CD_128_F4: return conv_launch_dma3f_t<2, 2, 4, 5, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 2, 4, 6, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 2, 4, 8, 2, 5>(a, out16, s);
+        case CD_192_F: return conv_launch_dma3f_t<3, 2, 4, 7, 2, 5>(a, out16, s) || conv_launch_dma3f_t<3, 2, 4, 9, 2, 5>(a, out16, s);
+        case CD_256_F: return conv_launch_dma3f_t<4, 2, 4, 9, 2, 4>(a, out16, s) || conv_launch_dma3f_t<4, 2, 4, 11, 2, 4>(a, out16, s);
         default: return false;
     }
 }

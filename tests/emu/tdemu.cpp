@@ -61,7 +61,7 @@ thread_local char* g_lds = nullptr;
 
 static constexpr size_t STACK_BYTES = 96 * 1024;
 static constexpr size_t LDS_BYTES = 160 * 1024;
-static constexpr int MAX_THREADS = 512;
+static constexpr int MAX_THREADS = 1024;                  // 768: eight matrix waves + four loader waves (k_conv_dma_h3p)
 
 struct WaveCtx {
     float a[2][64], b[2][64];
@@ -128,6 +128,7 @@ static void fiber_entry() {
     tdemu_switch(&dummy, cur->sp);
     __builtin_trap();
 }
+void yield_now() { yield(); }
 void syncthreads() {
     const unsigned g = W->bar_gen;
     if (++W->bar_count == (unsigned)W->nthreads) { W->bar_count = 0; W->bar_gen++; return; }

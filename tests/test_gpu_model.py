@@ -298,7 +298,8 @@ def test_every_schedule_option_reproduces_the_default_bit_for_bit():
     (round 2's schedule), chains with 1 / 4 channels per lane, the persistent or the LDS-DMA-fed Winograd GEMM, transforms riding in
     the GEMM's matrix waves, the next frame's cache-only chain launched at the end of the frame, the run on a partitioned chip (GEMMs and
     transforms on two CU-masked queues ordered by events only: cu_reserve); in the fp16 mode the tap-by-tap or
-    the row-image conv kernel, layer1 on the weights-resident kernel.  On the real streams and DMA engines (the emulator runs them
+    the row-image conv kernel, layer1 on the weights-resident kernel, the conv without / with dedicated loader waves (the default since round 4) or
+    with loader and matrix waves synchronised through LDS flags instead of barriers.  On the real streams and DMA engines (the emulator runs them
     in issue order) every variant must give the default's logits bit for bit, frame by frame, through warm-up and steady state --
     including a repeated pos_id, which the pre-launched chain mispredicts."""
     H, W = 257, 513
@@ -307,7 +308,7 @@ def test_every_schedule_option_reproduces_the_default_bit_for_bit():
     with torch.no_grad():
         for base, variants in (({}, [{"overlap": 0}, {"overlap": 1}, {"overlap": 33}, {"overlap": 8}, {"overlap": 1 | 8 | 64 | 32}, {"overlap": 41 | 128},
                                      {"cu_reserve": 32}, {"cu_reserve": 16, "cu_mode": 1}, {"cu_reserve": 64, "cu_mode": 2}]),
-                               ({"precision": 1}, [{"fusion": 6 | 2048}, {"fusion": 6 | 4096}, {"fusion": 6 | 1024}, {"overlap": 128}])):
+                               ({"precision": 1}, [{"fusion": 6 | 2048}, {"fusion": 6 | 4096}, {"fusion": 6 | 1024}, {"fusion": 38}, {"fusion": 38 | 16384}, {"overlap": 128}])):
             m = make_model("td4", "resnet18", seed=3, kernel_opts=dict(base))
             ref = [m(x, pos_id=p).clone() for x, p in zip(frames, pos)]
             m.engine.close()
