@@ -296,7 +296,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
            "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1)}
     if dom_n > 0 and dom_ms > 0:
         ach = dom_fl / (dom_ms * 1e-3) / 1e12
-        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA)" if precision == "fp16"
+        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA)" if precision == "fp16"
                            else "k_gemm_dma<0> / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / (2 * P)}
@@ -441,12 +441,12 @@ def main():
         # host cost of ENQUEUEING a frame (all of its launches, events and stream waits), measured on an empty queue so that the host
         # never waits for the device: when this approaches ms_per_step the rank is CPU-bound, which an 8-rank node can be with 8
         # launcher processes on one socket
-        nh = 4
+        nh = 0 if args.pmc_child else 4                               # (a counter pass counts bytes per frame: no extra frames there)
         parallel.barrier()
         th0 = time.perf_counter()
         for _ in range(nh):
             step()
-        host_us = (time.perf_counter() - th0) / nh * 1e6
+        host_us = (time.perf_counter() - th0) / max(nh, 1) * 1e6
         sync()
         dt = timed(args.steps)
         # `value` stays the contract's EXACTLY K steps; a window under 0.5 s (K = 20 at 275 frames/s is 73 ms) is re-measured over as
@@ -595,8 +595,8 @@ def main():
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             if opts["precision"]:
-                kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
-                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h3<|k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
+                kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> (dedicated loader waves) / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
+                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h3[pf]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:
