@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short legs for BASELINE configs[1] (td2-psp18 1024x2048 fp32) and configs[4] (td2-psp34 720x960 fp16, the "
                          "stand-in for the BiSeNet-34 the reference does not contain) that the default N = 1 run appends as `other_configs`")
-    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-pmc --no-direct-line --no-other-configs (A/B runs)")
+    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-pmc --no-direct-line --no-other-configs, no `sustained` window (A/B and profiler runs)")
     ap.add_argument("--perturb-rank", type=int, default=-1,
                     help="TEST ONLY: this rank scales one weight tensor by 1.001 after the broadcast; the N-rank line must then say "
                          "ranks_agree false and the run must exit non-zero (tests/test_bench_launch.py)")
@@ -452,7 +452,7 @@ def main():
         # `value` stays the contract's EXACTLY K steps; a window under 0.5 s (K = 20 at 275 frames/s is 73 ms) is re-measured over as
         # many frames as fill 0.5 s -- the same number on every rank (derived from the all-reduced K-step time) -- and printed beside it
         sustained = None
-        if not args.pmc_child and not args.dry_run and args.steps > 0:
+        if not args.pmc_child and not args.dry_run and not args.quick and args.steps > 0:
             dt_all = parallel.allreduce_max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()
             if dt_all < 0.5:
                 n_long = int(min(20000, max(args.steps + 1, round(0.6 * args.steps / max(dt_all, 1e-6)))))
