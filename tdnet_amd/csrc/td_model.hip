@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -328,6 +329,11 @@ struct tdnet {
     std::vector<float*> seg_t, seg_r, seg_x;
     // tdnet_opts.cu_reserve: the run on a partitioned chip -- part_g (GEMMs of both chains) on all but cu_reserve CUs, part_t (their
     // transforms) on the reserved ones; ev_in[c][i] / ev_g[c][i]: "input transform / GEMMs of chunk c of conv i done"
+    std::vector<hipStream_t> probe_streams;                            // TDNET_PROBE_EXTRA_STREAMS (probe only)
+    std::vector<hipStream_t> retired_streams;                          // chain2 candidates that shared the caller's hardware queue (place_chain_stream)
+    bool placed = false;
+    void* placed_for = nullptr;                                        // the caller stream chain2 was checked against
+    int chain_replaced = 0;
     hipStream_t part_g = nullptr, part_t = nullptr;
     std::vector<hipEvent_t> ev_in[2], ev_g[2];
     int part_grid = 0;                                                 // persistent GEMM grid on part_g: 3 workgroups per CU it may use
@@ -490,6 +496,8 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     for (float* q : {n->wino_v2, n->wino_m2}) if (q) hipFree(q);
     for (auto* v : {&n->seg_t, &n->seg_r, &n->seg_x}) for (float* q : *v) if (q) hipFree(q);
     if (n->chain2) hipStreamDestroy(n->chain2);
+    for (hipStream_t x : n->probe_streams) hipStreamDestroy(x);
+    for (hipStream_t x : n->retired_streams) hipStreamDestroy(x);
     if (n->part_g) hipStreamDestroy(n->part_g);
     if (n->part_t) hipStreamDestroy(n->part_t);
     for (auto* v : {&n->ev_in[0], &n->ev_in[1], &n->ev_g[0], &n->ev_g[1]}) for (hipEvent_t e : *v) if (e) hipEventDestroy(e);
@@ -835,6 +843,12 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
     TD_HIP(hipDeviceSynchronize());
+    if (const char* e = getenv("TDNET_PROBE_EXTRA_STREAMS")) {          // probe only (tools/idle_handle_probe.py): shift this handle's queue placement
+        for (int i = 0, k = atoi(e); i < k && i < 16; ++i) {
+            hipStream_t x = nullptr;
+            if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) == hipSuccess) n->probe_streams.push_back(x);
+        }
+    }
     {   // The side stream carries the cache-only attention chain (0.6 ms of work beside 2.5 ms of backbone): lowest priority, so its
         // workgroups fill what the critical path leaves instead of taking CUs from it.
         int least = 0, greatest = 0;
@@ -1565,6 +1579,69 @@ static void rejoin_streams(tdnet* n, hipStream_t s) {
     }
 }
 
+// ---- the second chain's stream must really be a second QUEUE --------------------------------------------------------------------------------
+// HIP deals a process's streams onto a small pool of hardware queues per priority class (4 by default), reusing queues once the pool is
+// full; two streams on one queue run their kernels one after the other.  With two or more other normal-priority streams alive in the
+// process, `chain2` used to land on the CALLER's queue: the two row-parity chains serialised and the headline fell from 275 to 183 frames/s
+// (tools/ab_opts.py under TDNET_PROBE_EXTRA_STREAMS, profiles/r04k_headline_vs_extra_streams_in_the_process.txt).  So the first frame on a
+// given caller stream checks: two 40-us spin kernels, one on the caller's stream and one on chain2, started together -- ~40 us for the
+// pair = two queues, ~80 us = one.  If they serialise, chain2 is replaced by a fresh stream (the rejected ones stay alive until the handle
+// dies, or the pool would hand the same queue out again), at most six times.  One host synchronisation per attempt, once per handle and stream.
+// Measured (profiles/r04k_*): one busy handle beside 0 / 1 / 2 / 3 idle ones 335 / 212 / 335 / 212 frames/s before, 333 / 334 / 333 / 334
+// with the check; two extra streams in the process 193-275 -> 273.  NOT cured: three or more extra normal-priority streams created before
+// the handle's own (182 frames/s although the spin pair runs side by side) -- something below HIP's queue pool that a marker kernel beside an
+// oversubscribed grid could not tell apart from ordinary occupancy (tried, removed).
+#ifndef TD_EMU
+__global__ void k_queue_probe_spin(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
+static int streams_share_a_queue(hipStream_t a, hipStream_t x, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, bool* shared) {
+    float worst = 1e9f;
+    for (int rep = 0; rep < 2; ++rep) {                                // the better of two: a context switch on the host must not look like a shared queue
+        TD_HIP(hipEventRecord(e0, a));
+        TD_HIP(hipStreamWaitEvent(x, e0, 0));
+        TD_LAUNCH(k_queue_probe_spin, dim3(1), dim3(64), 0, a, 4000ull);
+        TD_LAUNCH(k_queue_probe_spin, dim3(1), dim3(64), 0, x, 4000ull);
+        TD_HIP(hipEventRecord(e1, a));
+        TD_HIP(hipEventRecord(e2, x));
+        TD_HIP(hipStreamWaitEvent(a, e2, 0));                          // the caller's stream stays ordered behind everything this enqueued
+        TD_HIP(hipEventSynchronize(e1));
+        TD_HIP(hipEventSynchronize(e2));
+        float t1 = 0.f, t2 = 0.f;
+        TD_HIP(hipEventElapsedTime(&t1, e0, e1));
+        TD_HIP(hipEventElapsedTime(&t2, e0, e2));
+        worst = std::min(worst, std::max(t1, t2));
+    }
+    *shared = worst > 0.064f;                                          // 40 us each: 40-45 us side by side, 80+ us one after the other
+    if (getenv("TDNET_QUEUE_CHECK_VERBOSE")) fprintf(stderr, "tdnet queue check: spin pair %.1f us\n", worst * 1e3f);
+    return 0;
+}
+#endif
+static int place_chain_stream(tdnet* n, hipStream_t s) {
+    if (!n->chain2 || n->part_g || (n->placed && n->placed_for == (void*)s)) return 0;
+    n->placed = true; n->placed_for = (void*)s;
+#ifndef TD_EMU
+    if (getenv("TDNET_NO_QUEUE_CHECK")) return 0;                      // A/B of this very mechanism (tools/ab_opts.py)
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    TD_HIP(hipEventCreate(&e0)); TD_HIP(hipEventCreate(&e1)); TD_HIP(hipEventCreate(&e2));
+    int rc = 0;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        bool shared = false;
+        if ((rc = streams_share_a_queue(s, n->chain2, e0, e1, e2, &shared)) != 0 || !shared) break;
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+        n->retired_streams.push_back(n->chain2);
+        n->chain2 = fresh;
+        n->chain_replaced++;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    return rc;
+#else
+    return 0;
+#endif
+}
+
 static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s);
 static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
     const int rc = forward_lowres_impl(n, img, pos_id, s);
@@ -1577,6 +1654,7 @@ static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream
     PathLayers& L = n->paths[pos_id];
     n->nrec = 0;
     n->failed = false;
+    TD_TRY(place_chain_stream(n, s));
     TD_TRY(retire_stale_chain(n, s));
     const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
     if (steady) {
@@ -1631,6 +1709,7 @@ extern "C" int tdnet_encode(tdnet_t* n, const float* img, int pos_id, void* stre
     if (n->pending_slot >= 0) return td_fail("tdnet_encode: the previous encoded frame has not been propagated");
     n->nrec = 0;
     n->failed = false;
+    TD_TRY(place_chain_stream(n, (hipStream_t)stream));
     TD_TRY(retire_stale_chain(n, (hipStream_t)stream));
     if (encode_frame(n, n->paths[pos_id], img, (hipStream_t)stream)) { rejoin_streams(n, (hipStream_t)stream); return -1; }
     n->pending_pos = pos_id;
