@@ -882,12 +882,7 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
         }
     }
     if (n->seg_block >= 0) {
-        // (Round 4, tools/idle_handle_probe.py + stream_overlap_probe.hip + queue_pipe_probe.hip, profiles/r04k_*: with an ODD number of
-        // idle handles alive in the process this handle's frame ran at 0.63x -- its two chains serialised.  HIP deals normal-priority
-        // streams onto a pool of 4 hardware queues and two streams on one queue serialise; but creating chain2 at the highest priority
-        // -- another pool: never the caller's queue in the probe -- left the pattern in place (192 / 336 / 192 frames/s), so a second
-        // mechanism below HIP decides whether two queues dispatch side by side.  Not controllable from here: a process that keeps many
-        // handles should destroy the idle ones)
+        // (Which hardware queue this stream gets is HIP's choice; place_chain_stream() checks it against the caller's at the first frame.)
         TD_HIP(hipStreamCreateWithFlags(&n->chain2, hipStreamNonBlocking));
         TD_HIP(hipEventCreateWithFlags(&n->ev_cfork, hipEventDisableTiming));
         TD_HIP(hipEventCreateWithFlags(&n->ev_cjoin, hipEventDisableTiming));
