@@ -45,6 +45,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # before the HIP runtime starts (tdnet_amd/__init__.py says why: 275 -> 185 frames/s behind RCCL otherwise)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_FP16_MFMA_TFLOPS = 2500.0
@@ -488,6 +489,7 @@ def main():
            "host_launch_us_per_frame": [round(v, 1) for v in host_rank],
            "cpu_affinity": aff_rank if aff_rank is not None else "not pinned (N = 1: the whole host, %d CPUs allowed)" % (len(allowed0) if allowed0 else os.cpu_count() or 1),
            "omp_num_threads": (aff or {}).get("omp_num_threads", torch.get_num_threads()),
+           "hw_queues": __import__("tdnet_amd").hw_queue_note(),
            "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, %d clip%s per GPU"
                                   % (mname, H, W, spec.fifo, C, "" if C == 1 else "s (concurrent HIP streams)"),
                       "parallelism": ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else

@@ -840,6 +840,17 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
             // applied to the fp32 map while staging it -- and the conv runs on the LDS-DMA kernel (1024x2048: 77 -> 46 us).
             if (n->cfg.model != 1 && L.head3.h16 && !L.head3.wino) { L.head3.in16 = true; dma(L.head3); if (!L.head3.rh) L.head3.in16 = false; }
         }
+    {   // A frame runs on three hardware queues at once; with HIP's default of 4 queues per priority class a process that creates a few
+        // streams of its own (torch's pools, RCCL) owns enough queues that they are no longer all resident, and frames run at 0.66x
+        // (tdnet_amd/__init__.py, profiles/r04l_*).  The Python package sets GPU_MAX_HW_QUEUES=2 before the runtime starts; a C caller is told once.
+        static bool told = false;
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        if (!told && !getenv("TDNET_QUIET") && (!q || atoi(q) > 3)) {
+            told = true;
+            fprintf(stderr, "tdnet: GPU_MAX_HW_QUEUES is %s; export GPU_MAX_HW_QUEUES=2 before the HIP runtime starts -- with more hardware queues "
+                            "alive in the process this handle's streams are time-sliced (275 -> 185 frames/s measured behind an RCCL communicator)\n", q ? q : "not set");
+        }
+    }
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
     TD_HIP(hipDeviceSynchronize());

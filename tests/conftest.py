@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")      # before any GPU call of the test process (tdnet_amd/__init__.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p_ in (ROOT, os.path.join(ROOT, "tests")):
     if p_ not in sys.path:

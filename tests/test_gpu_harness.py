@@ -103,6 +103,30 @@ def test_bench_four_ranks_one_perturbed_rank_fails():
     assert len(line["cpu_affinity"]) == 4 and len(line["host_launch_us_per_frame"]) == 4 and min(line["host_launch_us_per_frame"]) > 0
 
 
+def test_a_handle_created_behind_an_rccl_communicator_runs_at_full_rate():
+    """The order of every multi-GPU run: init_process_group("nccl") (torch creates its stream pools, RCCL its queues), THEN the model.
+    With HIP's default of 4 hardware queues per priority class such a handle ran at 0.67x (185 instead of 275 frames/s: the process owns
+    more queues than stay resident and the frame's three streams are time-sliced); the package sets GPU_MAX_HW_QUEUES=2 at import
+    (tdnet_amd/__init__.py).  World size 1 over nccl on the box's one GPU, tools/rccl_streams_probe.py: the rate behind the communicator
+    must be within 8 % of the rate without one; the old default is run as well and printed, not asserted (it is the platform's behaviour)."""
+    import re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GPU_MAX_HW_QUEUES")}
+
+    def rate(mode, **env):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_streams_probe.py"), mode], env=dict(base, **env), cwd=root,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode(errors="replace")
+        m = re.search(r": ([0-9.]+) frames/s", out)
+        assert r.returncode == 0 and m, out[-2000:]
+        return float(m.group(1))
+    plain, behind = rate("none"), rate("nccl_first")
+    old = rate("nccl_first", GPU_MAX_HW_QUEUES="4")
+    print("td4-psp18 1024x2048: %.1f frames/s alone, %.1f behind an RCCL communicator (package default GPU_MAX_HW_QUEUES=2), %.1f with HIP's default of 4"
+          % (plain, behind, old))
+    assert behind >= 0.92 * plain, (plain, behind, old)
+
+
 def test_bench_line_carries_measured_hbm_traffic_of_the_dominant_kernel():
     """`roofline.traffic` comes from live rocprofv3 counter passes matched to the dominant kernel BY NAME: when the default GEMM kernel
     changed (k_gemm_persistent -> k_gemm_dma) the pattern went stale and the field silently became null.  A quarter-size frame, both legs:
