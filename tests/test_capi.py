@@ -150,3 +150,18 @@ def test_model_classes_mirror_reference_api():
     assert res.missing_keys == [] and res.unexpected_keys == []
     res = m2.load_state_dict(part)                                # strict: kept as given; the C library rejects it when the handle is built
     assert "not.in.the.reference" in m2.state_dict()
+
+
+def test_the_package_caps_the_hardware_queues_before_the_runtime_starts():
+    """tdnet_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 2 (a handle created behind an RCCL communicator otherwise runs at 0.67x) unless the
+    environment already says otherwise; bench.py, conftest.py and __graft_entry__.py set it before they import torch."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    code = "import os, sys; sys.path.insert(0, %r); import tdnet_amd; print(os.environ['GPU_MAX_HW_QUEUES'], '|', tdnet_amd.hw_queue_note())" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out.startswith("2 |") and "set by tdnet_amd at import" in out, out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="3"), stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert out.startswith("3 |") and "from the environment" in out, out
+    for f in ("bench.py", "__graft_entry__.py", os.path.join("tests", "conftest.py")):
+        src = open(os.path.join(ROOT, f)).read()
+        assert src.index('setdefault("GPU_MAX_HW_QUEUES"') < (src.index("import torch") if "import torch" in src else len(src)), f
