@@ -127,6 +127,28 @@ def test_a_handle_created_behind_an_rccl_communicator_runs_at_full_rate():
     assert behind >= 0.92 * plain, (plain, behind, old)
 
 
+def test_idle_handles_do_not_slow_a_busy_one():
+    """tools/idle_handle_probe.py: the C2 workload beside 0 / 1 / 2 / 3 idle td4 handles.  HIP reuses hardware queues once its pool is full;
+    with an odd number of idle handles alive the busy handle's second row-parity chain used to land on the CALLER's queue and the frame ran
+    at 0.63x (335 / 212 / 335 / 212 frames/s).  The first frame now checks the pair with two spin kernels and replaces the internal stream
+    (td_model.hip place_chain_stream).  Run under HIP's default pool size (4), where the collision occurs; TDNET_NO_QUEUE_CHECK=1 shows the
+    old behaviour (printed, not asserted)."""
+    import re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+    def rates(**extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "idle_handle_probe.py")], env=dict(env, GPU_MAX_HW_QUEUES="4", TDNET_QUIET="1", **extra),
+                           cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode(errors="replace")
+        v = [float(x) for x in re.findall(r"alive: ([0-9.]+) frames/s", out)]
+        assert r.returncode == 0 and len(v) == 4, out[-2000:]
+        return v
+    got, old = rates(), rates(TDNET_NO_QUEUE_CHECK="1")
+    print("busy handle beside 0..3 idle ones, frames/s: %s with the queue check, %s without" % (got, old))
+    assert min(got) >= 0.9 * got[0], (got, old)
+
+
 def test_bench_line_carries_measured_hbm_traffic_of_the_dominant_kernel():
     """`roofline.traffic` comes from live rocprofv3 counter passes matched to the dominant kernel BY NAME: when the default GEMM kernel
     changed (k_gemm_persistent -> k_gemm_dma) the pattern went stale and the field silently became null.  A quarter-size frame, both legs:
