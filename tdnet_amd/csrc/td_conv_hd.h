@@ -52,7 +52,9 @@ enum ConvDmaCode {
     CD_128_F = 23,        // loader + matrix waves handing buffers over through LDS flags, no barrier in the K loop (k_conv_dma_h3f): 128 rows, eight matrix waves
     CD_192_F = 24,        // ... 192 rows
     CD_256_F = 25,        // ... 256 rows
-    CD_128_F4 = 26        // ... 128 rows, four matrix waves of 64 x 64
+    CD_128_F4 = 26,       // ... 128 rows, four matrix waves of 64 x 64
+    CD_128_P8 = 27,       // k_conv_dma_h3p with EIGHT loader waves: 128 rows
+    CD_192_P8 = 28        // ... 192 rows
 };
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
@@ -597,7 +599,7 @@ struct ConvDmaPGeom {
 // matrix waves [0] step start, [1] first k-group's MFMAs issued, [2] all MFMAs issued, [3] after the barrier;
 // loader waves [0] step start, [1] pieces issued, [2] after the counted wait, [3] after the barrier
 #define TD_P_STAMP(st_, slot) do { if (blockIdx.x < 4 && (st_) < 24 && lane == 0) \
-    TD_P_TRACE[(((size_t)blockIdx.x * 12 + wave) * 24 + (st_)) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+    TD_P_TRACE[(((size_t)blockIdx.x * 16 + wave) * 24 + (st_)) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TD_P_STAMP(st_, slot) ((void)0)
 #endif
@@ -781,6 +783,8 @@ static inline bool conv_launch_dma3p(ConvArgs a, int rh, int KS, bool out16, hip
         case CD_128_P4: return conv_launch_dma3p_t<2, 2, 4, 5>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 6>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 8>(a, out16, s);
         case CD_192_P: return conv_launch_dma3p_t<3, 2, 4, 7>(a, out16, s) || conv_launch_dma3p_t<3, 2, 4, 9>(a, out16, s);
         case CD_256_P: return conv_launch_dma3p_t<4, 2, 4, 9>(a, out16, s) || conv_launch_dma3p_t<4, 2, 4, 11>(a, out16, s);
+        case CD_128_P8: return conv_launch_dma3p_t<2, 1, 8, 3>(a, out16, s) || conv_launch_dma3p_t<2, 1, 8, 4>(a, out16, s);   // EIGHT loader waves (two per SIMD): 16 waves per workgroup
+        case CD_192_P8: return conv_launch_dma3p_t<3, 2, 8, 4>(a, out16, s) || conv_launch_dma3p_t<3, 2, 8, 5>(a, out16, s);
         case CD_128_PR: return conv_launch_dma3p_t<2, 1, 4, 6, 5>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 8, 5>(a, out16, s);   // rotated K walk (experiment)
         case CD_192_PR: return conv_launch_dma3p_t<3, 2, 4, 9, 5>(a, out16, s);
         default: return false;

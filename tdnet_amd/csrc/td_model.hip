@@ -1033,9 +1033,10 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     } else if (L.h16 && L.rh) {                                         // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
         int rh = L.rh;
         const bool flags = rh == CD_128_F || rh == CD_192_F || rh == CD_256_F || rh == CD_128_F4;      // loader + matrix waves, LDS flags (k_conv_dma_h3f)
-        const bool loaders = flags || rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR;   // dedicated loader waves (k_conv_dma_h3p)
+        const bool loaders = flags || rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR ||
+                             rh == CD_128_P8 || rh == CD_192_P8;   // dedicated loader waves (k_conv_dma_h3p)
         if (loaders && (L.rowimg_off || !(flags ? conv_launch_dma3f(a, rh, L.KS, L.out16, s) : conv_launch_dma3p(a, rh, L.KS, L.out16, s))))
-            rh = (rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F) ? CD_192 : (rh == CD_256_P || rh == CD_256_F) ? CD_256 : CD_128_8W;                        // not a 3x3 "same" conv / halo too wide: the plain forms
+            rh = (rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F || rh == CD_192_P8) ? CD_192 : (rh == CD_256_P || rh == CD_256_F) ? CD_256 : CD_128_8W;                        // not a 3x3 "same" conv / halo too wide: the plain forms
         if (rh != L.rh || !loaders)
             if (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s)) conv_launch_dma(a, rh, L.KS, L.out16, s);
     }
@@ -1948,11 +1949,12 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (no_rowimg) tile -= 32;
     static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
                                          CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
-    static const int code_of_tile_p[10] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
-                                           CD_128_F, CD_192_F, CD_256_F, CD_128_F4};                           // 37 .. 40: the same without a barrier in the K loop (k_conv_dma_h3f)
-    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 40 ? code_of_tile_p[tile - 31] : 0;   // 30: the weights-resident 64 -> 64 kernel
+    static const int code_of_tile_p[12] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
+                                           CD_128_F, CD_192_F, CD_256_F, CD_128_F4,                            // 37 .. 40: the same without a barrier in the K loop (k_conv_dma_h3f)
+                                           CD_128_P8, CD_192_P8};                                              // 41 / 42: eight loader waves
+    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 42 ? code_of_tile_p[tile - 31] : 0;   // 30: the weights-resident 64 -> 64 kernel
     if (force_rh) tile = force_rh == CD_W64 ? CT_128x64 : CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..40 (+ 32 for 16..29)", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..42 (+ 32 for 16..29)", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;

@@ -5,7 +5,7 @@
 // args: code (17 = 128 rows / 8 matrix waves, 20 = 128 rows / 4, 18 = 192 rows, 19 = 256 rows) H W Cin Cout dil
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value tools/conv_h3p_trace.hip -o tools/_build/conv_h3p_trace
 #include <hip/hip_runtime.h>
-__device__ unsigned long long TD_P_TRACE[4 * 12 * 24 * 4];
+__device__ unsigned long long TD_P_TRACE[4 * 16 * 24 * 4];
 #define TD_P_TRACE TD_P_TRACE
 #include "../tdnet_amd/csrc/td_device.h"
 #include "../tdnet_amd/csrc/td_conv_hd.h"
@@ -44,18 +44,19 @@ int main(int argc, char** argv) {
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     printf("tile code %d, %d x %d x %d -> %d, dilation %d, %d K steps: %.1f us per launch (with the stamps), %.0f TFLOP/s\n", code, H, W, Cin, Cout, dil, nsteps, ms / 5 * 1e3,
            2.0 * H * W * Cin * 9.0 * Cout / (ms / 5 * 1e-3) / 1e12);
-    std::vector<unsigned long long> t(4 * 12 * 24 * 4);
+    std::vector<unsigned long long> t(4 * 16 * 24 * 4);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(TD_P_TRACE), t.size() * 8);
-    const int nwc = code == CD_128_P || code == CD_256_P || code == CD_128_PR || code == CD_128_F || code == CD_256_F ? 8 : code == CD_128_P4 || code == CD_128_F4 ? 4 : 6;
+    const int nwc = code == CD_128_P || code == CD_256_P || code == CD_128_PR || code == CD_128_F || code == CD_256_F || code == CD_128_P8 ? 8 : code == CD_128_P4 || code == CD_128_F4 ? 4 : 6;
+    const int nld = code == CD_128_P8 || code == CD_192_P8 ? 8 : 4;
     const int ns = nsteps < 24 ? nsteps : 24;
     for (int wg = 0; wg < 2; ++wg) {
         printf("workgroup %d: mean over steps 3..%d, shader cycles.  matrix waves: [to first group issued, rest of the MFMAs issued, to the barrier's end]; loaders: [issue, vmcnt wait, barrier]\n", wg, ns - 1);
-        for (int wv = 0; wv < nwc + 4; ++wv) {
+        for (int wv = 0; wv < nwc + nld; ++wv) {
             double d[3] = {0, 0, 0}, per = 0;
             int cnt = 0;
             for (int s = 3; s < ns; ++s, ++cnt) {
-                const unsigned long long* q = &t[(((size_t)wg * 12 + wv) * 24 + s) * 4];
-                const unsigned long long prev = t[(((size_t)wg * 12 + wv) * 24 + s - 1) * 4 + 3];
+                const unsigned long long* q = &t[(((size_t)wg * 16 + wv) * 24 + s) * 4];
+                const unsigned long long prev = t[(((size_t)wg * 16 + wv) * 24 + s - 1) * 4 + 3];
                 d[0] += (double)(q[1] - q[0]); d[1] += (double)(q[2] - q[1]); d[2] += (double)(q[3] - q[2]);
                 per += (double)(q[3] - prev);
             }
@@ -64,9 +65,9 @@ int main(int argc, char** argv) {
     }
     printf("workgroup 0, steps 6..8, stamps relative to step 6's start of matrix wave 0:\n");
     const unsigned long long base = t[(6) * 4 + 0];
-    for (int wv = 0; wv < nwc + 4; ++wv) {
+    for (int wv = 0; wv < nwc + nld; ++wv) {
         printf("  wave %2d:", wv);
-        for (int s = 6; s < 9; ++s) for (int k = 0; k < 4; ++k) printf(" %6lld", (long long)(t[(((size_t)0 * 12 + wv) * 24 + s) * 4 + k] - base));
+        for (int s = 6; s < 9; ++s) for (int k = 0; k < 4; ++k) printf(" %6lld", (long long)(t[(((size_t)0 * 16 + wv) * 24 + s) * 4 + k] - base));
         printf("\n");
     }
     return 0;
