@@ -7,7 +7,7 @@ TAG=${1:-pmc}; shift
 R=gpurun_out/$TAG
 rm -rf $R; mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 6 --no-cpu-baseline --no-pmc --no-direct-line $*"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 6 --quick $*"
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d "$GRAFT_REPO_ROOT/$R/pmc_sq" -o r1 -- $B > "$GRAFT_REPO_ROOT/$R/pmc_sq.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$GRAFT_REPO_ROOT/$R/pmc_fetch" -o r1 -- $B > "$GRAFT_REPO_ROOT/$R/pmc_fetch.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$GRAFT_REPO_ROOT/$R/pmc_write" -o r1 -- $B > "$GRAFT_REPO_ROOT/$R/pmc_write.log" 2>&1
