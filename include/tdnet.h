@@ -40,8 +40,9 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 8230   /* 2 | 4 | 32 | 8192; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
-                                       bit 8192 (precision 1 only) since round 4: 1042 -> 1053 frames/s at 720x960 fp16, bit-identical (profiles/r04j_*) */
+#define TDNET_FUSION_DEFAULT 40998   /* 2 | 4 | 32 | 8192 | 32768; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+                                       bits 8192 and 32768 (precision 1 only) since round 4: 1042 -> 1053 -> (see DESIGN) frames/s at 720x960 fp16, bit-identical
+                                       (profiles/r04j_*, r04x_*) */
 #define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
@@ -78,6 +79,8 @@ typedef struct tdnet_opts {
                                      resident in LDS (k_conv_dma_w64; measured no faster than the per-tile kernel: one wave per SIMD),
                                 8192 = precision 1 only (default): the 128 / 192 x 128 tiles of the LDS-DMA conv with four dedicated LOADER waves per
                                      workgroup (k_conv_dma_h3p: the matrix waves never issue vector memory inside the K loop); bit-identical,
+                                32768 = precision 1 only (default): on maps of <= 16384 output pixels the 3x3 "same" convs with <= 256 output channels run on
+                                     NARROW tiles (128 / 192 rows x 64 channels, k_conv_dma_h3n: half the weight bytes per K step and CU); bit-identical,
                                 16384 = precision 1 only: loader and matrix waves with NO workgroup barrier in the K loop -- buffers change hands through
                                      LDS flags, rings of 2-3 images and 4-5 weight steps (k_conv_dma_h3f); bit-identical.  Measured SLOWER (an LDS round
                                      trip is 300-600 cycles on a CU whose LDS carries the DMA writes and twelve waves' reads: every hand-over

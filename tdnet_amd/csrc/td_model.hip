@@ -826,7 +826,13 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
                 if (!c.h16 || !c.in16 || c.stem || (n->opts.fusion & 128)) return;
                 if (c.Cout >= 128 && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile)) {
                     c.rh = conv_dma_pick_rh(c.M_out, c.Cout, c.CoutPad % 256 == 0 && !(n->opts.fusion & 1024));
-                    if (n->opts.fusion & 16384)                         // loader + matrix waves, buffers handed over through LDS flags (k_conv_dma_h3f)
+                    // Small maps (720x960: 10800 output pixels): a 3x3 "same" conv with <= 256 output channels on NARROW tiles (rows x 64
+                    // channels, k_conv_dma_h3n) -- half the weight bytes per K step and CU, the term that dominates there: 128 channels
+                    // 13.8 -> 10.3 us, 256 channels 20.6 -> 19.8 us isolated (profiles/r04u_*).  No gain at 32768 pixels.
+                    const bool same3 = c.KS == 3 && c.stride == 1 && c.pad == c.dil;
+                    if ((n->opts.fusion & 32768) && same3 && c.M_out <= 16384 && c.Cout <= 256)
+                        c.rh = c.Cout <= 128 ? CD_128_N : CD_192_N;       // (256 channels on 128 x 64 tiles as well: 2.1 % instead of 2.6 % in the frame)
+                    else if (n->opts.fusion & 16384)                         // loader + matrix waves, buffers handed over through LDS flags (k_conv_dma_h3f)
                         c.rh = c.rh == CD_128 ? CD_128_F : c.rh == CD_192 ? CD_192_F : c.rh == CD_256 ? CD_256_F : c.rh;
                     else if (n->opts.fusion & 8192)                     // the 128- and 192-row tiles with four dedicated loader waves (k_conv_dma_h3p):
                         c.rh = c.rh == CD_128 ? CD_128_P : c.rh == CD_192 ? CD_192_P : c.rh;   // isolated 22.5 -> 21.0 / 57.8 -> 56.7 us; 256 rows: no gain (profiles/r04d_*)
@@ -1031,14 +1037,33 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     else if (L.h16 && L.rh == CD_W64) {                                 // 64 -> 64 channels: persistent workgroups with the weights resident in LDS
         if (!conv_launch_dma_w64(a, L.out16, s)) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     } else if (L.h16 && L.rh) {                                         // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
+        // A cascade of kernel forms for the SAME tile, each falling back to the next when the conv does not qualify (not a 3x3 "same" conv,
+        // halo wider than the form's image buffer): super-step barriers -> loader waves / LDS flags -> row images -> tap by tap.
         int rh = L.rh;
-        const bool flags = rh == CD_128_F || rh == CD_192_F || rh == CD_256_F || rh == CD_128_F4;      // loader + matrix waves, LDS flags (k_conv_dma_h3f)
-        const bool loaders = flags || rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR ||
-                             rh == CD_128_P8 || rh == CD_192_P8;   // dedicated loader waves (k_conv_dma_h3p)
-        if (loaders && (L.rowimg_off || !(flags ? conv_launch_dma3f(a, rh, L.KS, L.out16, s) : conv_launch_dma3p(a, rh, L.KS, L.out16, s))))
-            rh = (rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F || rh == CD_192_P8) ? CD_192 : (rh == CD_256_P || rh == CD_256_F) ? CD_256 : CD_128_8W;                        // not a 3x3 "same" conv / halo too wide: the plain forms
-        if (rh != L.rh || !loaders)
-            if (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s)) conv_launch_dma(a, rh, L.KS, L.out16, s);
+        bool done = false;
+        if (rh == CD_128_D || rh == CD_128_DN || rh == CD_192_DN || rh == CD_256_DN) {   // deep pipeline (k_conv_dma_h3d)
+            done = !L.rowimg_off && conv_launch_dma3d(a, rh, L.KS, L.out16, s);
+            if (!done) rh = rh == CD_128_D ? CD_128_P : rh == CD_128_DN ? CD_128_N : rh == CD_192_DN ? CD_192_N : CD_256_N;
+        }
+        const bool is192 = rh == CD_192_S || rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F || rh == CD_192_P8 || rh == CD_192_N;
+        const bool is256 = rh == CD_256_P || rh == CD_256_F || rh == CD_256_N;
+        if (rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {        // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
+            done = !L.rowimg_off && conv_launch_dma3n(a, rh, L.KS, L.out16, s);
+            if (!done) rh = is192 ? CD_192_P : is256 ? CD_256_P : CD_128_P;
+        }
+        if (rh == CD_128_S || rh == CD_192_S) {                          // loader waves, one barrier per super-step (k_conv_dma_h3s)
+            done = !L.rowimg_off && conv_launch_dma3s(a, rh, L.KS, L.out16, s);
+            if (!done) rh = is192 ? CD_192_P : CD_128_P;
+        }
+        if (!done && (rh == CD_128_F || rh == CD_192_F || rh == CD_256_F || rh == CD_128_F4)) {           // loader + matrix waves, LDS flags (k_conv_dma_h3f)
+            done = !L.rowimg_off && conv_launch_dma3f(a, rh, L.KS, L.out16, s);
+            if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
+        }
+        if (!done && (rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR || rh == CD_128_P8 || rh == CD_192_P8)) {
+            done = !L.rowimg_off && conv_launch_dma3p(a, rh, L.KS, L.out16, s);                           // dedicated loader waves (k_conv_dma_h3p)
+            if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
+        }
+        if (!done && (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s))) conv_launch_dma(a, rh, L.KS, L.out16, s);
     }
     else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
@@ -1945,16 +1970,19 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     // four / two LDS buffers whatever the grid (16 chooses by the grid); 22: 128 rows, eight waves; 23 / 26: the same on row images with one
     // barrier per super-step / per K step only; 24 / 25: 192 rows likewise; 27 / 28 / 29: 256 / 192 / 128 rows in the early-landing form
     // only; -1: the heuristic (DMA kernel where it applies)
-    const bool no_rowimg = tile >= 48;                                 // 48 + code: the same tile, tap-by-tap staging (k_conv_dma_h) instead of row images
+    const bool no_rowimg = tile >= 48 && tile < 64;                    // 48 + code: the same tile, tap-by-tap staging (k_conv_dma_h) instead of row images
     if (no_rowimg) tile -= 32;
     static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
                                          CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
-    static const int code_of_tile_p[12] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
+    static const int code_of_tile_p[21] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
                                            CD_128_F, CD_192_F, CD_256_F, CD_128_F4,                            // 37 .. 40: the same without a barrier in the K loop (k_conv_dma_h3f)
-                                           CD_128_P8, CD_192_P8};                                              // 41 / 42: eight loader waves
-    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 42 ? code_of_tile_p[tile - 31] : 0;   // 30: the weights-resident 64 -> 64 kernel
+                                           CD_128_P8, CD_192_P8, CD_128_S, CD_192_S,                           // 41 / 42: eight loader waves; 43 / 44: one barrier per super-step (k_conv_dma_h3s)
+                                           CD_128_N, CD_192_N, CD_256_N,                                       // 45 .. 47: narrow tiles, rows x 64 channels (k_conv_dma_h3n)
+                                           CD_128_D, CD_128_DN, CD_192_DN, CD_256_DN};                         // 64 .. 67 (NOT 48+: those mean "tap by tap"): deep pipeline (k_conv_dma_h3d)
+    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 47 ? code_of_tile_p[tile - 31]
+                       : tile >= 64 && tile <= 67 ? code_of_tile_p[tile - 64 + 17] : 0;   // 30: the weights-resident 64 -> 64 kernel
     if (force_rh) tile = force_rh == CD_W64 ? CT_128x64 : CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..42 (+ 32 for 16..29)", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d, 16..47 (+ 32 for 16..29) or 64..67", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;
@@ -1966,6 +1994,7 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
     L.in16 = L.out16 = true;
     L.rowimg_off = no_rowimg;
+    if (const char* e = getenv("TDNET_PROBE_STAGGER")) L.stagger = atoi(e);   // probes only: k_conv_dma_h3n decomposition (no fetch / no DMA / no MFMA)
     if (force_rh == CD_256x256 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
     if (force_rh == CD_W64 ? !conv_dma_w64_supports(Cin, Cout, L.CoutPad, KS, stride, dil, pad) : (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile))) {
         free_conv_layer(L);

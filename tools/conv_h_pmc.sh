@@ -24,7 +24,10 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_MFMA" \
-           "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE"; do
+           "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" \
+           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum" \
+           "SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_MISC SQ_LDS_ADDR_CONFLICT" \
+           "TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_TAG_STALL_sum TCC_BUSY_sum TCC_REQ_sum"; do
   i=$((i+1))
   timeout 200 rocprofv3 --kernel-trace --output-format csv --pmc $set -d $R/p$i -o r1 -- python /tmp/ch.py > $R/p$i.log 2>&1
 done
@@ -32,7 +35,7 @@ cd "$GRAFT_REPO_ROOT"
 python - "$R" <<'PY' | tee $R/summary.txt
 import csv, glob, collections, sys
 R = sys.argv[1]
-for i in range(1, 5):
+for i in range(1, 8):
     fs = glob.glob(R + "/p%d/**/*counter_collection.csv" % i, recursive=True)
     tr = glob.glob(R + "/p%d/**/*kernel_trace.csv" % i, recursive=True)
     if not fs or not tr:
