@@ -63,7 +63,8 @@ enum ConvDmaCode {
     CD_128_D = 34,        // DEEP pipeline (k_conv_dma_h3d: five weight buffers, whole-step fragment sets): 128 x 128
     CD_128_DN = 35,       // ... 128 x 64
     CD_192_DN = 36,       // ... 192 x 64
-    CD_256_DN = 37        // ... 256 x 64
+    CD_256_DN = 37,       // ... 256 x 64
+    CD_192_P1 = 38        // k_conv_dma_h3p, 192 x 128 with twelve matrix waves of 32 x 64 (sixteen waves per workgroup)
 };
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
@@ -792,6 +793,7 @@ static inline bool conv_launch_dma3p(ConvArgs a, int rh, int KS, bool out16, hip
         case CD_128_P4: return conv_launch_dma3p_t<2, 2, 4, 5>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 6>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 8>(a, out16, s);
         case CD_192_P: return conv_launch_dma3p_t<3, 2, 4, 7>(a, out16, s) || conv_launch_dma3p_t<3, 2, 4, 9>(a, out16, s);
         case CD_256_P: return conv_launch_dma3p_t<4, 2, 4, 9>(a, out16, s) || conv_launch_dma3p_t<4, 2, 4, 11>(a, out16, s);
+        case CD_192_P1: return conv_launch_dma3p_t<3, 1, 4, 7>(a, out16, s) || conv_launch_dma3p_t<3, 1, 4, 9>(a, out16, s);   // TWELVE matrix waves of 32 x 64: three per SIMD (six of 64 x 64 leave two SIMDs with twice the MFMAs)
         case CD_128_P8: return conv_launch_dma3p_t<2, 1, 8, 3>(a, out16, s) || conv_launch_dma3p_t<2, 1, 8, 4>(a, out16, s);   // EIGHT loader waves (two per SIMD): 16 waves per workgroup
         case CD_192_P8: return conv_launch_dma3p_t<3, 2, 8, 4>(a, out16, s) || conv_launch_dma3p_t<3, 2, 8, 5>(a, out16, s);
         case CD_128_PR: return conv_launch_dma3p_t<2, 1, 4, 6, 5>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 8, 5>(a, out16, s);   // rotated K walk (experiment)

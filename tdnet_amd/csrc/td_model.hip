@@ -835,7 +835,9 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
                     else if (n->opts.fusion & 16384)                         // loader + matrix waves, buffers handed over through LDS flags (k_conv_dma_h3f)
                         c.rh = c.rh == CD_128 ? CD_128_F : c.rh == CD_192 ? CD_192_F : c.rh == CD_256 ? CD_256_F : c.rh;
                     else if (n->opts.fusion & 8192)                     // the 128- and 192-row tiles with four dedicated loader waves (k_conv_dma_h3p):
-                        c.rh = c.rh == CD_128 ? CD_128_P : c.rh == CD_192 ? CD_192_P : c.rh;   // isolated 22.5 -> 21.0 / 57.8 -> 56.7 us; 256 rows: no gain (profiles/r04d_*)
+                        c.rh = c.rh == CD_128 ? CD_128_P : c.rh == CD_192 ? CD_192_P : c.rh;
+                        // isolated 22.5 -> 21.0 / 57.8 -> 56.7 us; 256 rows: no gain (profiles/r04d_*).  (192 rows with TWELVE matrix waves of 32 x 64 -- three
+                        // per SIMD instead of two SIMDs with twice the MFMAs -- is 3-5 % faster alone and 0.6 % SLOWER in the frame: profiles/r04z_*.)
                 }
                 else if ((n->opts.fusion & 4096) && conv_dma_w64_supports(c.Cin, c.Cout, c.CoutPad, c.KS, c.stride, c.dil, c.pad))
                     c.rh = CD_W64;                                      // layer1: weights resident in LDS (k_conv_dma_w64; measured no faster, opt-in)
@@ -1045,7 +1047,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
             done = !L.rowimg_off && conv_launch_dma3d(a, rh, L.KS, L.out16, s);
             if (!done) rh = rh == CD_128_D ? CD_128_P : rh == CD_128_DN ? CD_128_N : rh == CD_192_DN ? CD_192_N : CD_256_N;
         }
-        const bool is192 = rh == CD_192_S || rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F || rh == CD_192_P8 || rh == CD_192_N;
+        const bool is192 = rh == CD_192_P1 || rh == CD_192_S || rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F || rh == CD_192_P8 || rh == CD_192_N;
         const bool is256 = rh == CD_256_P || rh == CD_256_F || rh == CD_256_N;
         if (rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {        // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
             done = !L.rowimg_off && conv_launch_dma3n(a, rh, L.KS, L.out16, s);
@@ -1059,7 +1061,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
             done = !L.rowimg_off && conv_launch_dma3f(a, rh, L.KS, L.out16, s);
             if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
         }
-        if (!done && (rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR || rh == CD_128_P8 || rh == CD_192_P8)) {
+        if (!done && (rh == CD_192_P1 || rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR || rh == CD_128_P8 || rh == CD_192_P8)) {
             done = !L.rowimg_off && conv_launch_dma3p(a, rh, L.KS, L.out16, s);                           // dedicated loader waves (k_conv_dma_h3p)
             if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
         }
@@ -1974,15 +1976,16 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (no_rowimg) tile -= 32;
     static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
                                          CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
-    static const int code_of_tile_p[21] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
+    static const int code_of_tile_p[22] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
                                            CD_128_F, CD_192_F, CD_256_F, CD_128_F4,                            // 37 .. 40: the same without a barrier in the K loop (k_conv_dma_h3f)
                                            CD_128_P8, CD_192_P8, CD_128_S, CD_192_S,                           // 41 / 42: eight loader waves; 43 / 44: one barrier per super-step (k_conv_dma_h3s)
                                            CD_128_N, CD_192_N, CD_256_N,                                       // 45 .. 47: narrow tiles, rows x 64 channels (k_conv_dma_h3n)
-                                           CD_128_D, CD_128_DN, CD_192_DN, CD_256_DN};                         // 64 .. 67 (NOT 48+: those mean "tap by tap"): deep pipeline (k_conv_dma_h3d)
+                                           CD_128_D, CD_128_DN, CD_192_DN, CD_256_DN,                          // 64 .. 67 (NOT 48+: those mean "tap by tap"): deep pipeline (k_conv_dma_h3d)
+                                           CD_192_P1};                                                         // 68: 192 x 128 with twelve matrix waves of 32 x 64
     const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 47 ? code_of_tile_p[tile - 31]
-                       : tile >= 64 && tile <= 67 ? code_of_tile_p[tile - 64 + 17] : 0;   // 30: the weights-resident 64 -> 64 kernel
+                       : tile >= 64 && tile <= 68 ? code_of_tile_p[tile - 64 + 17] : 0;   // 30: the weights-resident 64 -> 64 kernel
     if (force_rh) tile = force_rh == CD_W64 ? CT_128x64 : CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d, 16..47 (+ 32 for 16..29) or 64..67", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d, 16..47 (+ 32 for 16..29) or 64..68", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;
