@@ -297,7 +297,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
            "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1)}
     if dom_n > 0 and dom_ms > 0:
         ach = dom_fl / (dom_ms * 1e-3) / 1e12
-        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA)" if precision == "fp16"
+        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> / k_conv_dma_h3n<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA; since round 4 incl. the 128-channel layers of small maps)" if precision == "fp16"
                            else "k_gemm_dma<0> / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / (2 * P)}
@@ -597,8 +597,8 @@ def main():
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             if opts["precision"]:
-                kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> (dedicated loader waves) / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
-                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h3[pf]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
+                kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> (dedicated loader waves) / k_conv_dma_h3n<RH,..> (narrow tiles) / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
+                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h3[a-z]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:
