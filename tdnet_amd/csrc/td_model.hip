@@ -130,6 +130,7 @@ struct ConvLayer {
     bool rowimg_off = false;                                           // tdnet_opts.fusion bit 2048: keep the tap-by-tap LDS-DMA kernel
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
+    int probe = 0;                                                     // tdnet_op_conv2d_f16io under TDNET_PROBE_STAGGER only (never set by a handle)
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
     bool gdma = false;                                                 // the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h; tdnet_opts.overlap bit 8)
     int vw = 0;                                                        // != 0: the low-register F(4x4) transform kernels with vw channels per lane (td_wino.h k_wino4_*_c)
@@ -1033,7 +1034,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
+    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = (!n && L.probe) ? 100 + L.probe : 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || (L.rh && L.rh != CD_W64)) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
     else if (L.h16 && L.rh == CD_W64) {                                 // 64 -> 64 channels: persistent workgroups with the weights resident in LDS
@@ -1997,7 +1998,7 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
     L.in16 = L.out16 = true;
     L.rowimg_off = no_rowimg;
-    if (const char* e = getenv("TDNET_PROBE_STAGGER")) L.stagger = atoi(e);   // probes only: k_conv_dma_h3n decomposition (no fetch / no DMA / no MFMA)
+    if (const char* e = getenv("TDNET_PROBE_STAGGER")) L.probe = atoi(e);     // probes only: k_conv_dma_h3n decomposition (no fetch / no DMA / no MFMA)
     if (force_rh == CD_256x256 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
     if (force_rh == CD_W64 ? !conv_dma_w64_supports(Cin, Cout, L.CoutPad, KS, stride, dil, pad) : (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile))) {
         free_conv_layer(L);
