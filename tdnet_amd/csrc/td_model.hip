@@ -920,6 +920,13 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
 // ---------------------------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------------------------
+// TIMING PROBE ONLY (tools/ab_opts.py under TDNET_PROBE_SKIP=<mask>; results are garbage): what would the frame cost WITHOUT a piece of it?
+//   1 = no Winograd transforms, 2 = no cache-only attention chain, 4 = no final attention, 8 = no Winograd GEMMs.  Upper bounds for what any
+//   optimisation of that piece can return (DESIGN_experiments 8.6).
+static int probe_skip() {
+    static const int m = [] { const char* e = getenv("TDNET_PROBE_SKIP"); return e ? atoi(e) : 0; }();
+    return m;
+}
 static void prof_begin(tdnet* n, int family, int dominant, double flops, hipStream_t s) {
     if (!n || !n->prof) return;
     if (n->nrec == n->recs.size()) {
@@ -977,6 +984,7 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     wa.ln_mean = lnf ? lnf->mean : nullptr; wa.ln_rstd = lnf ? lnf->rstd : nullptr; wa.ln_g = lnf ? lnf->g : nullptr; wa.ln_b = lnf ? lnf->b : nullptr;
     wa.Tc = (int)Tc; wa.ny = ck.ny; wa.cy = ck.cy; wa.nx = ck.nx; wa.cx = ck.cx;
     auto transform = [&](bool out_side) {
+        if (n && (probe_skip() & 1)) return;
         prof_begin(n, 2, false, 0, s);
         const int C = out_side ? L.Cout : L.Cin;
         if (L.vw == 1) launch_wino4_c<1>(out_side, wa, s);
@@ -995,7 +1003,8 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         TD_HIP(hipStreamWaitEvent(waiter, after_in, 0));
     }
     prof_begin(n, 0, 2, 2.0 * nb * Tc * (double)L.Cin * L.Cout, s);
-    if (L.pers && gemm_supports(L.Cin)) {
+    if (n && (probe_skip() & 8)) { /* timing probe: no GEMMs */ }
+    else if (L.pers && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
         ga.M = (int)Tc; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP; ga.stagger = L.stagger;
@@ -1091,6 +1100,7 @@ static int run_attention(tdnet* n, const float* q, const float* k, const float* 
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
     a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
     a.ln_part = ln_part; a.ln_nstr = 0;
+    if (n && (probe_skip() & 4) && Lq > Lk) return 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
     const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
@@ -1200,6 +1210,7 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s, float* vp, int e
     hipStream_t c = n->side;
     TD_HIP(hipEventRecord(n->ev_fork, s));
     TD_HIP(hipStreamWaitEvent(c, n->ev_fork, 0));
+    if (probe_skip() & 2) { TD_HIP(hipEventRecord(n->ev_join, c)); return 0; }
     if (n->P == 4) {
         const CacheSlot &c0 = n->slots[e0], &c1 = n->slots[e1], &c2 = n->slots[e2];
         TD_TRY(run_conv(n, L.atn[0].fc, c0.v, 1, n->Lk, nullptr, vp, c));
@@ -1238,6 +1249,7 @@ static WinoArgs wino_chunk_args(const ConvLayer& L, const float* in, int H, int 
     return wa;
 }
 static void wino_transform_alone(tdnet* n, const ConvLayer& L, const WinoArgs& wa, bool out_side, hipStream_t s) {
+    if (n && (probe_skip() & 1)) return;
     prof_begin(n, 2, false, 0, s);
     const int C = out_side ? L.Cout : L.Cin;
     if (L.vw == 4 && C % 4 == 0) launch_wino4_c<4>(out_side, wa, s);
