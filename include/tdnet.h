@@ -80,11 +80,9 @@ typedef struct tdnet_opts {
                                 8192 = precision 1 only (default): the 128 / 192 x 128 tiles of the LDS-DMA conv with four dedicated LOADER waves per
                                      workgroup (k_conv_dma_h3p: the matrix waves never issue vector memory inside the K loop); bit-identical,
                                 32768 = precision 1 only (default): on maps of <= 16384 output pixels the 3x3 "same" convs with <= 256 output channels run on
-                                     NARROW tiles (128 / 192 rows x 64 channels, k_conv_dma_h3n: half the weight bytes per K step and CU); bit-identical,
-                                16384 = precision 1 only: loader and matrix waves with NO workgroup barrier in the K loop -- buffers change hands through
-                                     LDS flags, rings of 2-3 images and 4-5 weight steps (k_conv_dma_h3f); bit-identical.  Measured SLOWER (an LDS round
-                                     trip is 300-600 cycles on a CU whose LDS carries the DMA writes and twelve waves' reads: every hand-over
-                                     costs one; the 192 / 256-row forms spill): experiment, profiles/r04f_* .. r04j_*                          */
+                                     NARROW tiles (128 / 192 rows x 64 channels, k_conv_dma_h3n: half the weight bytes per K step and CU); bit-identical.
+                                     (16384 was an experiment removed in round 4 -- loader / matrix waves handing buffers over through LDS flags,
+                                     slower -- and is ignored.)                                                                              */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
                                 1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -22,6 +22,12 @@ STAMP_MARK = b"tdnet-src-hash:"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off"]
 
 
+def extra_flags():
+    """TDNET_EXTRA_CXXFLAGS: flags of a NON-shipping build (e.g. -DTDNET_TIMING_PROBES for tools/ab_opts.py's skip probe).  Part of the stamp, so
+    such a library never passes for the one the default flags build: a process without the variable rebuilds it."""
+    return os.environ.get("TDNET_EXTRA_CXXFLAGS", "").split()
+
+
 def sources():
     """The regular *.h / *.hip files of csrc/ + the C-ABI header: an editor backup, a stray directory or a build product next to them
     neither changes the stamp nor breaks the hash."""
@@ -41,7 +47,7 @@ def source_hash():
     """sha256 over (file name, content) of every source + the compile flags + the ROCm release, 16 hex digits: a change of
     -ffp-contract or of the target arch rebuilds like a change of a kernel does."""
     h = hashlib.sha256()
-    h.update((" ".join(FLAGS) + "\0" + toolchain_id() + "\0").encode())
+    h.update((" ".join(FLAGS + extra_flags()) + "\0" + toolchain_id() + "\0").encode())
     for p in sources():
         h.update(os.path.basename(p).encode() + b"\0")
         with open(p, "rb") as f:
@@ -65,7 +71,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ['-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, "td_model.hip"), "-o", OUT]
+    cmd = [hipcc] + FLAGS + extra_flags() + ['-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, "td_model.hip"), "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

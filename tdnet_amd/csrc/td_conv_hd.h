@@ -46,25 +46,9 @@ enum ConvDmaCode {
     CD_128_P = 17,        // row-image kernel with four dedicated loader waves (k_conv_dma_h3p): 128 rows, eight matrix waves of 32 x 64
     CD_192_P = 18,        // ... 192 rows, six matrix waves of 64 x 64
     CD_256_P = 19,        // ... 256 rows, eight matrix waves of 64 x 64
-    CD_128_P4 = 20,       // ... 128 rows, four matrix waves of 64 x 64
-    CD_128_PR = 21,       // CD_128_P with the K walk rotated per tile (experiment: L2 channel hot spots)
-    CD_192_PR = 22,       // CD_192_P likewise
-    CD_128_F = 23,        // loader + matrix waves handing buffers over through LDS flags, no barrier in the K loop (k_conv_dma_h3f): 128 rows, eight matrix waves
-    CD_192_F = 24,        // ... 192 rows
-    CD_256_F = 25,        // ... 256 rows
-    CD_128_F4 = 26,       // ... 128 rows, four matrix waves of 64 x 64
-    CD_128_P8 = 27,       // k_conv_dma_h3p with EIGHT loader waves: 128 rows
-    CD_192_P8 = 28,       // ... 192 rows
-    CD_128_S = 29,        // loader waves, ONE barrier per super-step, six weight buffers (k_conv_dma_h3s): 128 rows
-    CD_192_S = 30,        // ... 192 rows
-    CD_128_N = 31,        // NARROW tiles, rows x 64 channels, loader waves (k_conv_dma_h3n): 128 rows
-    CD_192_N = 32,        // ... 192 rows
-    CD_256_N = 33,        // ... 256 rows
-    CD_128_D = 34,        // DEEP pipeline (k_conv_dma_h3d: five weight buffers, whole-step fragment sets): 128 x 128
-    CD_128_DN = 35,       // ... 128 x 64
-    CD_192_DN = 36,       // ... 192 x 64
-    CD_256_DN = 37,       // ... 256 x 64
-    CD_192_P1 = 38        // k_conv_dma_h3p, 192 x 128 with twelve matrix waves of 32 x 64 (sixteen waves per workgroup)
+    CD_128_N = 20,        // NARROW tiles, rows x 64 channels, loader waves (k_conv_dma_h3n): 128 rows
+    CD_192_N = 21,        // ... 192 rows
+    CD_256_N = 22         // ... 256 rows
 };
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
@@ -602,9 +586,6 @@ struct ConvDmaPGeom {
     static_assert(G::NPB % NP == 0, "every loader stages the same number of weight pieces");
     static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
 };
-// ROT != 0 (experiment): the workgroups of a launch walk the K dimension from DIFFERENT starting super-steps (tile_m * ROT mod nsuper), so
-// that the CUs of an XCD do not all ask the L2 for the same weight lines at the same moment.  Changes the summation order (per tile): not
-// bit-identical to the other kernels, same error bound.
 #ifdef TD_P_TRACE      // tools/conv_h3p_trace.hip only: s_memtime stamps of workgroups 0..3, every wave (matrix and loader), the first 24 K steps:
 // matrix waves [0] step start, [1] first k-group's MFMAs issued, [2] all MFMAs issued, [3] after the barrier;
 // loader waves [0] step start, [1] pieces issued, [2] after the counted wait, [3] after the barrier
@@ -613,7 +594,7 @@ struct ConvDmaPGeom {
 #else
 #define TD_P_STAMP(st_, slot) ((void)0)
 #endif
-template <int RH, int OUT16, int MI, int NP, int IP, int ROT = 0>
+template <int RH, int OUT16, int MI, int NP, int IP>
 TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p(ConvArgs p) {
     using G = ConvDmaGeom<RH, 1, MI>;
     using GP = ConvDmaPGeom<RH, MI, NP, IP>;
@@ -655,22 +636,17 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p
             const int pb = pw + NP * jb;                                // piece pb = 2 kq + q: 64 consecutive packed slots of k-group kq
             b_off[jb] = (unsigned)((pb / 2) * p.CoutPad + n0 + (pb % 2) * 64 + lane) * 16u;
         }
-        const int rot = ROT ? (tile_m * ROT + tile_n) % nsuper : 0;
-        auto issue_image_piece = [&](int u, int j) {                  // u: position in this workgroup's walk; ur: the super-step it multiplies there
-            int ur = u + rot;
-            if (ROT && ur >= nsuper) ur -= nsuper;
-            const int chunk = ur / 3, ky = ur - chunk * 3;
+        auto issue_image_piece = [&](int u, int j) {                  // u: super-step = (64-channel chunk, kernel row)
+            const int chunk = u / 3, ky = u - chunk * 3;
             const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
             const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
             td_buf_ld16_lds(in_buf, smem + (u & 1) * GP::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
         };
         auto issue_weights = [&](int step, int buf) {
             const bool live = step < p.nsteps;
-            int sr = step;
-            if (ROT && live) { sr = step + 3 * rot; if (sr >= p.nsteps) sr -= p.nsteps; }
 #pragma unroll
             for (int jb = 0; jb < WPP; ++jb)
-                td_buf_ld16_lds(w_buf, wbase + buf * G::B_BYTES + (pw + NP * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB, (unsigned)(live ? sr : 0) * w_step_bytes);
+                td_buf_ld16_lds(w_buf, wbase + buf * G::B_BYTES + (pw + NP * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB, (unsigned)(live ? step : 0) * w_step_bytes);
         };
 #pragma unroll
         for (int j = 0; j < IP; ++j) issue_image_piece(0, j);
@@ -774,14 +750,14 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p
     }
     td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
 }
-template <int RH, int MI, int NP, int IP, int ROT = 0>
+template <int RH, int MI, int NP, int IP>
 static inline bool conv_launch_dma3p_t(const ConvArgs& a, bool out16, hipStream_t s) {
     using G = ConvDmaGeom<RH, 1, MI>;
     using GP = ConvDmaPGeom<RH, MI, NP, IP>;
     if (conv_dma3_slots(G::BM, a.W, a.dil) > GP::CAP) return false;
     const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
-    if (out16) TD_LAUNCH((k_conv_dma_h3p<RH, 1, MI, NP, IP, ROT>), dim3(grid), dim3(64 * (GP::NWC + NP)), GP::LDS_BYTES, s, a);
-    else TD_LAUNCH((k_conv_dma_h3p<RH, 0, MI, NP, IP, ROT>), dim3(grid), dim3(64 * (GP::NWC + NP)), GP::LDS_BYTES, s, a);
+    if (out16) TD_LAUNCH((k_conv_dma_h3p<RH, 1, MI, NP, IP>), dim3(grid), dim3(64 * (GP::NWC + NP)), GP::LDS_BYTES, s, a);
+    else TD_LAUNCH((k_conv_dma_h3p<RH, 0, MI, NP, IP>), dim3(grid), dim3(64 * (GP::NWC + NP)), GP::LDS_BYTES, s, a);
     return true;
 }
 // rh: CD_128_P / CD_192_P / CD_256_P (x 128 channels); the smallest image buffer that holds the halo.  false = not launched.
@@ -790,14 +766,8 @@ static inline bool conv_launch_dma3p(ConvArgs a, int rh, int KS, bool out16, hip
     a.tiles_n = a.CoutPad / 128;
     switch (rh) {
         case CD_128_P: return conv_launch_dma3p_t<2, 1, 4, 5>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 6>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 8>(a, out16, s);
-        case CD_128_P4: return conv_launch_dma3p_t<2, 2, 4, 5>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 6>(a, out16, s) || conv_launch_dma3p_t<2, 2, 4, 8>(a, out16, s);
         case CD_192_P: return conv_launch_dma3p_t<3, 2, 4, 7>(a, out16, s) || conv_launch_dma3p_t<3, 2, 4, 9>(a, out16, s);
         case CD_256_P: return conv_launch_dma3p_t<4, 2, 4, 9>(a, out16, s) || conv_launch_dma3p_t<4, 2, 4, 11>(a, out16, s);
-        case CD_192_P1: return conv_launch_dma3p_t<3, 1, 4, 7>(a, out16, s) || conv_launch_dma3p_t<3, 1, 4, 9>(a, out16, s);   // TWELVE matrix waves of 32 x 64: three per SIMD (six of 64 x 64 leave two SIMDs with twice the MFMAs)
-        case CD_128_P8: return conv_launch_dma3p_t<2, 1, 8, 3>(a, out16, s) || conv_launch_dma3p_t<2, 1, 8, 4>(a, out16, s);   // EIGHT loader waves (two per SIMD): 16 waves per workgroup
-        case CD_192_P8: return conv_launch_dma3p_t<3, 2, 8, 4>(a, out16, s) || conv_launch_dma3p_t<3, 2, 8, 5>(a, out16, s);
-        case CD_128_PR: return conv_launch_dma3p_t<2, 1, 4, 6, 5>(a, out16, s) || conv_launch_dma3p_t<2, 1, 4, 8, 5>(a, out16, s);   // rotated K walk (experiment)
-        case CD_192_PR: return conv_launch_dma3p_t<3, 2, 4, 9, 5>(a, out16, s);
         default: return false;
     }
 }
@@ -836,8 +806,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
     const int gs0 = oy0 * Wh + ox0;
     const int S = BM + 2 * d * ((BM - 2) / p.W + 2);
     const int nsuper = p.nsteps / 3;
-    const int probe = p.nbatch - 100;                                  // operator probes only (TDNET_PROBE_STAGGER -> nbatch = 100 + mode; the model passes 1):
-                                                                       // 1 = every DMA piece out of range, 2 = no DMA, 3 = no MFMA (DESIGN_experiments 8.2)
 
     if (wave >= NWC) {
         const int pw = wave - NWC;
@@ -863,13 +831,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
         auto issue_image_piece = [&](int u, int j) {
             const int chunk = u / 3, ky = u - chunk * 3;
             const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
-            const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u && probe != 1;
-            if (probe == 2) return;
+            const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
             td_buf_ld16_lds(in_buf, smem + (u & 1) * GN::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
         };
         auto issue_weights = [&](int step, int buf) {
-            const bool live = step < p.nsteps && probe != 1;
-            if (probe == 2) return;
+            const bool live = step < p.nsteps;
 #pragma unroll
             for (int jb = 0; jb < WPP; ++jb)
                 td_buf_ld16_lds(w_buf, wbase + buf * GN::B_BYTES + (pw + NP * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB, (unsigned)(live ? step : 0) * w_step_bytes);
@@ -920,7 +886,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
         for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
     auto mma = [&](auto kx_tag, const char* img, const char* wb) {
         constexpr int KX = decltype(kx_tag)::value;
-        if (probe == 3) return;
         f16x8 af[2], bf[2][NJ];
         af[0] = *reinterpret_cast<const f16x8*>(img + a_rd[KX]);
 #pragma unroll
@@ -965,627 +930,6 @@ static inline bool conv_launch_dma3n(ConvArgs a, int rh, int KS, bool out16, hip
         case CD_128_N: return conv_launch_dma3n_t<2, 4, 5>(a, out16, s) || conv_launch_dma3n_t<2, 4, 6>(a, out16, s) || conv_launch_dma3n_t<2, 4, 8>(a, out16, s);
         case CD_192_N: return conv_launch_dma3n_t<3, 4, 7>(a, out16, s) || conv_launch_dma3n_t<3, 4, 9>(a, out16, s);
         case CD_256_N: return conv_launch_dma3n_t<4, 4, 9>(a, out16, s) || conv_launch_dma3n_t<4, 4, 11>(a, out16, s);
-        default: return false;
-    }
-}
-
-// ---- DEEP pipeline: five weight buffers, whole-step fragment sets (round 4) ---------------------------------------------------------------------
-// Decomposition of k_conv_dma_h3n on the 720x960 layer3 shape (TDNET_PROBE_STAGGER, profiles/r04v_*): 20.5 us as it is; 16.2 us with NO
-// DMA at all (fragment reads, MFMAs, barriers); 18.2 us with the DMA but NO MFMAs.  Two floors of ~0.45-0.5 us per K step, both latencies:
-//   * the matrix waves fetch one k-group of fragments ahead; a group is two MFMAs (64 cycles), an LDS read under load 130-250: four round trips
-//     and a barrier per step for 256 cycles of MFMAs;
-//   * the loaders issue the weights two steps ahead; a step of 0.5 us puts two steps at the L2 -> LDS latency under this load.
-// Here both get slack.  Loaders: ring of FIVE weight buffers -- step t issues W(t + 4) -- and the image of super-step v in two shares at steps
-// 3v - 4 and 3v - 3; the counted wait at the end of step t guarantees the data of step t + 2.  Matrix waves: TWO whole-step fragment sets --
-// during the MFMAs of step t the 12 fragment reads of step t + 1 (landed since the end of step t - 1) are in flight, so after a barrier the
-// first MFMA has its operands.  NQ = 64-channel groups per tile (1: narrow tiles of k_conv_dma_h3n, 2: 128 channels).  Matrix waves of 32 x 64.
-// Same products, same order: bit-identical.
-template <int RH, int NQ, int NP, int IP>
-struct ConvDmaDGeom {
-    static constexpr int BM = 64 * RH, BN = 64 * NQ, NWC = 2 * RH * NQ, NBW = 5;
-    static constexpr int B_BYTES = 8 * BN * 16;
-    static constexpr int CAP = IP * NP * 8, IMG_BYTES = CAP * 128, LDS_BYTES = 2 * IMG_BYTES + NBW * B_BYTES;
-    static constexpr int WPP = 8 * NQ / NP, SA = (IP + 1) / 2, SB = IP - SA;
-    static_assert((8 * NQ) % NP == 0, "every loader stages the same number of weight pieces");
-    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
-    static_assert(64 * (NWC + NP) <= 1024, "workgroup size");
-};
-template <int RH, int NQ, int OUT16, int NP, int IP>
-TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * NQ + NP), 1) k_conv_dma_h3d(ConvArgs p) {
-    using GD = ConvDmaDGeom<RH, NQ, NP, IP>;
-    constexpr int NJ = 2, BM = GD::BM, NWC = GD::NWC, WPP = GD::WPP, NBW = GD::NBW, SA = GD::SA, SB = GD::SB;
-    TD_DYN_LDS(smem);
-    char* const wbase = smem + 2 * GD::IMG_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
-    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * GD::BN;
-    const int d = p.dil, Wh = p.W + 2 * d;
-    const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
-    const int gs0 = oy0 * Wh + ox0;
-    const int S = BM + 2 * d * ((BM - 2) / p.W + 2);
-    const int nsuper = p.nsteps / 3;
-
-    if (wave >= NWC) {
-        // ======================================================== loader wave ========================================================
-        const int pw = wave - NWC;
-        unsigned a_base[IP], a_ok[IP];
-#pragma unroll
-        for (int j = 0; j < IP; ++j) {
-            const int sl = 8 * (pw + NP * j) + (lane >> 3);
-            const int gs = gs0 + sl;
-            const int r = gs / Wh, ix = gs - r * Wh - d;
-            const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
-            const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
-            a_ok[j] = 0u;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
-        }
-        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
-        const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
-        const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
-        unsigned b_off[WPP];
-#pragma unroll
-        for (int jb = 0; jb < WPP; ++jb) {
-            const int pb = pw + NP * jb;                                // piece pb = NQ kq + q: 64 consecutive packed slots of k-group kq, column group q
-            b_off[jb] = (unsigned)((pb / NQ) * p.CoutPad + n0 + (pb % NQ) * 64 + lane) * 16u;
-        }
-        auto issue_image = [&](int v, int j0, int j1) {                // pieces j0 .. j1 - 1 of the image of super-step v (zero fill past the end)
-            const int chunk = v / 3, ky = v - chunk * 3;
-            const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
-#pragma unroll
-            for (int j = 0; j < IP; ++j)
-                if (j >= j0 && j < j1) {
-                    const bool ok = v < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
-                    td_buf_ld16_lds(in_buf, smem + (v & 1) * GD::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
-                }
-        };
-        int wslot = 4;                                                 // slot of the weights issued next: step t + 4 goes to (t + 4) mod 5
-        auto issue_weights = [&](int step, int slot) {
-            const bool live = step < p.nsteps;
-#pragma unroll
-            for (int jb = 0; jb < WPP; ++jb)
-                td_buf_ld16_lds(w_buf, wbase + slot * GD::B_BYTES + (pw + NP * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB, (unsigned)(live ? step : 0) * w_step_bytes);
-        };
-        // prologue: what the steps 0 and 1 need, then what may still fly
-        issue_image(0, 0, IP);
-        issue_weights(0, 0);
-        issue_weights(1, 1);
-        issue_weights(2, 2);
-        issue_weights(3, 3);
-        issue_image(1, 0, SA);
-        TD_WAIT_VM_PIECES(2 * WPP + SA);
-        TD_BARRIER_RAW();                                              // B0: the data of steps 0 and 1 is there (the matrix waves fetch step 0's fragments now)
-        for (int u = 0; u < nsuper; ++u) {
-            // kx = 0 (t = 3 u): the second share of image u + 1 FIRST (step t + 1's wait must cover it), then W(t + 4)
-            issue_image(u + 1, SA, IP);
-            issue_weights(3 * u + 4, wslot);
-            if (++wslot == NBW) wslot = 0;
-            TD_WAIT_VM_PIECES(2 * WPP + SA + SB);                      // in flight: everything issued in steps t - 1 and t
-            TD_BARRIER_RAW();
-            // kx = 1: W(t + 4); the next super-step's image must be complete now
-            issue_weights(3 * u + 5, wslot);
-            if (++wslot == NBW) wslot = 0;
-            TD_WAIT_VM_PIECES(2 * WPP);                                // in flight: W(t + 3), W(t + 4) -- the share issued before W(t + 3) has landed
-            TD_BARRIER_RAW();
-            // kx = 2: W(t + 4) and the first share of image u + 2 (its buffer, image u's, was read for the last time during step t - 1)
-            issue_weights(3 * u + 6, wslot);
-            if (++wslot == NBW) wslot = 0;
-            issue_image(u + 2, 0, SA);
-            TD_WAIT_VM_PIECES(2 * WPP + SA);
-            TD_BARRIER_RAW();
-        }
-        TD_WAIT_VM_PIECES(0);
-        return;
-    }
-
-    // ========================================================= matrix wave ==========================================================
-    const int half = lane >> 5, l31 = lane & 31;
-    const int wm = wave / NQ, wn = wave - wm * NQ;
-    unsigned a_rd[3];
-    {
-        const int m = m0 + wm * 32 + l31;
-        const int oy = m / p.W, ox = m - oy * p.W;
-        const int sm = (oy - oy0) * Wh + ox - ox0;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int sl = sm + kx * d;
-            a_rd[kx] = (unsigned)(sl * 128 + (((half) ^ ((sl >> 1) & 7)) << 4));
-        }
-    }
-    constexpr int BKQ = GD::BN * 16;
-    const unsigned b_rd = (unsigned)(half * BKQ + (wn * 64 + l31) * 16);
-    f32x16 acc[1][NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-    f16x8 FA[2][4], FB[2][4][NJ];
-    auto load = [&](auto kx_tag, auto set_tag, const char* img, const char* wb) {
-        constexpr int KX = decltype(kx_tag)::value, SET = decltype(set_tag)::value;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            FA[SET][g] = *reinterpret_cast<const f16x8*>(img + (a_rd[KX] ^ (unsigned)(g << 5)));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) FB[SET][g][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + g * 2 * BKQ + j * 512);
-        }
-    };
-    auto fma = [&](auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[0][j] = td_mfma32_f16(FA[SET][g], FB[SET][g][j], acc[0][j]);
-    };
-    int step = 0, ws = 0;                                              // the step whose fragments are fetched NEXT, and its weight slot
-    // fetch the fragments of `step` (tap KX of the image of super-step step / 3)
-    auto fetch = [&](auto kx_tag, auto set_tag) {
-        const int v = step / 3;
-        load(kx_tag, set_tag, smem + (v & 1) * GD::IMG_BYTES, wbase + ws * GD::B_BYTES);
-        ++step;
-        if (++ws == NBW) ws = 0;
-    };
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
-    TD_BARRIER_RAW();                                                  // B0
-    fetch(K0{}, K0{});
-    // one K step: the next step's fragments go into the other set while this step's are multiplied (past the last step: a harmless re-read)
-    auto kstep = [&](auto kxn_tag, auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-        if (step < p.nsteps) fetch(kxn_tag, std::integral_constant<int, SET ^ 1>{});
-        fma(set_tag);
-        TD_BARRIER_RAW();
-    };
-    int u = 0;
-    for (; u + 1 < nsuper; u += 2) {                                   // two super-steps: the sets alternate 0 1 0 1 0 1; the tag is the NEXT step's tap
-        kstep(K1{}, K0{}); kstep(K2{}, K1{}); kstep(K0{}, K0{});
-        kstep(K1{}, K1{}); kstep(K2{}, K0{}); kstep(K0{}, K1{});
-    }
-    if (u < nsuper) { kstep(K1{}, K0{}); kstep(K2{}, K1{}); kstep(K0{}, K0{}); }
-    td_store_acc_h<1, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32, n0 + wn * 64, lane);
-}
-template <int RH, int NQ, int NP, int IP>
-static inline bool conv_launch_dma3d_t(const ConvArgs& a, bool out16, hipStream_t s) {
-    using GD = ConvDmaDGeom<RH, NQ, NP, IP>;
-    if (conv_dma3_slots(GD::BM, a.W, a.dil) > GD::CAP) return false;
-    const int grid = ((a.M + GD::BM - 1) / GD::BM) * a.tiles_n;
-    if (out16) TD_LAUNCH((k_conv_dma_h3d<RH, NQ, 1, NP, IP>), dim3(grid), dim3(64 * (GD::NWC + NP)), GD::LDS_BYTES, s, a);
-    else TD_LAUNCH((k_conv_dma_h3d<RH, NQ, 0, NP, IP>), dim3(grid), dim3(64 * (GD::NWC + NP)), GD::LDS_BYTES, s, a);
-    return true;
-}
-// rh: CD_128_D (128 x 128), CD_128_DN / CD_192_DN / CD_256_DN (rows x 64 channels); false = not launched
-static inline bool conv_launch_dma3d(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
-    if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3 || a.nsteps < 6) return false;
-    a.tiles_n = a.CoutPad / (rh == CD_128_D ? 128 : 64);
-    switch (rh) {
-        case CD_128_D: return conv_launch_dma3d_t<2, 2, 4, 5>(a, out16, s) || conv_launch_dma3d_t<2, 2, 4, 6>(a, out16, s) || conv_launch_dma3d_t<2, 2, 4, 8>(a, out16, s);
-        case CD_128_DN: return conv_launch_dma3d_t<2, 1, 4, 5>(a, out16, s) || conv_launch_dma3d_t<2, 1, 4, 6>(a, out16, s) || conv_launch_dma3d_t<2, 1, 4, 8>(a, out16, s);
-        case CD_192_DN: return conv_launch_dma3d_t<3, 1, 4, 7>(a, out16, s) || conv_launch_dma3d_t<3, 1, 4, 9>(a, out16, s);
-        case CD_256_DN: return conv_launch_dma3d_t<4, 1, 4, 9>(a, out16, s) || conv_launch_dma3d_t<4, 1, 4, 11>(a, out16, s);
-        default: return false;
-    }
-}
-
-// ---- loader waves, ONE barrier per super-step (round 4) ----------------------------------------------------------------------------------------
-// k_conv_dma_h3p meets a barrier every K step; its trace (profiles/r04e_*) shows the loaders as the long pole of a step -- ~615 cycles to issue
-// their 7-8 pieces, ~130 until the previous step has landed, ~200 at the barrier -- while the matrix waves, done after ~660, wait.  The CU takes
-// an LDS-DMA piece every ~25 cycles whoever issues it, so the issue time is given; what can go is two of every three waits and barriers, and
-// two of every three cold starts of the fragment pipeline.  Here a super-step (64 channels x one kernel row = three K steps) is ONE phase: the
-// loaders issue the whole next super-step (its image and its three weight steps, 17 pieces per loader) into the other half of a double
-// buffer -- six weight buffers, two images -- wait once, and meet the matrix waves once; the matrix waves run the three taps as one stream
-// of twelve k-groups, fetching each group's fragments under the previous group's MFMAs across the tap boundaries.
-// Same products, same order: bit-identical to k_conv_dma_h3 / _h3p.
-template <int RH, int MI, int NP, int IP>
-struct ConvDmaSGeom {
-    using G = ConvDmaGeom<RH, 1, MI>;
-    static constexpr int NWC = G::NW;
-    static constexpr int CAP = IP * NP * 8;
-    static constexpr int IMG_BYTES = CAP * 128, LDS_BYTES = 2 * IMG_BYTES + 6 * G::B_BYTES;
-    static constexpr int WPP = G::NPB / NP;
-    static_assert(G::NPB % NP == 0, "every loader stages the same number of weight pieces");
-    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
-};
-template <int RH, int OUT16, int MI, int NP, int IP>
-TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3s(ConvArgs p) {
-    using G = ConvDmaGeom<RH, 1, MI>;
-    using GS = ConvDmaSGeom<RH, MI, NP, IP>;
-    constexpr int NJ = 2, BM = G::BM, NWC = GS::NWC, WPP = GS::WPP;
-    TD_DYN_LDS(smem);
-    char* const wbase = smem + 2 * GS::IMG_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
-    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * G::BN;
-    const int d = p.dil, Wh = p.W + 2 * d;
-    const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
-    const int gs0 = oy0 * Wh + ox0;
-    const int S = BM + 2 * d * ((BM - 2) / p.W + 2);
-    const int nsuper = p.nsteps / 3;
-
-    if (wave >= NWC) {
-        // ======================================================== loader wave ========================================================
-        const int pw = wave - NWC;
-        unsigned a_base[IP], a_ok[IP];
-#pragma unroll
-        for (int j = 0; j < IP; ++j) {
-            const int sl = 8 * (pw + NP * j) + (lane >> 3);
-            const int gs = gs0 + sl;
-            const int r = gs / Wh, ix = gs - r * Wh - d;
-            const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
-            const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
-            a_ok[j] = 0u;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
-        }
-        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
-        const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
-        const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
-        unsigned b_off[WPP];
-#pragma unroll
-        for (int jb = 0; jb < WPP; ++jb) {
-            const int pb = pw + NP * jb;
-            b_off[jb] = (unsigned)((pb / 2) * p.CoutPad + n0 + (pb % 2) * 64 + lane) * 16u;
-        }
-        auto issue_super = [&](int u) {                               // everything super-step u needs, into half u & 1; weights first (they are read first)
-            const bool live = u < nsuper;
-            const int hb = u & 1;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int jb = 0; jb < WPP; ++jb)
-                    td_buf_ld16_lds(w_buf, wbase + (hb * 3 + kx) * G::B_BYTES + (pw + NP * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB,
-                                    (unsigned)(live ? 3 * u + kx : 0) * w_step_bytes);
-            const int chunk = u / 3, ky = u - chunk * 3;
-            const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
-#pragma unroll
-            for (int j = 0; j < IP; ++j) {
-                const bool ok = live && ((a_ok[j] >> ky) & 1u) != 0u;
-                td_buf_ld16_lds(in_buf, smem + hb * GS::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
-            }
-        };
-        issue_super(0);
-        TD_WAIT_VM_PIECES(0);
-        TD_BARRIER_RAW();
-        for (int u = 0; u < nsuper; ++u) {
-            if (u + 1 < nsuper) issue_super(u + 1);                  // wave-uniform; the other half was read during super-step u - 1
-            TD_WAIT_VM_PIECES(0);
-            TD_BARRIER_RAW();
-        }
-        return;
-    }
-
-    // ========================================================= matrix wave ==========================================================
-    const int half = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
-    unsigned a_rd[3][MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * 32 * MI + 32 * i + l31;
-        const int oy = m / p.W, ox = m - oy * p.W;
-        const int sm = (oy - oy0) * Wh + ox - ox0;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int sl = sm + kx * d;
-            a_rd[kx][i] = (unsigned)(sl * 128 + (((half) ^ ((sl >> 1) & 7)) << 4));
-        }
-    }
-    constexpr int BKQ = G::BN * 16;
-    const unsigned b_rd = (unsigned)(half * BKQ + (wn * 64 + l31) * 16);
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    TD_BARRIER_RAW();                                                  // the loaders' prologue
-    for (int u = 0; u < nsuper; ++u) {
-        const char* img = smem + (u & 1) * GS::IMG_BYTES;
-        const char* wb = wbase + (u & 1) * 3 * G::B_BYTES;
-        f16x8 af[2][MI], bf[2][NJ];
-        auto fetch = [&](int q, int set) {                             // k-group q = 4 kx + g of the super-step (compile time after unrolling)
-            const int kx = q >> 2, g = q & 3;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[set][i] = *reinterpret_cast<const f16x8*>(img + (a_rd[kx][i] ^ (unsigned)(g << 5)));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[set][j] = *reinterpret_cast<const f16x8*>(wb + kx * G::B_BYTES + b_rd + g * 2 * BKQ + j * 512);
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            if (q < 11) fetch(q + 1, (q + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(af[q & 1][i], bf[q & 1][j], acc[i][j]);
-        }
-        TD_BARRIER_RAW();
-    }
-    td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
-}
-template <int RH, int MI, int NP, int IP>
-static inline bool conv_launch_dma3s_t(const ConvArgs& a, bool out16, hipStream_t s) {
-    using G = ConvDmaGeom<RH, 1, MI>;
-    using GS = ConvDmaSGeom<RH, MI, NP, IP>;
-    if (conv_dma3_slots(G::BM, a.W, a.dil) > GS::CAP) return false;
-    const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
-    if (out16) TD_LAUNCH((k_conv_dma_h3s<RH, 1, MI, NP, IP>), dim3(grid), dim3(64 * (GS::NWC + NP)), GS::LDS_BYTES, s, a);
-    else TD_LAUNCH((k_conv_dma_h3s<RH, 0, MI, NP, IP>), dim3(grid), dim3(64 * (GS::NWC + NP)), GS::LDS_BYTES, s, a);
-    return true;
-}
-// rh: CD_128_S / CD_192_S; false = not launched (not a 3x3 "same" conv, or the halo does not fit beside six weight buffers)
-static inline bool conv_launch_dma3s(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
-    if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
-    a.tiles_n = a.CoutPad / 128;
-    switch (rh) {
-        case CD_128_S: return conv_launch_dma3s_t<2, 1, 4, 5>(a, out16, s) || conv_launch_dma3s_t<2, 1, 4, 6>(a, out16, s) || conv_launch_dma3s_t<2, 1, 4, 7>(a, out16, s);
-        case CD_192_S: return conv_launch_dma3s_t<3, 2, 4, 7>(a, out16, s);
-        default: return false;
-    }
-}
-
-// ---- loader waves and matrix waves WITHOUT a workgroup barrier in the K loop: buffers change hands through LDS flags (round 4) ------------------
-// The in-kernel trace of k_conv_dma_h3p (tools/conv_h3p_trace.hip, profiles/r04e_*) shows what a barrier per K step costs once the roles are
-// separated: per 128 x 128 step the loaders need ~620 cycles to issue (the CU's LDS-DMA path takes a 1 KB piece every ~24 cycles with four
-// waves issuing and the matrix waves reading fragments) + ~130 to see the previous step land, the matrix waves ~220 to get their first
-// fragments after the barrier + ~400 to issue their MFMAs -- and then everybody waits for the slowest: a period of 1100 cycles for 512
-// of MFMAs and ~550 of DMA.  Here nobody waits for anybody who is not late:
-//   * weights live in a ring of NSW step buffers, images in a ring of NSI super-step buffers;
-//   * a loader wave walks the units I(u) W(3u) W(3u+1) W(3u+2) I(u+1) ... : wait until the unit's buffer was READ (free counter of its
-//     slot), issue its pieces, then a counted vmcnt tells it that the PREVIOUS unit has landed and it adds 1 to that unit's ready counter;
-//   * a matrix wave waits until a unit's ready counter says all NP loaders' pieces have landed, multiplies, and adds 1 to the free counter.
-// Counters only grow (use g of a slot is complete at NP (g + 1) resp. NWC (g + 1)): no reset, no ABA.  Same images, same weights, same
-// products in the same order as k_conv_dma_h3 / _h3p: bit-identical results.
-template <int RH, int MI, int NP, int IP, int NSI, int NSW>
-struct ConvDmaFGeom {
-    using G = ConvDmaGeom<RH, 1, MI>;
-    static constexpr int NWC = G::NW;
-    static constexpr int CAP = IP * NP * 8;
-    static constexpr int IMG_BYTES = CAP * 128, DATA_BYTES = NSI * IMG_BYTES + NSW * G::B_BYTES, LDS_BYTES = DATA_BYTES + 256;
-    static constexpr int WPP = G::NPB / NP;
-    static_assert(G::NPB % NP == 0, "every loader stages the same number of weight pieces");
-    static_assert(2 * (NSI + NSW) * 4 <= 256, "flag block");
-    static_assert(NSI >= 2 && NSW >= 2, "a unit's ready signal is given while the NEXT unit is in flight");
-    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
-};
-template <int RH, int OUT16, int MI, int NP, int IP, int NSI, int NSW>
-TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3f(ConvArgs p) {
-    using G = ConvDmaGeom<RH, 1, MI>;
-    using GF = ConvDmaFGeom<RH, MI, NP, IP, NSI, NSW>;
-    constexpr int NJ = 2, BM = G::BM, NWC = GF::NWC, WPP = GF::WPP;
-    TD_DYN_LDS(smem);
-    char* const wbase = smem + NSI * GF::IMG_BYTES;
-    td_flag_t* const iready = td_flag_ptr(smem + GF::DATA_BYTES);
-    td_flag_t* const ifree = iready + NSI;
-    td_flag_t* const wready = ifree + NSI;
-    td_flag_t* const wfree = wready + NSW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
-    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * G::BN;
-    const int d = p.dil, Wh = p.W + 2 * d;
-    const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
-    const int gs0 = oy0 * Wh + ox0;
-    const int S = BM + 2 * d * ((BM - 2) / p.W + 2);
-    const int nsuper = p.nsteps / 3;
-    if (tid < 2 * (NSI + NSW)) iready[tid] = 0u;
-    TD_BARRIER_RAW();                                                  // the only workgroup barrier of the kernel
-
-    if (wave >= NWC) {
-        // ======================================================== loader wave ========================================================
-        const int pw = wave - NWC;
-        unsigned a_base[IP], a_ok[IP];
-#pragma unroll
-        for (int j = 0; j < IP; ++j) {
-            const int sl = 8 * (pw + NP * j) + (lane >> 3);
-            const int gs = gs0 + sl;
-            const int r = gs / Wh, ix = gs - r * Wh - d;
-            const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
-            const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
-            a_ok[j] = 0u;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
-        }
-        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
-        const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
-        const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
-        unsigned b_off[WPP];
-#pragma unroll
-        for (int jb = 0; jb < WPP; ++jb) {
-            const int pb = pw + NP * jb;
-            b_off[jb] = (unsigned)((pb / 2) * p.CoutPad + n0 + (pb % 2) * 64 + lane) * 16u;
-        }
-        // Units in issue order: I(u) W(3u) W(3u+1) W(3u+2) I(u+1) ...  A unit's "landed" signal is given TWO units later (after the next two
-        // units were issued, a counted vmcnt leaves exactly their pieces in flight): one unit of lag (4-5 pieces, ~400 cycles of issue) is
-        // shorter than the DMA latency under load and made every signal wait.  The free counter of a unit's slot is looked at one unit
-        // early (td_flag_peek) so that its LDS round trip is not on the issue path.
-        int islot = 0, igen = 0, wslot = 0, wgen = 0;                  // slot / use count of the NEXT image and weight unit
-        td_flag_t *pend1 = nullptr, *pend2 = nullptr;                  // ready flags of the last and the last-but-one unit issued
-        unsigned peek = 0u;                                            // free counter of the next unit's slot, read a unit ago
-        auto acquire = [&](td_flag_t* freeflag, int gen) {            // the slot's previous contents have been read by all matrix waves
-            if (gen > 0 && !td_flag_reached(peek, (unsigned)(NWC * gen))) {
-                // The ring is full: this loader is ahead and about to idle.  Whatever it has in flight is published first -- the units'
-                // signals must not wait for a FUTURE issue that itself waits for the matrix waves (first version: the matrix waves
-                // saw a unit ~550 cycles after it had landed, profiles/r04g_*).
-                TD_WAIT_VM_PIECES(0);
-                TD_LANES_ARRIVED();
-                if (pend2) td_flag_add(pend2);
-                if (pend1) td_flag_add(pend1);
-                pend1 = pend2 = nullptr;
-                td_flag_wait_ge(freeflag, (unsigned)(NWC * gen));
-            }
-        };
-        auto landed = [&](td_flag_t* mine) {                          // after the counted wait: the last-but-one unit is complete
-            if (pend2) { TD_LANES_ARRIVED(); td_flag_add(pend2); }
-            pend2 = pend1; pend1 = mine;
-        };
-        for (int u = 0; u < nsuper; ++u) {
-            {   // I(u)
-                acquire(ifree + islot, igen);
-                peek = td_flag_peek(wfree + wslot);
-                const int chunk = u / 3, ky = u - chunk * 3;
-                const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
-                char* img = smem + islot * GF::IMG_BYTES;
-#pragma unroll
-                for (int j = 0; j < IP; ++j) {
-                    const bool ok = ((a_ok[j] >> ky) & 1u) != 0u;
-                    td_buf_ld16_lds(in_buf, img + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
-                }
-                TD_WAIT_VM_PIECES(IP + WPP);                           // in flight: I(u) and W(3 u - 1)
-                landed(iready + islot);
-                if (++islot == NSI) { islot = 0; ++igen; }
-            }
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {                           // W(3 u + kx)
-                TD_P_STAMP(3 * u + kx, 0);
-                acquire(wfree + wslot, wgen);
-                TD_P_STAMP(3 * u + kx, 1);
-                td_flag_t* const mine = wready + wslot;
-                const unsigned soff = (unsigned)(3 * u + kx) * w_step_bytes;
-                char* wb = wbase + wslot * G::B_BYTES;
-                if (++wslot == NSW) { wslot = 0; ++wgen; }
-                peek = kx == 2 ? td_flag_peek(ifree + islot) : td_flag_peek(wfree + wslot);
-#pragma unroll
-                for (int jb = 0; jb < WPP; ++jb) td_buf_ld16_lds(w_buf, wb + (pw + NP * jb) * 1024, b_off[jb], soff);
-                TD_P_STAMP(3 * u + kx, 2);
-                if (kx == 0) TD_WAIT_VM_PIECES(WPP + IP); else TD_WAIT_VM_PIECES(2 * WPP);
-                landed(mine);
-                TD_P_STAMP(3 * u + kx, 3);
-            }
-        }
-        TD_WAIT_VM_PIECES(WPP);
-        landed(nullptr);
-        TD_WAIT_VM_PIECES(0);
-        landed(nullptr);
-        return;
-    }
-
-    // ========================================================= matrix wave ==========================================================
-    const int half = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
-    unsigned a_rd[3][MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * 32 * MI + 32 * i + l31;
-        const int oy = m / p.W, ox = m - oy * p.W;
-        const int sm = (oy - oy0) * Wh + ox - ox0;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int sl = sm + kx * d;
-            a_rd[kx][i] = (unsigned)(sl * 128 + (((half) ^ ((sl >> 1) & 7)) << 4));
-        }
-    }
-    constexpr int BKQ = G::BN * 16;
-    const unsigned b_rd = (unsigned)(half * BKQ + (wn * 64 + l31) * 16);
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // A matrix wave holds the fragments of TWO whole K steps: while the MFMAs of step s run from one set, all 4 (MI + NJ) fragment reads
-    // of step s + 1 are in flight into the other.  An LDS read on this CU takes 200-300 cycles (the queue carries the DMA writes and
-    // twelve waves' reads: tools/conv_h3p_trace.hip), a k-group of MFMAs 64-128: fetching one k-group ahead, the wave waited on the LDS
-    // before every group and again behind every flag (first version: 1650 cycles per step).  With a step of slack nothing on the wave's path
-    // waits for the LDS, and a slot is released as soon as its fragments sit in registers -- a step BEFORE its products are done.
-    f16x8 FA[2][4][MI], FB[2][4][NJ];
-    auto load = [&](auto kx_tag, auto set_tag, const char* img, const char* wb) {
-        constexpr int KX = decltype(kx_tag)::value, SET = decltype(set_tag)::value;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) FA[SET][g][i] = *reinterpret_cast<const f16x8*>(img + (a_rd[KX][i] ^ (unsigned)(g << 5)));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) FB[SET][g][j] = *reinterpret_cast<const f16x8*>(wb + b_rd + g * 2 * BKQ + j * 512);
-        }
-    };
-    auto fma = [&](auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = td_mfma32_f16(FA[SET][g][i], FB[SET][g][j], acc[i][j]);
-    };
-    int islot = 0, igen = 0, wslot = 0, wgen = 0;                      // slot / use of the unit whose fragments are fetched NEXT
-    int step = 0;
-    const char* img = smem;
-    td_flag_t* ifr = ifree;
-    unsigned wpeek = 0u, ipeek = 0u;
-    // fetch the fragments of step `step` (tap KX) into set SET: make sure its image (KX == 0) and weights have landed, read, look ahead
-    auto fetch = [&](auto kx_tag, auto set_tag) {
-        constexpr int KX = decltype(kx_tag)::value;
-        if (KX == 0) {
-            if (!td_flag_reached(ipeek, (unsigned)(NP * (igen + 1)))) td_flag_wait_ge(iready + islot, (unsigned)(NP * (igen + 1)));
-            img = smem + islot * GF::IMG_BYTES;
-            ifr = ifree + islot;
-            if (++islot == NSI) { islot = 0; ++igen; }
-        }
-        if (!td_flag_reached(wpeek, (unsigned)(NP * (wgen + 1)))) td_flag_wait_ge(wready + wslot, (unsigned)(NP * (wgen + 1)));
-        load(kx_tag, set_tag, img, wbase + wslot * G::B_BYTES);
-    };
-    // after TD_WAIT_LDS_READS(): the fragments of the fetched step are in registers -> its weight slot (and, with the image's last tap, its
-    // image slot) is free; then the ready counters of the step after it are looked at, a whole step before they are needed
-    auto release = [&](auto kx_tag) {
-        constexpr int KX = decltype(kx_tag)::value;
-        TD_LANES_ARRIVED();
-        td_flag_add(wfree + wslot);
-        if (KX == 2) td_flag_add(ifr);
-        if (++wslot == NSW) { wslot = 0; ++wgen; }
-        wpeek = td_flag_peek(wready + wslot);
-        if (KX == 2) ipeek = td_flag_peek(iready + islot);
-    };
-    // one K step: fetch step + 1 into the other set, multiply this step's set, release step + 1's buffers
-    auto kstep = [&](auto kx_tag, auto set_tag) {
-        constexpr int KX = decltype(kx_tag)::value, SET = decltype(set_tag)::value, KN = (KX + 1) % 3;
-        TD_P_STAMP(step, 0);
-        const bool more = step + 1 < p.nsteps;                         // wave-uniform
-        if (more) fetch(std::integral_constant<int, KN>{}, std::integral_constant<int, SET ^ 1>{});
-        TD_P_STAMP(step, 1);
-        fma(set_tag);
-        TD_P_STAMP(step, 2);
-        TD_WAIT_LDS_READS();
-        if (more) release(std::integral_constant<int, KN>{});
-        TD_P_STAMP(step, 3);
-        ++step;
-    };
-    wpeek = td_flag_peek(wready);
-    ipeek = td_flag_peek(iready);
-    fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    TD_WAIT_LDS_READS();
-    release(std::integral_constant<int, 0>{});
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
-    int u = 0;
-    for (; u + 1 < nsuper; u += 2) {                                   // two super-steps: the fragment sets alternate 0 1 0 1 0 1
-        kstep(K0{}, K0{}); kstep(K1{}, K1{}); kstep(K2{}, K0{});
-        kstep(K0{}, K1{}); kstep(K1{}, K0{}); kstep(K2{}, K1{});
-    }
-    if (u < nsuper) { kstep(K0{}, K0{}); kstep(K1{}, K1{}); kstep(K2{}, K0{}); }
-    td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
-}
-template <int RH, int MI, int NP, int IP, int NSI, int NSW>
-static inline bool conv_launch_dma3f_t(const ConvArgs& a, bool out16, hipStream_t s) {
-    using G = ConvDmaGeom<RH, 1, MI>;
-    using GF = ConvDmaFGeom<RH, MI, NP, IP, NSI, NSW>;
-    if (conv_dma3_slots(G::BM, a.W, a.dil) > GF::CAP) return false;
-    const int grid = ((a.M + G::BM - 1) / G::BM) * a.tiles_n;
-    if (out16) TD_LAUNCH((k_conv_dma_h3f<RH, 1, MI, NP, IP, NSI, NSW>), dim3(grid), dim3(64 * (GF::NWC + NP)), GF::LDS_BYTES, s, a);
-    else TD_LAUNCH((k_conv_dma_h3f<RH, 0, MI, NP, IP, NSI, NSW>), dim3(grid), dim3(64 * (GF::NWC + NP)), GF::LDS_BYTES, s, a);
-    return true;
-}
-// rh: CD_128_F / CD_192_F / CD_256_F; the smallest image buffers that hold the halo, as many ring slots as the LDS takes.  false = not launched.
-static inline bool conv_launch_dma3f(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
-    if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
-    a.tiles_n = a.CoutPad / 128;
-    switch (rh) {
-        case CD_128_F: return conv_launch_dma3f_t<2, 1, 4, 5, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 1, 4, 6, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 1, 4, 8, 2, 5>(a, out16, s);
-        case CD_128_F4: return conv_launch_dma3f_t<2, 2, 4, 5, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 2, 4, 6, 3, 5>(a, out16, s) || conv_launch_dma3f_t<2, 2, 4, 8, 2, 5>(a, out16, s);
-        case CD_192_F: return conv_launch_dma3f_t<3, 2, 4, 7, 2, 5>(a, out16, s) || conv_launch_dma3f_t<3, 2, 4, 9, 2, 5>(a, out16, s);
-        case CD_256_F: return conv_launch_dma3f_t<4, 2, 4, 9, 2, 4>(a, out16, s) || conv_launch_dma3f_t<4, 2, 4, 11, 2, 4>(a, out16, s);
         default: return false;
     }
 }

@@ -79,31 +79,6 @@ TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, u
 #define TD_BARRIER_RAW() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
                               __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); } while (0)
 
-// LDS flags: 4-byte counters in the workgroup's own LDS through which waves hand buffers to each other WITHOUT a workgroup barrier
-// (k_conv_dma_h3f: loader waves publish "landed", matrix waves publish "read").  The pointer type pins the LDS address space: a flat
-// atomic would also count on vmcnt and break the loaders' counted waits.  td_flag_add: one lane adds 1 (relaxed: the caller orders its own
-// earlier accesses -- s_waitcnt vmcnt(N) for LDS-DMA pieces, TD_WAIT_LDS_READS() for fragment reads -- the LDS itself executes in order);
-// td_flag_wait_ge: every lane polls the same word (a broadcast read) until counter - target >= 0, with a short sleep between polls.
-typedef __attribute__((address_space(3))) unsigned td_flag_t;
-TD_DEV td_flag_t* td_flag_ptr(char* lds) { return (td_flag_t*)lds; }
-TD_DEV void td_flag_add(td_flag_t* f) {
-    if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-TD_DEV void td_flag_wait_ge(td_flag_t* f, unsigned target) {
-    for (;;) {
-        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if ((int)(v - target) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-}
-#define TD_WAIT_LDS_READS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   // this wave's LDS reads have returned
-#define TD_LANES_ARRIVED() ((void)0)   // a wave's lanes pass an s_waitcnt together; the emulator (lanes = fibers) needs a wave barrier here
-// a look at a flag that is USED later: the read is issued here and its LDS round trip (~100 cycles) passes under the work in between;
-// counters only grow, so a value that already reaches the target stays valid, and one that does not is polled again (td_flag_wait_ge)
-TD_DEV unsigned td_flag_peek(td_flag_t* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-TD_DEV bool td_flag_reached(unsigned peeked, unsigned target) { return (int)(__builtin_amdgcn_readfirstlane(peeked) - target) >= 0; }
-
 // wave priority 0..3 for the SIMD's instruction arbiter (priority first, then age)
 #define TD_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 

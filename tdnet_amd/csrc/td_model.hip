@@ -130,7 +130,6 @@ struct ConvLayer {
     bool rowimg_off = false;                                           // tdnet_opts.fusion bit 2048: keep the tap-by-tap LDS-DMA kernel
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int stagger = 0;                                                   // tdnet_opts.stagger
-    int probe = 0;                                                     // tdnet_op_conv2d_f16io under TDNET_PROBE_STAGGER only (never set by a handle)
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
     bool gdma = false;                                                 // the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h; tdnet_opts.overlap bit 8)
     int vw = 0;                                                        // != 0: the low-register F(4x4) transform kernels with vw channels per lane (td_wino.h k_wino4_*_c)
@@ -833,8 +832,6 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
                     const bool same3 = c.KS == 3 && c.stride == 1 && c.pad == c.dil;
                     if ((n->opts.fusion & 32768) && same3 && c.M_out <= 16384 && c.Cout <= 256)
                         c.rh = c.Cout <= 128 ? CD_128_N : CD_192_N;       // (256 channels on 128 x 64 tiles as well: 2.1 % instead of 2.6 % in the frame)
-                    else if (n->opts.fusion & 16384)                         // loader + matrix waves, buffers handed over through LDS flags (k_conv_dma_h3f)
-                        c.rh = c.rh == CD_128 ? CD_128_F : c.rh == CD_192 ? CD_192_F : c.rh == CD_256 ? CD_256_F : c.rh;
                     else if (n->opts.fusion & 8192)                     // the 128- and 192-row tiles with four dedicated loader waves (k_conv_dma_h3p):
                         c.rh = c.rh == CD_128 ? CD_128_P : c.rh == CD_192 ? CD_192_P : c.rh;
                         // isolated 22.5 -> 21.0 / 57.8 -> 56.7 us; 256 rows: no gain (profiles/r04d_*).  (192 rows with TWELVE matrix waves of 32 x 64 -- three
@@ -920,13 +917,23 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
 // ---------------------------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------------------------
-// TIMING PROBE ONLY (tools/ab_opts.py under TDNET_PROBE_SKIP=<mask>; results are garbage): what would the frame cost WITHOUT a piece of it?
+// TIMING PROBE, compiled in only with -DTDNET_TIMING_PROBES (TDNET_EXTRA_CXXFLAGS of tdnet_amd/build.py; never in the shipped library): under
+// TDNET_PROBE_SKIP=<mask> a handle leaves pieces of the frame OUT -- the results are garbage -- to measure what the frame costs without them:
 //   1 = no Winograd transforms, 2 = no cache-only attention chain, 4 = no final attention, 8 = no Winograd GEMMs.  Upper bounds for what any
-//   optimisation of that piece can return (DESIGN_experiments 8.6).
+//   optimisation of that piece can return (DESIGN_experiments 8.6, profiles/r04z_frame_budget_*).
+#ifdef TDNET_TIMING_PROBES
 static int probe_skip() {
-    static const int m = [] { const char* e = getenv("TDNET_PROBE_SKIP"); return e ? atoi(e) : 0; }();
+    static const int m = [] {
+        const char* e = getenv("TDNET_PROBE_SKIP");
+        const int v = e ? atoi(e) : 0;
+        if (v) fprintf(stderr, "tdnet: TDNET_PROBE_SKIP=%d -- pieces of the frame are NOT computed, every result of this process is garbage (timing probe build)\n", v);
+        return v;
+    }();
     return m;
 }
+#else
+static constexpr int probe_skip() { return 0; }
+#endif
 static void prof_begin(tdnet* n, int family, int dominant, double flops, hipStream_t s) {
     if (!n || !n->prof) return;
     if (n->nrec == n->recs.size()) {
@@ -1043,36 +1050,23 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = (!n && L.probe) ? 100 + L.probe : 1;
+    a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.stagger = L.stagger; a.nbatch = 1;
     prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || (L.rh && L.rh != CD_W64)) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
     else if (L.h16 && L.rh == CD_W64) {                                 // 64 -> 64 channels: persistent workgroups with the weights resident in LDS
         if (!conv_launch_dma_w64(a, L.out16, s)) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     } else if (L.h16 && L.rh) {                                         // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
         // A cascade of kernel forms for the SAME tile, each falling back to the next when the conv does not qualify (not a 3x3 "same" conv,
-        // halo wider than the form's image buffer): super-step barriers -> loader waves / LDS flags -> row images -> tap by tap.
+        // halo wider than the form's image buffer): narrow tiles -> loader waves -> row images -> tap by tap.
         int rh = L.rh;
         bool done = false;
-        if (rh == CD_128_D || rh == CD_128_DN || rh == CD_192_DN || rh == CD_256_DN) {   // deep pipeline (k_conv_dma_h3d)
-            done = !L.rowimg_off && conv_launch_dma3d(a, rh, L.KS, L.out16, s);
-            if (!done) rh = rh == CD_128_D ? CD_128_P : rh == CD_128_DN ? CD_128_N : rh == CD_192_DN ? CD_192_N : CD_256_N;
-        }
-        const bool is192 = rh == CD_192_P1 || rh == CD_192_S || rh == CD_192_P || rh == CD_192_PR || rh == CD_192_F || rh == CD_192_P8 || rh == CD_192_N;
-        const bool is256 = rh == CD_256_P || rh == CD_256_F || rh == CD_256_N;
+        const bool is192 = rh == CD_192_P || rh == CD_192_N, is256 = rh == CD_256_P || rh == CD_256_N;
         if (rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {        // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
             done = !L.rowimg_off && conv_launch_dma3n(a, rh, L.KS, L.out16, s);
             if (!done) rh = is192 ? CD_192_P : is256 ? CD_256_P : CD_128_P;
         }
-        if (rh == CD_128_S || rh == CD_192_S) {                          // loader waves, one barrier per super-step (k_conv_dma_h3s)
-            done = !L.rowimg_off && conv_launch_dma3s(a, rh, L.KS, L.out16, s);
-            if (!done) rh = is192 ? CD_192_P : CD_128_P;
-        }
-        if (!done && (rh == CD_128_F || rh == CD_192_F || rh == CD_256_F || rh == CD_128_F4)) {           // loader + matrix waves, LDS flags (k_conv_dma_h3f)
-            done = !L.rowimg_off && conv_launch_dma3f(a, rh, L.KS, L.out16, s);
-            if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
-        }
-        if (!done && (rh == CD_192_P1 || rh == CD_128_P || rh == CD_192_P || rh == CD_256_P || rh == CD_128_P4 || rh == CD_128_PR || rh == CD_192_PR || rh == CD_128_P8 || rh == CD_192_P8)) {
-            done = !L.rowimg_off && conv_launch_dma3p(a, rh, L.KS, L.out16, s);                           // dedicated loader waves (k_conv_dma_h3p)
+        if (!done && (rh == CD_128_P || rh == CD_192_P || rh == CD_256_P)) {                              // dedicated loader waves (k_conv_dma_h3p)
+            done = !L.rowimg_off && conv_launch_dma3p(a, rh, L.KS, L.out16, s);
             if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
         }
         if (!done && (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s))) conv_launch_dma(a, rh, L.KS, L.out16, s);
@@ -1985,20 +1979,15 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     // four / two LDS buffers whatever the grid (16 chooses by the grid); 22: 128 rows, eight waves; 23 / 26: the same on row images with one
     // barrier per super-step / per K step only; 24 / 25: 192 rows likewise; 27 / 28 / 29: 256 / 192 / 128 rows in the early-landing form
     // only; -1: the heuristic (DMA kernel where it applies)
-    const bool no_rowimg = tile >= 48 && tile < 64;                    // 48 + code: the same tile, tap-by-tap staging (k_conv_dma_h) instead of row images
+    const bool no_rowimg = tile >= 48 && tile <= 61;                   // 48 + code: the same tile, tap-by-tap staging (k_conv_dma_h) instead of row images
     if (no_rowimg) tile -= 32;
     static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
                                          CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
-    static const int code_of_tile_p[22] = {CD_128_P, CD_192_P, CD_256_P, CD_128_P4, CD_128_PR, CD_192_PR,       // 31 .. 36: dedicated loader waves (k_conv_dma_h3p); 35 / 36: rotated K walk
-                                           CD_128_F, CD_192_F, CD_256_F, CD_128_F4,                            // 37 .. 40: the same without a barrier in the K loop (k_conv_dma_h3f)
-                                           CD_128_P8, CD_192_P8, CD_128_S, CD_192_S,                           // 41 / 42: eight loader waves; 43 / 44: one barrier per super-step (k_conv_dma_h3s)
-                                           CD_128_N, CD_192_N, CD_256_N,                                       // 45 .. 47: narrow tiles, rows x 64 channels (k_conv_dma_h3n)
-                                           CD_128_D, CD_128_DN, CD_192_DN, CD_256_DN,                          // 64 .. 67 (NOT 48+: those mean "tap by tap"): deep pipeline (k_conv_dma_h3d)
-                                           CD_192_P1};                                                         // 68: 192 x 128 with twelve matrix waves of 32 x 64
-    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 47 ? code_of_tile_p[tile - 31]
-                       : tile >= 64 && tile <= 68 ? code_of_tile_p[tile - 64 + 17] : 0;   // 30: the weights-resident 64 -> 64 kernel
+    static const int code_of_tile_p[6] = {CD_128_P, CD_192_P, CD_256_P,        // 31 .. 33: row images with four dedicated loader waves (k_conv_dma_h3p)
+                                          CD_128_N, CD_192_N, CD_256_N};       // 34 .. 36: narrow tiles, rows x 64 channels (k_conv_dma_h3n)
+    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile == 30 ? CD_W64 : tile >= 31 && tile <= 36 ? code_of_tile_p[tile - 31] : 0;   // 30: the weights-resident 64 -> 64 kernel
     if (force_rh) tile = force_rh == CD_W64 ? CT_128x64 : CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d, 16..47 (+ 32 for 16..29) or 64..68", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..36 (+ 32 for 16..29)", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;
@@ -2010,7 +1999,6 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, (long)Ho * Wo, o, tile < 0 ? -1 : tile)) return -1;
     L.in16 = L.out16 = true;
     L.rowimg_off = no_rowimg;
-    if (const char* e = getenv("TDNET_PROBE_STAGGER")) L.probe = atoi(e);     // probes only: k_conv_dma_h3n decomposition (no fetch / no DMA / no MFMA)
     if (force_rh == CD_256x256 && L.CoutPad % 256) { free_conv_layer(L); return td_fail("tdnet_op_conv2d_f16io: the 256 x 256 tile needs Cout padded to a multiple of 256"); }
     if (force_rh == CD_W64 ? !conv_dma_w64_supports(Cin, Cout, L.CoutPad, KS, stride, dil, pad) : (force_rh && !conv_dma_supports(Cin, Cout, KS, L.tile))) {
         free_conv_layer(L);

@@ -158,16 +158,6 @@ TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, u
     memcpy(lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
 }
 #define TD_WAIT_VM_PIECES(n) ((void)0)
-// LDS flags (csrc/td_device.h): fibers are cooperative, so the add is a plain one and the poll yields to the other fibers
-typedef unsigned td_flag_t;
-namespace tdemu { void yield_now(); }
-TD_DEV td_flag_t* td_flag_ptr(char* lds) { return (td_flag_t*)lds; }
-TD_DEV void td_flag_add(td_flag_t* f) { if ((threadIdx.x & 63) == 0) *f += 1u; }
-TD_DEV void td_flag_wait_ge(td_flag_t* f, unsigned target) { while ((int)(*(volatile td_flag_t*)f - target) < 0) tdemu::yield_now(); }
-#define TD_WAIT_LDS_READS() ((void)0)
-#define TD_LANES_ARRIVED() td_wave_sync()
-TD_DEV unsigned td_flag_peek(td_flag_t* f) { return *(volatile td_flag_t*)f; }
-TD_DEV bool td_flag_reached(unsigned peeked, unsigned target) { return (int)(peeked - target) >= 0; }
 #define TD_BARRIER_RAW() tdemu::syncthreads()
 
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }

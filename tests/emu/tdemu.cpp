@@ -128,7 +128,6 @@ static void fiber_entry() {
     tdemu_switch(&dummy, cur->sp);
     __builtin_trap();
 }
-void yield_now() { yield(); }
 void syncthreads() {
     const unsigned g = W->bar_gen;
     if (++W->bar_count == (unsigned)W->nthreads) { W->bar_count = 0; W->bar_gen++; return; }

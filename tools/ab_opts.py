@@ -7,7 +7,12 @@
 One process, one set of synthetic weights and frames; per round every variant gets a fresh handle (an idle handle's streams slow a busy
 one: INTEGRATION.md 3), P + 4 warm-up frames and `steps` timed frames between two device synchronisations; the rounds interleave the
 variants (A B C A B C ...) so that clock / thermal drift of the box spreads over all of them.  Also reports whether each variant's logits
-of a fixed 6-frame replay are bit-identical to the first variant's.  Costs ~3 s per variant and round instead of a bench.py process each."""
+of a fixed 6-frame replay are bit-identical to the first variant's.  Costs ~3 s per variant and round instead of a bench.py process each.
+
+Frame budget by leaving pieces out (DESIGN_experiments 8.6): a NON-shipping library built with TDNET_EXTRA_CXXFLAGS=-DTDNET_TIMING_PROBES (the
+variable must be set both where the library is built and where it is loaded, it is part of the build stamp) honours TDNET_PROBE_SKIP=<mask>
+(1 no Winograd transforms, 2 no cache-only chain, 4 no final attention, 8 no Winograd GEMMs; results are garbage, timing only):
+    export TDNET_EXTRA_CXXFLAGS=-DTDNET_TIMING_PROBES; for m in 0 1 2 4 8; do TDNET_PROBE_SKIP=$m python tools/ab_opts.py --rounds 2 ""; done"""
 import argparse
 import json
 import os

@@ -2,7 +2,7 @@
 // with TD_P_TRACE stamps s_memtime (shader cycles) per wave and step; s_memrealtime around the launch gives the clock the chip held.
 //   matrix waves: step start | first k-group's MFMAs issued | all MFMAs issued | after the barrier
 //   loader waves: step start | pieces issued | after the counted vmcnt wait | after the barrier
-// args: code (17 = 128 rows / 8 matrix waves, 20 = 128 rows / 4, 18 = 192 rows, 19 = 256 rows) H W Cin Cout dil
+// args: code (17 = 128 rows / 8 matrix waves, 18 = 192 rows / 6, 19 = 256 rows / 8) H W Cin Cout dil
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value tools/conv_h3p_trace.hip -o tools/_build/conv_h3p_trace
 #include <hip/hip_runtime.h>
 __device__ unsigned long long TD_P_TRACE[4 * 16 * 24 * 4];
@@ -34,8 +34,7 @@ int main(int argc, char** argv) {
     a.H = H; a.W = W; a.Cin = Cin; a.Wo = W; a.Cout = Cout; a.CoutPad = CoutPad; a.stride = 1; a.dil = dil; a.pad = dil; a.M = H * W;
     a.nsteps = nsteps; a.act = 1; a.tiles_n = 0; a.stagger = 0; a.nbatch = 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const bool flags = code == CD_128_F || code == CD_192_F || code == CD_256_F || code == CD_128_F4;   // k_conv_dma_h3f: stamps = [unit / step start, slot acquired / ready seen, issued / MFMAs issued, signalled]
-    auto launch = [&]() { return flags ? conv_launch_dma3f(a, code, KS, true, 0) : conv_launch_dma3p(a, code, KS, true, 0); };
+    auto launch = [&]() { return conv_launch_dma3p(a, code, KS, true, 0); };
     for (int i = 0; i < 3; ++i) if (!launch()) { printf("shape does not run on the loader-wave kernel\n"); return 1; }
     hipEventRecord(e0, 0);
     for (int i = 0; i < 5; ++i) launch();
@@ -46,8 +45,7 @@ int main(int argc, char** argv) {
            2.0 * H * W * Cin * 9.0 * Cout / (ms / 5 * 1e-3) / 1e12);
     std::vector<unsigned long long> t(4 * 16 * 24 * 4);
     hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(TD_P_TRACE), t.size() * 8);
-    const int nwc = code == CD_128_P || code == CD_256_P || code == CD_128_PR || code == CD_128_F || code == CD_256_F || code == CD_128_P8 ? 8 : code == CD_128_P4 || code == CD_128_F4 ? 4 : 6;
-    const int nld = code == CD_128_P8 || code == CD_192_P8 ? 8 : 4;
+    const int nwc = code == CD_192_P ? 6 : 8, nld = 4;
     const int ns = nsteps < 24 ? nsteps : 24;
     for (int wg = 0; wg < 2; ++wg) {
         printf("workgroup %d: mean over steps 3..%d, shader cycles.  matrix waves: [to first group issued, rest of the MFMAs issued, to the barrier's end]; loaders: [issue, vmcnt wait, barrier]\n", wg, ns - 1);
