@@ -11,7 +11,10 @@ Differences from the reference, on purpose:
   * `reset()` empties the K/Q/V FIFO so a second clip can be fed (the reference has no reset);
   * a batch of N > 1 frames is N independent video streams in the reference too (every cached tensor, LayerNorm plane and softmax is
     per sample; td4_psp18.py:123-154 with [N, Lk, 64] queue entries): here sample i runs on its own handle (own FIFO), created the
-    first time a batch that large arrives.  Like the reference's queues, the batch size must not change while frames are cached;
+    first time a batch that large arrives, and samples 1 .. N-1 on HIP streams of their own beside the caller's, joined before
+    forward() returns: frames of small maps leave CUs idle that another sample's kernels fill (720x960 fp16, two samples: 1430
+    frames/s instead of 1089; 1024x2048: no change -- profiles/r04z_multi_clip_*).  Like the reference's queues, the batch size
+    must not change while frames are cached;
   * `load_state_dict(strict=False)` drops unexpected keys and reports missing ones like nn.Module does, but a missing tensor has no
     "constructor initialisation" to fall back on here: it is taken from the seeded synthetic generator when `synthetic_seed` is given
     and is an error at the first frame otherwise;
@@ -58,6 +61,7 @@ class _TDNetBase(nn.Module):
 
     def _init_batch_state(self):
         self._extra_engines = []                                       # handles of the batch samples 1 .. N-1 (own FIFO each)
+        self._extra_streams = []                                       # ... and the HIP streams their frames are enqueued on
         self._missing_keys = []
         self._batch = None                                             # batch size of the frames currently cached
 
@@ -183,14 +187,33 @@ class _TDNetBase(nn.Module):
         if pos_id not in range(self.path_num):
             raise RuntimeError("pos_id must be t mod %d" % self.path_num)
 
+    def _for_each_sample(self, img, call):
+        """call(i, engine, raw_stream) for every batch sample: sample 0 on the caller's stream, sample i > 0 on its own stream, which
+        waits for the caller's (the input is ready) and is joined again before this returns -- so the caller's stream stays the only
+        one the caller has to order against, as with a single handle.  N = 1 (test.py:46-53): one handle, one call, no events."""
+        engines = self._engines_for_batch(img)
+        cur = torch.cuda.current_stream(img.device)
+        if len(engines) == 1:
+            call(0, engines[0], cur.cuda_stream)
+            return
+        while len(self._extra_streams) < len(engines) - 1:
+            self._extra_streams.append(torch.cuda.Stream(img.device))
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        for i, eng in enumerate(engines):
+            s = cur if i == 0 else self._extra_streams[i - 1]
+            if i:
+                s.wait_event(ready)
+            call(i, eng, s.cuda_stream)
+        for s in self._extra_streams[:len(engines) - 1]:
+            cur.wait_stream(s)
+
     def forward(self, img, pos_id=0):
         self._check_frame(img, pos_id)
         img = img.contiguous().float()
         N = img.shape[0]
         out = torch.empty((N, self.nclass, img.shape[2], img.shape[3]), device=img.device, dtype=torch.float32)
-        s = torch.cuda.current_stream(img.device).cuda_stream
-        for i, eng in enumerate(self._engines_for_batch(img)):          # N = 1 (test.py:46-53): one handle, one call
-            eng.forward(img[i].data_ptr(), pos_id, out[i].data_ptr(), s)
+        self._for_each_sample(img, lambda i, eng, s: eng.forward(img[i].data_ptr(), pos_id, out[i].data_ptr(), s))
         return out
 
     def forward_labels(self, img, pos_id=0):
@@ -199,9 +222,7 @@ class _TDNetBase(nn.Module):
         img = img.contiguous().float()
         N = img.shape[0]
         out = torch.empty((N, img.shape[2], img.shape[3]), device=img.device, dtype=torch.int32)
-        s = torch.cuda.current_stream(img.device).cuda_stream
-        for i, eng in enumerate(self._engines_for_batch(img)):
-            eng.forward_labels(img[i].data_ptr(), pos_id, out[i].data_ptr(), s)
+        self._for_each_sample(img, lambda i, eng, s: eng.forward_labels(img[i].data_ptr(), pos_id, out[i].data_ptr(), s))
         return out
 
     # ---- split frame + cache transport (path-parallel single stream: parallel.PathParallelStream) ------------------

@@ -333,11 +333,23 @@ def test_batch_of_streams_and_non_strict_loading():
     b = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, T, seed=22)]
     with torch.no_grad():
         ma, mb, m2 = make_model("td4", "resnet18", seed=4), make_model("td4", "resnet18", seed=4), make_model("td4", "resnet18", seed=4)
+        refs = []
         for t in range(T):
             ra, rb = ma(a[t], pos_id=t % 4), mb(b[t], pos_id=t % 4)
             out = m2(torch.cat([a[t], b[t]], 0), pos_id=t % 4)
             assert out.shape == (2, 19, H, W)
             assert torch.equal(out[0:1], ra) and torch.equal(out[1:2], rb), t
+            refs.append(torch.cat([ra, rb], 0))
+        # sample 1 runs on a stream of its own beside the caller's: a caller on a NON-default stream must find both samples complete
+        # when its own stream gets there (the join), without a device synchronisation in between
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            m5 = make_model("td4", "resnet18", seed=4)
+            sums = [m5(torch.cat([a[t], b[t]], 0), pos_id=t % 4).double().sum(dim=(1, 2, 3)) for t in range(T)]
+        side.synchronize()
+        for t in range(T):
+            assert torch.equal(sums[t], refs[t].double().sum(dim=(1, 2, 3))), t
         lab = m2.forward_labels(torch.cat([a[0], b[0]], 0), pos_id=(T % 4))
         assert lab.shape == (2, H, W)
         with pytest.raises(RuntimeError, match="batch size"):
