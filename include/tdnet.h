@@ -212,6 +212,11 @@ int tdnet_op_layernorm_hw(const float* x_dev, int HW, int C, const float* g_dev,
 /* PPM (td4_psp18.py:271-284): c4 NHWC [h,w,512] -> z NHWC [h,w,512]; w_host: 4 folded [128,512] matrices, b_host 4x[128] */
 int tdnet_op_ppm(const float* c4_dev, int h, int w, const float* w_host, const float* b_host, int path_num, int pid,
                  float* z_dev, void* stream);
+/* Do two HIP streams run on ONE hardware queue (HIP deals streams onto a small pool of queues, GPU_MAX_HW_QUEUES per priority class, and
+ * reuses them; kernels of two streams on one queue run one after the other)?  Two 40-us spin kernels started together: *shared = 1 when
+ * they serialise.  Synchronises both streams with the host.  The module uses it to place the streams of the samples of a batch
+ * (tdnet_amd/model/_base.py); a handle applies the same test to its internal streams at its first frame.                              */
+int tdnet_op_streams_share_queue(void* stream_a, void* stream_b, int* shared);
 /* bilinear align_corners=True (td4_psp18.py:227): planar [C,h,w] -> [C,H,W]                                       */
 int tdnet_op_upsample(const float* in_dev, int C, int h, int w, int H, int W, float* out_dev, void* stream);
 

@@ -78,6 +78,7 @@ SYMBOLS = {
     "tdnet_op_layernorm_hw": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_op_ppm": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
                                     c_void_p, c_void_p]),
+    "tdnet_op_streams_share_queue": (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "tdnet_op_upsample": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          c_void_p, c_void_p]),
 }

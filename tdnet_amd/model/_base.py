@@ -11,9 +11,9 @@ Differences from the reference, on purpose:
   * `reset()` empties the K/Q/V FIFO so a second clip can be fed (the reference has no reset);
   * a batch of N > 1 frames is N independent video streams in the reference too (every cached tensor, LayerNorm plane and softmax is
     per sample; td4_psp18.py:123-154 with [N, Lk, 64] queue entries): here sample i runs on its own handle (own FIFO), created the
-    first time a batch that large arrives, and samples 1 .. N-1 on HIP streams of their own beside the caller's, joined before
-    forward() returns: frames of small maps leave CUs idle that another sample's kernels fill (720x960 fp16, two samples: 1430
-    frames/s instead of 1089; 1024x2048: no change -- profiles/r04z_multi_clip_*).  Like the reference's queues, the batch size
+    first time a batch that large arrives, and the odd samples on a second HIP stream beside the caller's, joined before
+    forward() returns: frames of small maps leave CUs idle that another sample's kernels fill (720x960 fp16, two samples: 1445
+    frames/s instead of 1100; 1024x2048: no change -- profiles/r04z_multi_clip_*).  Like the reference's queues, the batch size
     must not change while frames are cached;
   * `load_state_dict(strict=False)` drops unexpected keys and reports missing ones like nn.Module does, but a missing tensor has no
     "constructor initialisation" to fall back on here: it is taken from the seeded synthetic generator when `synthetic_seed` is given
@@ -62,6 +62,7 @@ class _TDNetBase(nn.Module):
     def _init_batch_state(self):
         self._extra_engines = []                                       # handles of the batch samples 1 .. N-1 (own FIFO each)
         self._extra_streams = []                                       # ... and the HIP streams their frames are enqueued on
+        self._extra_streams_for = None                                 # the caller's stream they were placed against
         self._missing_keys = []
         self._batch = None                                             # batch size of the frames currently cached
 
@@ -188,7 +189,7 @@ class _TDNetBase(nn.Module):
             raise RuntimeError("pos_id must be t mod %d" % self.path_num)
 
     def _for_each_sample(self, img, call):
-        """call(i, engine, raw_stream) for every batch sample: sample 0 on the caller's stream, sample i > 0 on its own stream, which
+        """call(i, engine, raw_stream) for every batch sample: even samples on the caller's stream, odd ones on a second stream, which
         waits for the caller's (the input is ready) and is joined again before this returns -- so the caller's stream stays the only
         one the caller has to order against, as with a single handle.  N = 1 (test.py:46-53): one handle, one call, no events."""
         engines = self._engines_for_batch(img)
@@ -196,17 +197,40 @@ class _TDNetBase(nn.Module):
         if len(engines) == 1:
             call(0, engines[0], cur.cuda_stream)
             return
-        while len(self._extra_streams) < len(engines) - 1:
-            self._extra_streams.append(torch.cuda.Stream(img.device))
+        if self._extra_streams_for != cur.cuda_stream:                 # placed against the caller's stream: another caller stream, again
+            self._extra_streams, self._extra_streams_for = [], cur.cuda_stream
+        # TWO lanes whatever N: even samples on the caller's stream, odd ones on one extra stream.  A third concurrent frame gains
+        # nothing and can cost a lot (720x960 fp16, frames/s in total: 1 sample 1100, 2: 1445, 3 on three streams: 1280 with two
+        # hardware queues, 850 with three -- the process then owns more busy queues than stay resident; profiles/r04z_*batched*)
+        if not self._extra_streams:
+            self._extra_streams.append(self._stream_beside([cur], img.device, engines[0].lib))
+        side = self._extra_streams[0]
         ready = torch.cuda.Event()
         ready.record(cur)
+        side.wait_event(ready)
         for i, eng in enumerate(engines):
-            s = cur if i == 0 else self._extra_streams[i - 1]
-            if i:
-                s.wait_event(ready)
-            call(i, eng, s.cuda_stream)
-        for s in self._extra_streams[:len(engines) - 1]:
-            cur.wait_stream(s)
+            call(i, eng, (side if i & 1 else cur).cuda_stream)
+        cur.wait_stream(side)
+
+    @staticmethod
+    def _stream_beside(taken, device, lib):
+        """A stream whose kernels really run BESIDE those of `taken`: HIP deals streams onto a small pool of hardware queues and two
+        streams on one queue serialise (which pair collides depends on how many streams the process has created -- with three queues
+        the second sample's first candidate lands on the caller's queue: 1066 instead of 1430 frames/s for two 720x960 clips,
+        profiles/r04z_hw_queues_*).  Candidates from torch's pool are tried against every taken stream with the library's spin-pair test
+        (include/tdnet.h tdnet_op_streams_share_queue); with more samples than queues the last candidate is used as it is."""
+        import ctypes
+        s = None
+        for _ in range(8):
+            s = torch.cuda.Stream(device)
+            shared = ctypes.c_int(0)
+            for t in taken:
+                lib.check(lib.tdnet_op_streams_share_queue(t.cuda_stream, s.cuda_stream, ctypes.byref(shared)))
+                if shared.value:
+                    break
+            if not shared.value:
+                break
+        return s
 
     def forward(self, img, pos_id=0):
         self._check_frame(img, pos_id)
