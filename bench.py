@@ -393,7 +393,13 @@ def main():
         models, streams, clips = [None], [None], [[torch.zeros(1) for _ in range(NF)]]
     else:
         models = [make_model(kopts) for _ in range(C)]                            # extra clips: own handle (weights + FIFO), own stream
-        streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(C - 1)]
+        # two lanes whatever C (model/_base.py _for_each_sample): even clips on the current stream, odd ones on ONE more stream that is
+        # checked to sit on another hardware queue; a third concurrently busy stream costs more than it fills
+        from tdnet_amd import _capi
+        from tdnet_amd.model._base import _TDNetBase
+        cur_s = torch.cuda.current_stream(dev)
+        side_s = _TDNetBase._stream_beside([cur_s], dev, _capi.lib()) if C > 1 else None
+        streams = [cur_s if c % 2 == 0 else side_s for c in range(C)]
         # one clip per handle (different seeds), pre-staged on the device; frames cycle, pos_id keeps counting
         clips = [[torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=100 + rank + 1000 * c)] for c in range(C)]
     model, clip = models[0], clips[0]

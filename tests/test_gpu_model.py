@@ -350,6 +350,12 @@ def test_batch_of_streams_and_non_strict_loading():
         side.synchronize()
         for t in range(T):
             assert torch.equal(sums[t], refs[t].double().sum(dim=(1, 2, 3))), t
+        # three samples on the two lanes: samples 0 and 2 share the caller's stream, sample 1 runs beside them
+        c = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, T, seed=23)]
+        mc, m6 = make_model("td4", "resnet18", seed=4), make_model("td4", "resnet18", seed=4)
+        for t in range(T):
+            out = m6(torch.cat([a[t], b[t], c[t]], 0), pos_id=t % 4)
+            assert torch.equal(out[0:2], refs[t]) and torch.equal(out[2:3], mc(c[t], pos_id=t % 4)), t
         lab = m2.forward_labels(torch.cat([a[0], b[0]], 0), pos_id=(T % 4))
         assert lab.shape == (2, H, W)
         with pytest.raises(RuntimeError, match="batch size"):
