@@ -85,9 +85,11 @@ def parse_args(argv=None):
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips served concurrently by one GPU, each with its own handle/FIFO on its own HIP stream "
                          "(throughput mode; a step is then one frame of EVERY clip).  Default 1 = BASELINE's one clip per GPU")
-    ap.add_argument("--mode", default="clips", choices=["clips", "path-parallel"],
+    ap.add_argument("--mode", default="clips", choices=["clips", "path-parallel", "frame-pipelined"],
                     help="clips (default, BASELINE): independent clips, one per GPU, no per-frame communication | path-parallel: ONE "
-                         "stream served by all N ranks, one all-gather of cache entries per round of N frames (a step = one round)")
+                         "stream served by all N ranks, one all-gather of cache entries per round of N frames (a step = one round) | "
+                         "frame-pipelined: each rank's ONE clip with two frames in flight (two handles on two HIP streams of the rank, "
+                         "parallel.FramePipelinedStream; a step = one round of two frames; throughput mode for maps that leave CUs idle)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT the model (CPU, gloo): rank launch, rendezvous, weight broadcast, barriers, timing "
                          "reduction and the JSON line; `value` is null.  Used by tests/test_bench_launch.py; never a measurement")
@@ -388,6 +390,8 @@ def main():
         return m
 
     C = 1 if args.dry_run else max(1, args.clips_per_gpu)
+    if args.mode == "frame-pipelined" and not args.dry_run:
+        C = 2                                                                     # two handles, ONE clip (set up below)
     NF = 8
     if args.dry_run:
         models, streams, clips = [None], [None], [[torch.zeros(1) for _ in range(NF)]]
@@ -411,9 +415,19 @@ def main():
         clip = clips[0] = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=100)]   # the SAME stream on every rank
         C = 1
 
+    fpl = None
+    if args.mode == "frame-pipelined" and not args.dry_run:
+        fpl = parallel.FramePipelinedStream(models[:2], P, dev, (H, W))
+        C = 1
+    FR = C * (2 if fpl is not None else 1)                            # frames per step and rank
+
     def step(ms=None, n_clips=None):
         ms = models if ms is None else ms
         t = state["t"]
+        if fpl is not None and ms is models:                          # one round: frames t, t + 1 of the clip, no join between rounds
+            out = fpl.process([clip[t % NF], clip[(t + 1) % NF]], first_frame=t, join=False)
+            state["t"] = t + 2
+            return out[0]
         if args.dry_run:
             clip[t % NF].add_(1.0)
             state["t"] = t + 1
@@ -469,7 +483,7 @@ def main():
         return 0
     tmax = parallel.allreduce_max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()
     per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
-    per_rank[rank] = C * args.steps / dt
+    per_rank[rank] = FR * args.steps / dt
     per_rank = parallel.allreduce_sum(per_rank).tolist()
     init_rank = torch.zeros(world, dtype=torch.float64, device=dev)
     init_rank[rank] = init_s
@@ -481,7 +495,7 @@ def main():
     if aff is not None:
         aff_rank = parallel.gather_strings("node %s cpus %s (%d), %d threads%s" % (aff.get("numa_node"), aff.get("cpus"), aff.get("n_cpus", 0), aff.get("omp_num_threads", 0),
                                                                                "" if aff.get("pinned") else " NOT PINNED: " + str(aff.get("why", ""))), world, dev)
-    fps = world * C * args.steps / tmax
+    fps = world * FR * args.steps / tmax
 
     mname = ("psp%s" if args.model == "psp" else args.model + "-psp%s") % args.backbone[6:]
     res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
@@ -498,12 +512,14 @@ def main():
            "hw_queues": __import__("tdnet_amd").hw_queue_note(),
            "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, %d clip%s per GPU"
                                   % (mname, H, W, spec.fifo, C, "" if C == 1 else "s (concurrent HIP streams)"),
-                      "parallelism": ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else
+                      "parallelism": ("clip-parallel x%d, RCCL weight broadcast only; each clip with TWO FRAMES IN FLIGHT (two handles on two HIP "
+                                      "streams, cache entries handed over between encode and propagate; bit-identical outputs)" % world) if fpl is not None else
+                                     ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else
                                      ("path-parallel x%d: one stream, one all-gather of %d cache entries per round" % (world, world)),
                       "target_fps_per_gpu": 30}}
     if sustained is not None:
         res["sustained"] = {"steps_timed": sustained[0], "seconds": round(sustained[1], 4),
-                            "value": round(world * C * sustained[0] / sustained[1], 3),
+                            "value": round(world * FR * sustained[0] / sustained[1], 3),
                             "unit": "frames/s", "ms_per_step": round(1e3 * sustained[1] / sustained[0], 4),
                             "note": "the same timed loop (barrier + synchronize on both sides, max over ranks) over >= 0.5 s, because --steps %d "
                                     "is a %.0f-ms window; `value` above is exactly --steps frames" % (args.steps, 1e3 * tmax)}
@@ -645,7 +661,7 @@ def main():
             ms_.engine.close()                                          # streams of a handle are hardware queues: release them now
             del ms_
         exec_gflop = (acc[0][1] + acc[1][1]) / nprof / 1e9           # conv/GEMM (executed: Winograd GEMM FLOP) + attention matmuls
-        single_fps = C * args.steps / tmax                            # this GPU's frames/s
+        single_fps = FR * args.steps / tmax                           # this GPU's frames/s
         res["frame"] = {"algorithmic_gflop": round(gflop, 1), "algorithmic_tflops": round(gflop * single_fps / 1e3, 2),
                         "algorithmic_frac_of_roof": round(gflop * single_fps / 1e3 / peak, 4),
                         "executed_gflop": round(exec_gflop, 1), "executed_tflops": round(exec_gflop * single_fps / 1e3, 2),

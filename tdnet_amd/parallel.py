@@ -263,3 +263,98 @@ class PathParallelStream:
                 else:
                     self.stage.cache_push(*self._split(buf[j]))
         return outs
+
+
+class FramePipelinedStream:
+    """One video stream on ONE GPU with W (= 2) frames in flight: PathParallelStream's round with the ranks replaced by LANES -- W handles
+    with the same weights on W HIP streams of one process, the exchange a pair of device-to-device copies.
+
+    A frame of a small map leaves most of the chip idle (720x960 fp16: most launches have fewer workgroups than the chip has CUs, and a
+    K loop is a chain of latencies), and what frame t + 1 needs from frame t is only its cache entry, which exists once frame t is
+    ENCODED (td4_psp18.py:145-154).  So lane j of a round encodes frame r0 + j beside the other lane, exports the entry, then walks the
+    round in frame order: pushes the entries of the frames before its own (waiting for their encode events), propagates its own frame,
+    pushes the ones after.  Both FIFOs go through exactly the states of the sequential loop (test.py:45-53): the outputs are bit for bit
+    those of one handle, only the order of work on the chip changes.  Throughput mode: a frame's LATENCY does not improve (it grows by
+    what the other lane takes from it); at 1024x2048, where a frame fills the chip, there is nothing to gain.
+
+    `stages`: W model instances (tdnet_amd.model) loaded with the same state_dict.  The rounds of consecutive process() calls chain
+    without a host or device join in between when join=False; the caller's stream then has to wait (`join()`) before it reads outputs."""
+
+    def __init__(self, stages, path_num, device, frame_size):
+        self.stages, self.P, self.device = list(stages), path_num, torch.device(device)
+        self.W = len(self.stages)
+        if self.W < 1:
+            raise ValueError("FramePipelinedStream: at least one stage")
+        H, Wd = int(frame_size[0]), int(frame_size[1])
+        self._sizes = self.stages[0].cache_entry_numel_for(H, Wd)
+        for st in self.stages:
+            st.ensure_engine(H, Wd, self.device)
+        # [round parity][lane]: lane j re-exports into its row two rounds later, after waiting for the "round done" events the other
+        # lanes recorded behind their reads of it
+        self._buf = torch.zeros(2, self.W, sum(self._sizes), dtype=torch.float32, device=self.device)
+        self._done = [[None] * self.W, [None] * self.W]
+        self._lanes, self._lanes_for, self._round = None, None, 0
+
+    def _split(self, row):
+        nq, nk, nv = self._sizes
+        return row[:nq], row[nq:nq + nk], row[nq + nk:]
+
+    def _lane_streams(self, cur):
+        if self._lanes_for != cur.cuda_stream:
+            from .model._base import _TDNetBase
+            lanes = [cur]
+            for _ in range(self.W - 1):
+                lanes.append(_TDNetBase._stream_beside(lanes, self.device, self.stages[0].engine.lib))
+            self._lanes, self._lanes_for = lanes, cur.cuda_stream
+        return self._lanes
+
+    def join(self):
+        """The caller's current stream waits for every lane (needed after process(..., join=False) before outputs are read on it)."""
+        if self._lanes:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self._lanes[1:]:
+                cur.wait_stream(s)
+
+    def process(self, frames, labels=False, first_frame=0, join=True):
+        """frames: consecutive frames of the stream ([1,3,H,W] device tensors); frames[i] is frame first_frame + i.  Returns the list of
+        outputs in frame order (logits, or int32 labels)."""
+        T, W = len(frames), self.W
+        cur = torch.cuda.current_stream(self.device)
+        lanes = self._lane_streams(cur)
+        ready = torch.cuda.Event()
+        ready.record(cur)                                             # the frames are the caller's: produced on its stream
+        for s in lanes[1:]:
+            s.wait_event(ready)
+        outs = [None] * T
+        for r0 in range(0, T, W):
+            n = min(W, T - r0)
+            par = self._round & 1
+            buf, done = self._buf[par], self._done[par]
+            self._round += 1
+            enc = []
+            for j in range(n):
+                with torch.cuda.stream(lanes[j]):
+                    for i in range(W):
+                        if i != j and done[i] is not None:
+                            lanes[j].wait_event(done[i])               # lane i has read this row (two rounds ago)
+                    self.stages[j].encode(frames[r0 + j], pos_id=(first_frame + r0 + j) % self.P)
+                    self.stages[j].cache_export(*self._split(buf[j]))
+                    e = torch.cuda.Event()
+                    e.record(lanes[j])
+                    enc.append(e)
+            for j in range(W):                                        # a lane without a frame in a short last round still takes every entry
+                with torch.cuda.stream(lanes[j]):
+                    for i in range(n):
+                        if i == j:
+                            outs[r0 + j] = self.stages[j].propagate(labels=labels)
+                            if j:
+                                outs[r0 + j].record_stream(cur)        # allocated on the lane's stream, consumed on the caller's
+                        else:
+                            lanes[j].wait_event(enc[i])
+                            self.stages[j].cache_push(*self._split(buf[i]))
+                    done[j] = torch.cuda.Event()
+                    done[j].record(lanes[j])
+        if join:
+            self.join()
+        return outs
+

@@ -79,3 +79,29 @@ def test_two_ranks_one_stream_bit_identical(name, T):
             ref = m(torch.from_numpy(x).to(dev), pos_id=t % spec.path_num).cpu().numpy()
             assert np.array_equal(got, ref), (t, float(np.abs(got - ref).max()))   # and bit-identical to one handle
     assert tm.clip_miou(hist) >= 0.9995
+
+
+@pytest.mark.parametrize("name,T", [("td4", 11), ("td2", 5)])
+def test_two_frames_in_flight_on_one_gpu_bit_identical(name, T):
+    """parallel.FramePipelinedStream: the same round with the ranks replaced by two LANES of one process (two handles, two HIP streams,
+    the exchange a device-to-device copy) -- one clip, two frames in flight.  Bit for bit one handle serving the stream, over an odd
+    number of frames (a short last round), a second process() call that continues the stream without a join in between, and labels."""
+    H, W = 129, 257
+    dev = torch.device("cuda", 0)
+    spec, m = _make(name, H, W, dev)
+    _, a = _make(name, H, W, dev)
+    _, b = _make(name, H, W, dev)
+    P = spec.path_num
+    frames = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, T + 4, seed=9)]
+    with torch.no_grad():
+        ref = [m(x, pos_id=t % P) for t, x in enumerate(frames)]
+        fp = parallel.FramePipelinedStream([a, b], P, dev, (H, W))
+        outs = fp.process(frames[:T], join=False)                       # T odd: lane 1 has no frame in the last round
+        outs += fp.process(frames[T:T + 1], first_frame=T, join=False)  # ... and the next call starts on lane 0 again
+        labs = fp.process(frames[T + 1:], labels=True, first_frame=T + 1)
+        torch.cuda.synchronize()
+    assert a.engine.fifo_len() == b.engine.fifo_len() == spec.fifo
+    for t in range(T + 1):
+        assert torch.equal(outs[t], ref[t]), (name, t, float((outs[t] - ref[t]).abs().max()))
+    for i, lab in enumerate(labs):
+        assert torch.equal(lab[0].long(), ref[T + 1 + i][0].max(0)[1]), (name, T + 1 + i)
