@@ -256,7 +256,7 @@ def profile_dominant(eng, step_one, nprof, sync, torch):
     return acc
 
 
-def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite):
+def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite, pipelined=False):
     """One short leg for another BASELINE.json config on this GPU: frames/s over `steps` steady frames, the dominant kernel's roofline
     fraction (profiled replay) and parity against the CPU oracle on `cpu_frames` steady frames.  Own model, own clip, own oracle."""
     import numpy as np
@@ -308,7 +308,46 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         par, cpu_t, _ = parity_sample(m, ref, clip, P, P, cpu_frames, precision == "fp32", torch, np, tdnet_ref)
         leg["parity"] = par
         leg["cpu_baseline"] = {"value": round(cpu_frames / cpu_t, 4), "unit": "frames/s", "kind": "port", "sample": "%d steady-state frames" % cpu_frames}
-    eng.close()
+    if pipelined:
+        # the same clip with TWO FRAMES IN FLIGHT (parallel.FramePipelinedStream: two handles on two HIP streams, the cache entry handed
+        # over between encode and propagate): first held bit for bit to this leg's single handle on a replay from an empty FIFO, then timed
+        from tdnet_amd import parallel
+        nchk = P + 4
+        with torch.no_grad():
+            m.reset()
+            refs = [m(clip[t % NF], pos_id=t % P).clone() for t in range(nchk)]
+            sync()
+            eng.close()
+            stages = []
+            for _ in range(2):
+                st_ = cls(nclass=19, path_num=P, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
+                st_.load_state_dict(sd)
+                stages.append(st_)
+            fp = parallel.FramePipelinedStream(stages, P, dev, (H, W))
+            outs = fp.process([clip[t % NF] for t in range(nchk)])
+            same = all(torch.equal(x, y) for x, y in zip(outs, refs))
+            del outs, refs
+            t = nchk                                                    # even: the rounds stay aligned with pos_id = t mod P
+            for _ in range(6):
+                fp.process([clip[t % NF], clip[(t + 1) % NF]], first_frame=t, join=False); t += 2
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):                                      # `steps` rounds = 2 x steps frames
+                fp.process([clip[t % NF], clip[(t + 1) % NF]], first_frame=t, join=False); t += 2
+            sync()
+            dt2 = time.perf_counter() - t0
+        leg["two_frames_in_flight"] = {"value": round(2 * steps / dt2, 3), "unit": "frames/s", "frames": 2 * steps, "vs_one_handle": round(2 * steps / dt2 / leg["value"], 3),
+                                       "bit_identical_to_one_handle": bool(same), "frames_compared": nchk,
+                                       "what": "ONE clip, two handles on two HIP streams of this process, frame t + 1 encoded beside frame t (bench.py --mode frame-pipelined); "
+                                               "throughput of small maps that leave CUs idle, a frame's latency grows"}
+        if not same:
+            leg["two_frames_in_flight"]["FAILED"] = True
+            leg.setdefault("parity", {})["FAILED"] = True
+        for st_ in stages:
+            st_._close_engines()
+        del stages, fp
+    else:
+        eng.close()
     del m
     return leg
 
@@ -736,7 +775,7 @@ def main():
                                  "td2_psp50(backbone='resnet18', path_num=2), Testing/model/pspnet/td2_psp50.py:52-58"),
                 other_config_leg("configs[4]", "td2", "resnet34", (720, 960), "fp16", 40, ncpu, dev, sync,
                                  "td2-bise34 does not exist in the reference (SURVEY 0): td2_psp50(backbone='resnet34') is its stand-in; "
-                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path")]
+                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path", pipelined=True)]
             if any(l.get("parity", {}).get("FAILED") for l in res["other_configs"]):
                 exit_code = 3
     if rank == 0:
