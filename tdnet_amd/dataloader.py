@@ -60,8 +60,9 @@ class cityscapesLoader():
               [255, 0, 0], [0, 0, 142], [0, 0, 70], [0, 60, 100], [0, 80, 100], [0, 0, 230], [119, 11, 32]]
     label_colours = dict(zip(range(19), colors))
 
-    def __init__(self, img_path, in_size):
+    def __init__(self, img_path, in_size, pin_memory=False):
         self.img_path = img_path
+        self.pin_memory = bool(pin_memory)               # not in the reference: frames land in page-locked memory (DevicePrefetcher uploads them without a bounce copy)
         self.n_classes = 19
         self.files = sorted(recursive_glob(rootdir=self.img_path, suffix=".png"))
         self.files_num = len(self.files)
@@ -75,7 +76,8 @@ class cityscapesLoader():
         img = img_u8 / 255.0
         img = (img - self.mean) / self.std
         img = img.transpose(2, 0, 1)[np.newaxis, :]
-        return torch.from_numpy(img).float()
+        t = torch.from_numpy(img).float()
+        return t.pin_memory() if self.pin_memory else t
 
     def load_frames(self):
         from PIL import Image
@@ -94,3 +96,105 @@ class cityscapesLoader():
         other = (temp < 0) | (temp >= self.n_classes)
         rgb[other] = temp[other][:, None]
         return rgb
+
+
+class DevicePrefetcher:
+    """Iterate `loader.data` items ([img [1,3,H,W] fp32 CPU, name, folder, size], dataloader.py:73) with the image ALREADY ON THE DEVICE:
+    the host->device copy of item i + 1 runs on a copy stream while the caller's stream computes item i.  Page-locked frames
+    (cityscapesLoader(..., pin_memory=True)) upload asynchronously; a pageable frame is staged by the HIP runtime while the host waits (still
+    under the device's previous frame; an own bounce copy into pinned memory was measured SLOWER than that: 106 against 149 frames/s).
+    The reference's loop (`image = image.to(device)`, test.py:47) is then a no-op and needs no change.  Not in the reference: its loop
+    uploads a pageable tensor synchronously (216 frames/s at 1024x2048 on MI355X against 255-270 this way, 274 with a resident clip;
+    tools/pcie_inclusive_probe.py).
+
+    `depth` (>= 2, default 3) device buffers, reused round-robin: work enqueued on the yielded tensor BEFORE the next `depth - 1` requests
+    is safe (the upload that overwrites it waits for an event recorded at that request); the frame loop's use (forward, then drop) fits,
+    clone() to keep a frame longer.  Three rather than two, so that the upload of item i + 1 -- issued when item i is requested -- goes
+    into the buffer of item i - 2, whose frame has long finished: a pageable upload then never makes the host wait for frame i - 1."""
+
+    def __init__(self, items, device, depth=3):
+        self.items, self.device, self.depth = list(items), torch.device(device), max(2, int(depth))
+        if self.device.type != "cuda":
+            raise ValueError("DevicePrefetcher stages frames for a GPU: device must be cuda")
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        if not self.items:
+            return
+        dev, D = self.device, self.depth
+        copy_s = torch.cuda.Stream(dev)
+        shape = tuple(self.items[0][0].shape)
+        on_dev = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(D)]
+        landed = [None] * D                                            # the upload into slot k has arrived (copy stream)
+        freed = [None] * D                                             # the consumer's stream has passed its last use of slot k
+
+        def upload(i):
+            k = i % D
+            img = self.items[i][0]
+            if tuple(img.shape) != shape:
+                raise RuntimeError("DevicePrefetcher: frame %d has shape %s, the stream's frames are %s" % (i, tuple(img.shape), shape))
+            with torch.cuda.stream(copy_s):
+                if freed[k] is not None:
+                    copy_s.wait_event(freed[k])                        # the DEVICE buffer: the consumer's last use of it is behind that event
+                on_dev[k].copy_(img, non_blocking=True)                # page-locked frame: asynchronous; pageable: HIP stages it, the host waits here
+                landed[k] = torch.cuda.Event()
+                landed[k].record(copy_s)
+
+        upload(0)
+        for i in range(len(self.items)):
+            if i >= 1:                                                 # the consumer asks for item i: its use of item i - 1 is enqueued
+                freed[(i - 1) % D] = torch.cuda.Event()
+                freed[(i - 1) % D].record(torch.cuda.current_stream(dev))
+            if i + 1 < len(self.items):
+                upload(i + 1)                                          # into the slot of item i + 1 - D
+            torch.cuda.current_stream(dev).wait_event(landed[i % D])
+            yield [on_dev[i % D]] + list(self.items[i][1:])
+
+
+class LabelDownloader:
+    """Device int32 label maps -> host numpy arrays through pinned memory, asynchronously: submit(labels, tag) enqueues the copy on a side
+    stream and returns the results that have ARRIVED meanwhile as [(tag, array)], in order; drain() waits for the rest.  The arrays are
+    VIEWS of the pinned buffers, valid until the next submit() / drain() call (copy what must live longer).  Replaces the
+    synchronous `output.max(1)[1].cpu().numpy()` of test.py:61 (a 16.8 MB int64 round trip per 1024x2048 frame) in a loop that wants the
+    device to keep running."""
+
+    def __init__(self, device, depth=3):
+        self.device, self.depth = torch.device(device), max(2, int(depth))
+        self.stream = torch.cuda.Stream(self.device)
+        self._slots, self._inflight, self._handed = [], [], []
+
+    def _collect(self, block):
+        self._slots.extend(self._handed)                              # the views handed out by the previous call expire now
+        self._handed = []
+        out = []
+        while self._inflight and (block or self._inflight[0][0].query()):
+            ev, buf, tag = self._inflight.pop(0)
+            ev.synchronize()
+            out.append((tag, buf.numpy()))
+            self._handed.append(buf)
+        return out
+
+    def submit(self, labels, tag=None):
+        done = self._collect(block=len(self._inflight) >= self.depth)
+        buf = None
+        for j, b in enumerate(self._slots):
+            if b.shape == labels.shape and b.dtype == labels.dtype:
+                buf = self._slots.pop(j)
+                break
+        if buf is None:
+            buf = torch.empty(labels.shape, dtype=labels.dtype).pin_memory()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            buf.copy_(labels, non_blocking=True)
+            labels.record_stream(self.stream)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._inflight.append((ev, buf, tag))
+        return done
+
+    def drain(self):
+        return self._collect(block=True)

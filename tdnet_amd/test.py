@@ -25,7 +25,7 @@ def test(args):
     from tdnet_amd.model import td2_psp50, td4_psp18
     device = torch.device("cuda")
     H, W = (int(v) for v in args.in_size.lower().split("x"))
-    vid_seq = cityscapesLoader(img_path=args.img_path, in_size=(H, W))
+    vid_seq = cityscapesLoader(img_path=args.img_path, in_size=(H, W), pin_memory=getattr(args, "prefetch", False))
     vid_seq.load_frames()
     if args.model == "td4-psp18":
         path_num = 4
@@ -42,8 +42,42 @@ def test(args):
         raise SystemExit("model must be one of td4-psp18, td2-psp50, td2-psp18, td2-psp34, psp101")
     model.eval()
     model.to(device)
+
+    def save(pred, img_name, folder, ori_size):
+        pred = np.squeeze(pred, axis=0).astype(np.int8)
+        # cv2.resize(pred, (W//4, H//4), INTER_NEAREST) (test.py:64): nearest sample at floor(dst * scale)
+        oh, ow = ori_size[1] // 4, ori_size[0] // 4
+        ys = np.minimum((np.arange(oh) * (pred.shape[0] / oh)).astype(np.int64), pred.shape[0] - 1)
+        xs = np.minimum((np.arange(ow) * (pred.shape[1] / ow)).astype(np.int64), pred.shape[1] - 1)
+        decoded = vid_seq.decode_segmap(pred[ys][:, xs])
+        save_dir = os.path.join(args.output_path, folder)
+        os.makedirs(save_dir, exist_ok=True)
+        from PIL import Image
+        Image.fromarray(decoded.astype(np.uint8)).save(os.path.join(save_dir, img_name))
+
     timer, i = 0.0, -1
     with torch.no_grad():
+        if args.prefetch:
+            # throughput loop (not in the reference): frame i + 1 is uploaded while frame i computes, the labels come back
+            # asynchronously as int32 (the full-resolution logits are never written), PNGs are written as they arrive
+            from tdnet_amd.dataloader import DevicePrefetcher, LabelDownloader
+            down = LabelDownloader(device)
+            torch.cuda.synchronize()
+            start_time = timeit.default_timer()
+            for i, (image, img_name, folder, ori_size) in enumerate(DevicePrefetcher(vid_seq.data, device)):
+                labels = model.forward_labels(image, pos_id=i % path_num)
+                for tag, pred in down.submit(labels, (img_name, folder, ori_size)):
+                    save(pred, *tag)
+            for tag, pred in down.drain():
+                save(pred, *tag)
+            torch.cuda.synchronize()
+            timer = timeit.default_timer() - start_time
+            print("---------------------")
+            print(" Model: {0:s}".format(args.model))
+            if i >= 0:
+                print(" {0:d} frames, prefetched upload + asynchronous labels: {1:3.5f} s per frame including the PNG writer".format(i + 1, timer / (i + 1)))
+            print("---------------------")
+            return
         for i, (image, img_name, folder, ori_size) in enumerate(vid_seq.data):
             image = image.to(device)
             torch.cuda.synchronize()
@@ -53,16 +87,7 @@ def test(args):
             elapsed_time = timeit.default_timer() - start_time
             if i > 5:
                 timer += elapsed_time
-            pred = np.squeeze(output.data.max(1)[1].cpu().numpy(), axis=0).astype(np.int8)
-            # cv2.resize(pred, (W//4, H//4), INTER_NEAREST) (test.py:64): nearest sample at floor(dst * scale)
-            oh, ow = ori_size[1] // 4, ori_size[0] // 4
-            ys = np.minimum((np.arange(oh) * (pred.shape[0] / oh)).astype(np.int64), pred.shape[0] - 1)
-            xs = np.minimum((np.arange(ow) * (pred.shape[1] / ow)).astype(np.int64), pred.shape[1] - 1)
-            decoded = vid_seq.decode_segmap(pred[ys][:, xs])
-            save_dir = os.path.join(args.output_path, folder)
-            os.makedirs(save_dir, exist_ok=True)
-            from PIL import Image
-            Image.fromarray(decoded.astype(np.uint8)).save(os.path.join(save_dir, img_name))
+            save(output.data.max(1)[1].cpu().numpy(), img_name, folder, ori_size)
             print(" Frame {0:2d}   RunningTime/Latency={1:3.5f} s".format(i + 1, elapsed_time))
     print("---------------------")
     print(" Model: {0:s}".format(args.model))
@@ -82,4 +107,5 @@ if __name__ == "__main__":
     parser.add_argument("--model", nargs="?", type=str, default="td4-psp18", help="model in [td4-psp18, td2-psp50, td2-psp18, td2-psp34]")
     parser.add_argument("--in_size", nargs="?", type=str, default="769x1537", help="HxW fed to the network (test.py:24)")
     parser.add_argument("--synthetic_seed", nargs="?", type=int, default=None, help="run on seeded synthetic weights")
+    parser.add_argument("--prefetch", action="store_true", help="throughput loop: upload of the next frame under the current one, asynchronous label download")
     test(parser.parse_args())
