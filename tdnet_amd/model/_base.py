@@ -302,6 +302,7 @@ class _TDNetBase(nn.Module):
             if e is not None:
                 e.reset()
         self._batch = None
+        self._pending_shape = None                                     # a frame encoded but not propagated is dropped with the FIFO (tdnet_reset)
 
     @property
     def engine(self):

@@ -315,9 +315,28 @@ class FramePipelinedStream:
             for s in self._lanes[1:]:
                 cur.wait_stream(s)
 
+    def reset(self):
+        """Empty both FIFOs (a new clip) and forget the rounds in flight; the lanes are joined first."""
+        self.join()
+        torch.cuda.current_stream(self.device).synchronize()
+        for st in self.stages:
+            st.reset()
+        self._done = [[None] * self.W, [None] * self.W]
+
     def process(self, frames, labels=False, first_frame=0, join=True):
         """frames: consecutive frames of the stream ([1,3,H,W] device tensors); frames[i] is frame first_frame + i.  Returns the list of
-        outputs in frame order (logits, or int32 labels)."""
+        outputs in frame order (logits, or int32 labels).  A frame that fails (wrong size, a kernel error) leaves the lanes' FIFOs in
+        different states: the stream is reset() -- as after the last frame of a clip -- and the exception re-raised."""
+        try:
+            return self._process(frames, labels, first_frame, join)
+        except Exception:
+            try:
+                self.reset()
+            except Exception:                                         # the original error is the one to report
+                pass
+            raise
+
+    def _process(self, frames, labels, first_frame, join):
         T, W = len(frames), self.W
         cur = torch.cuda.current_stream(self.device)
         lanes = self._lane_streams(cur)

@@ -105,3 +105,12 @@ def test_two_frames_in_flight_on_one_gpu_bit_identical(name, T):
         assert torch.equal(outs[t], ref[t]), (name, t, float((outs[t] - ref[t]).abs().max()))
     for i, lab in enumerate(labs):
         assert torch.equal(lab[0].long(), ref[T + 1 + i][0].max(0)[1]), (name, T + 1 + i)
+    # a failing frame (wrong size) resets the stream instead of leaving the two FIFOs in different states; the next clip runs as from new
+    with torch.no_grad():
+        with pytest.raises(Exception):
+            fp.process([frames[0], frames[1][:, :, :65]], first_frame=0)
+        assert a.engine.fifo_len() == b.engine.fifo_len() == 0
+        again = fp.process(frames[:3])
+        torch.cuda.synchronize()
+    for t in range(3):
+        assert torch.equal(again[t], ref[t]), (name, "after reset", t)
