@@ -329,7 +329,7 @@ struct tdnet {
     std::vector<float*> seg_t, seg_r, seg_x;
     // tdnet_opts.cu_reserve: the run on a partitioned chip -- part_g (GEMMs of both chains) on all but cu_reserve CUs, part_t (their
     // transforms) on the reserved ones; ev_in[c][i] / ev_g[c][i]: "input transform / GEMMs of chunk c of conv i done"
-    std::vector<hipStream_t> probe_streams;                            // TDNET_PROBE_EXTRA_STREAMS (probe only)
+    std::vector<hipStream_t> probe_streams;                            // TDNET_PROBE_EXTRA_STREAMS (-DTDNET_TIMING_PROBES builds only)
     std::vector<hipStream_t> retired_streams;                          // chain2 candidates that shared the caller's hardware queue (place_chain_stream)
     bool placed = false;
     void* placed_for = nullptr;                                        // the caller stream chain2 was checked against
@@ -860,12 +860,14 @@ extern "C" int tdnet_finalize_weights(tdnet_t* n) {
     n->sd.clear();
     if (alloc_workspace(n)) return -1;
     TD_HIP(hipDeviceSynchronize());
-    if (const char* e = getenv("TDNET_PROBE_EXTRA_STREAMS")) {          // probe only (tools/idle_handle_probe.py): shift this handle's queue placement
+#ifdef TDNET_TIMING_PROBES
+    if (const char* e = getenv("TDNET_PROBE_EXTRA_STREAMS")) {          // probe builds only: k extra streams before the handle's own shift its queue placement (DESIGN_experiments 8.4)
         for (int i = 0, k = atoi(e); i < k && i < 16; ++i) {
             hipStream_t x = nullptr;
             if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) == hipSuccess) n->probe_streams.push_back(x);
         }
     }
+#endif
     {   // The side stream carries the cache-only attention chain (0.6 ms of work beside 2.5 ms of backbone): lowest priority, so its
         // workgroups fill what the critical path leaves instead of taking CUs from it.
         int least = 0, greatest = 0;

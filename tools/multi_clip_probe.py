@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--precision", default="fp16")
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--clips", default="1,2,3,4")
+    ap.add_argument("--offset-us", type=float, default=0.0, help="delay the odd clips' streams once by this much before the timed loop (phase offset between the lanes)")
     ap.add_argument("--batched", action="store_true", help="ONE model fed [K, 3, H, W] batches (model/_base.py: sample i on its own handle and stream) "
                                                           "instead of K models on K caller streams")
     a = ap.parse_args()
@@ -57,7 +58,13 @@ def main():
             m = cls(nclass=19, path_num=P, model_path=None, backbone=a.backbone, kernel_opts=dict(opts)).eval().to(dev)
             m.load_state_dict(sd)
             models.append(m)
-        streams = [torch.cuda.Stream(dev) for _ in range(K)]
+        # which hardware queue a new stream lands on depends on how many streams the process has created (a lottery: the same K = 2 ran
+        # 1059 or 1445 frames/s): every stream is placed beside the ones taken so far with the library's spin-pair test
+        from tdnet_amd import _capi
+        from tdnet_amd.model._base import _TDNetBase
+        streams = []
+        for _ in range(K):
+            streams.append(_TDNetBase._stream_beside(streams, dev, _capi.lib()) if streams else torch.cuda.Stream(dev))
         with torch.no_grad():
             outs = [[] for _ in range(K)]
             for t in range(P + 2):                                     # replay from an empty FIFO: compared with the clip alone
@@ -74,6 +81,13 @@ def main():
                         models[c](clips[c][t % NF], pos_id=t % P)
                 t += 1
             torch.cuda.synchronize(dev)
+            if a.offset_us > 0 and K > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); torch.cuda._sleep(1000000); e1.record(); torch.cuda.synchronize(dev)
+                per_us = 1000000 / (e0.elapsed_time(e1) * 1e3)          # _sleep cycles per microsecond
+                for c in range(1, K, 2):
+                    with torch.cuda.stream(streams[c]):
+                        torch.cuda._sleep(int(a.offset_us * per_us))
             t0 = time.perf_counter()
             for _ in range(a.steps):
                 for c in range(K):
