@@ -587,7 +587,7 @@ def main():
         else:
             clip0 = clip if rank == 0 else [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, nchk, seed=100)]
             vec = []
-            model.reset()
+            fpl.reset() if fpl is not None else model.reset()            # (two frames in flight: both lanes' FIFOs)
             with torch.no_grad():
                 for t in range(nchk):
                     out = model(clip0[t % len(clip0)], pos_id=t % P)
@@ -595,6 +595,8 @@ def main():
                     my_labels.append(lab.to(torch.uint8))
                     vec += logits_digest(out, torch) + torch.bincount(lab.flatten(), minlength=19)[:19].tolist()
             model.reset()
+            if fpl is not None:
+                fpl.reset()
         v = torch.tensor(vec, dtype=torch.int64, device=dev)
         vmin, vmax = v.clone(), v.clone()
         dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
