@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--size", default="720x960")
     ap.add_argument("--precision", default="fp16")
     ap.add_argument("--rounds", type=int, default=60)
+    ap.add_argument("--lane-opts", default="", help="tdnet_opts of the two pipelined handles only, k=v,... (the single handle keeps the defaults)")
     a = ap.parse_args()
     import torch
     from tdnet_amd import arch, parallel, weights
@@ -34,8 +35,10 @@ def main():
     cls = td4_psp18.td4_psp18 if a.model == "td4" else td2_psp50.td2_psp50
     opts = {"precision": 1} if a.precision == "fp16" else {}
 
-    def make():
-        m = cls(nclass=19, path_num=P, model_path=None, backbone=a.backbone, kernel_opts=dict(opts)).eval().to(dev)
+    lane_opts = {k.strip(): int(v) for k, _, v in (p.partition("=") for p in a.lane_opts.split(",") if p.strip())}
+
+    def make(extra=None):
+        m = cls(nclass=19, path_num=P, model_path=None, backbone=a.backbone, kernel_opts=dict(opts, **(extra or {}))).eval().to(dev)
         m.load_state_dict(sd)
         return m
     n = 2 * a.rounds
@@ -54,7 +57,7 @@ def main():
         fps_one = n / (time.perf_counter() - t0)
         one.engine.close()
         del one
-        stages = [make(), make()]
+        stages = [make(lane_opts), make(lane_opts)]
         fp = parallel.FramePipelinedStream(stages, P, dev, (H, W))
         outs = fp.process([clip[t % NF] for t in range(P + 5)], first_frame=0)          # odd count: a short last round
         same = all(torch.equal(x, y) for x, y in zip(outs, ref))
@@ -72,7 +75,7 @@ def main():
         fps_two = n / (time.perf_counter() - t0)
     print("%s-psp%s %dx%d %s: one handle %.1f frames/s (host loop %.0f us/frame); two frames in flight %.1f frames/s (x %.3f; host loop %.0f us/frame); outputs %s" %
           (a.model, a.backbone[6:], H, W, a.precision, fps_one, host_one, fps_two, fps_two / fps_one, host_two,
-           "bit-identical to the single handle" if same else "DIFFER from the single handle"))
+           ("bit-identical to the single handle" if same else "DIFFER from the single handle") + ("" if not lane_opts else "  [lanes: %s]" % a.lane_opts)))
 
 
 if __name__ == "__main__":
