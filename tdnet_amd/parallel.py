@@ -278,7 +278,8 @@ class FramePipelinedStream:
     what the other lane takes from it); at 1024x2048, where a frame fills the chip, there is nothing to gain.
 
     `stages`: W model instances (tdnet_amd.model) loaded with the same state_dict.  The rounds of consecutive process() calls chain
-    without a host or device join in between when join=False; the caller's stream then has to wait (`join()`) before it reads outputs."""
+    without a host or device join in between when join=False; the caller's stream then has to wait (`join()`) before it reads outputs.
+    Lane 0 IS the caller's current stream: feed a stream from one HIP stream, and join() before moving to another."""
 
     def __init__(self, stages, path_num, device, frame_size):
         self.stages, self.P, self.device = list(stages), path_num, torch.device(device)

@@ -152,6 +152,16 @@ def test_model_classes_mirror_reference_api():
     assert "not.in.the.reference" in m2.state_dict()
 
 
+def test_streams_share_queue_argument_checks():
+    """include/tdnet.h tdnet_op_streams_share_queue: the two paths that need no device -- a NULL result pointer is an error with a message,
+    a stream compared with itself shares its queue by definition (the spin-pair test itself is exercised by the GPU batch tests)."""
+    lib = _capi.lib()
+    assert lib.tdnet_op_streams_share_queue(None, None, None) != 0
+    assert b"shared is NULL" in lib.tdnet_last_error()
+    shared = ctypes.c_int(0)
+    assert lib.tdnet_op_streams_share_queue(ctypes.c_void_p(64), ctypes.c_void_p(64), ctypes.byref(shared)) == 0 and shared.value == 1
+
+
 def test_the_package_caps_the_hardware_queues_before_the_runtime_starts():
     """tdnet_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 2 (a handle created behind an RCCL communicator otherwise runs at 0.67x) unless the
     environment already says otherwise; bench.py, conftest.py and __graft_entry__.py set it before they import torch."""
