@@ -1,0 +1,232 @@
+"""parallel.FramePipelinedStream without a GPU: its event / stream logic under a SCHEDULE SIMULATOR.
+
+The class only enqueues work: stage calls, event records, stream waits.  Here torch.cuda's streams and events are replaced by queues of
+deferred operations, the stages by a model of a handle (pending entry, FIFO of the last `depth` entries, output = function of the frame
+and of the FIFO it met), and the queued operations are then EXECUTED in many legal interleavings -- lane 0 as far ahead as its waits
+allow, lane 1 as far ahead, alternating, random.  Whatever the order, every output must be the sequential loop's (test.py:45-53) and
+both FIFOs must end in its state; an event wait that is missing (an entry pushed before its frame was encoded, an exchange row
+re-exported while a lane still reads it) shows up as a wrong output in the schedules that run one lane ahead."""
+import contextlib
+import random
+
+import pytest
+import torch
+
+from tdnet_amd import parallel
+
+
+class _Event:
+    def __init__(self, sim):
+        self.sim, self.done, self.recorded = sim, False, False
+
+    def record(self, stream=None):
+        stream = stream or self.sim.current
+        assert not self.recorded, "the class under test records an event once"
+        self.recorded = True
+        stream.ops.append(("record", self))
+
+    def synchronize(self):
+        self.sim.run_until(lambda: self.done)
+
+    def query(self):
+        return self.done
+
+
+class _Stream:
+    def __init__(self, sim, name):
+        self.sim, self.name, self.ops = sim, name, []
+        self.cuda_stream = id(self)
+
+    def wait_event(self, ev):
+        assert ev.recorded, "waiting for an event that was never recorded would not wait at all"
+        self.ops.append(("wait", ev))
+
+    def wait_stream(self, other):
+        ev = _Event(self.sim)
+        ev.record(other)
+        self.wait_event(ev)
+
+    def synchronize(self):
+        self.sim.run_until(lambda: not self.ops)
+
+
+class _Sim:
+    """Deferred execution of what the class enqueues; `policy` picks the next stream among those whose head operation can run."""
+
+    def __init__(self, policy, seed=0):
+        self.main = _Stream(self, "lane0")
+        self.current = self.main
+        self.streams = [self.main]
+        self.policy, self.rng = policy, random.Random(seed)
+
+    def new_stream(self):
+        s = _Stream(self, "lane%d" % len(self.streams))
+        self.streams.append(s)
+        return s
+
+    def enqueue(self, fn):
+        self.current.ops.append(("run", fn))
+
+    @contextlib.contextmanager
+    def stream_ctx(self, s):
+        prev, self.current = self.current, s
+        try:
+            yield
+        finally:
+            self.current = prev
+
+    def _runnable(self):
+        return [s for s in self.streams if s.ops and (s.ops[0][0] != "wait" or s.ops[0][1].done)]
+
+    def step(self):
+        ready = self._runnable()
+        if not ready:
+            assert not any(s.ops for s in self.streams), "deadlock: " + str([(s.name, s.ops[0][0]) for s in self.streams if s.ops])
+            return False
+        if self.policy == "random":
+            s = self.rng.choice(ready)
+        elif self.policy == "alternate":
+            s = ready[self.rng.randrange(len(ready))] if self.rng.random() < 0.2 else ready[0]
+            ready.reverse()
+        else:                                                         # "first:k" -- lane k as far ahead as its waits allow
+            k = int(self.policy.split(":")[1])
+            pref = [x for x in ready if x is self.streams[min(k, len(self.streams) - 1)]]
+            s = pref[0] if pref else ready[0]
+        kind, arg = s.ops.pop(0)
+        if kind == "run":
+            arg()
+        elif kind == "record":
+            arg.done = True
+        return True
+
+    def run_until(self, cond):
+        while not cond():
+            assert self.step(), "nothing left to run"
+
+    def drain(self):
+        while self.step():
+            pass
+
+
+class _Out:
+    def __init__(self):
+        self.value = None
+
+    def record_stream(self, s):
+        pass
+
+
+class _Stage:
+    """A handle as the split frame sees it: encode leaves an entry pending, propagate reads the FIFO and commits it, push appends a peer's."""
+
+    class _Eng:
+        lib = None
+
+    def __init__(self, sim, depth):
+        self.sim, self.depth, self.fifo, self.pending, self.engine = sim, depth, [], None, _Stage._Eng()
+
+    def cache_entry_numel_for(self, H, W):
+        return 2, 2, 3
+
+    def ensure_engine(self, H, W, device):
+        pass
+
+    def encode(self, frame, pos_id=0):
+        fid = int(frame)
+
+        def run():
+            assert self.pending is None, "a frame was encoded over a pending one"
+            self.pending = 1000.0 + fid                              # the entry's content: a function of the frame alone
+        self.sim.enqueue(run)
+
+    def cache_export(self, q, k, v):
+        def run():
+            q.fill_(self.pending); k.fill_(self.pending + 0.25); v.fill_(self.pending + 0.5)
+        self.sim.enqueue(run)
+
+    def cache_push(self, q, k, v):
+        def run():
+            e = float(q[0])
+            assert float(k[0]) == e + 0.25 and float(v[-1]) == e + 0.5, "an exchange row was read while it was being rewritten"
+            self.fifo = (self.fifo + [e])[-self.depth:]
+        self.sim.enqueue(run)
+
+    def propagate(self, labels=False):
+        out = _Out()
+
+        def run():
+            out.value = (self.pending, tuple(self.fifo))
+            self.fifo = (self.fifo + [self.pending])[-self.depth:]
+            self.pending = None
+        self.sim.enqueue(run)
+        return out
+
+    def reset(self):
+        self.fifo, self.pending = [], None
+
+
+def _sequential(T, depth, first=0):
+    fifo, outs = [], []
+    for t in range(first, first + T):
+        e = 1000.0 + t
+        outs.append((e, tuple(fifo)))
+        fifo = (fifo + [e])[-depth:]
+    return outs, fifo
+
+
+@pytest.fixture
+def sim_env(monkeypatch):
+    def make(policy, seed):
+        sim = _Sim(policy, seed)
+        monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: sim.current)
+        monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: _Event(sim))
+        monkeypatch.setattr(torch.cuda, "stream", sim.stream_ctx)
+        from tdnet_amd.model import _base
+        monkeypatch.setattr(_base._TDNetBase, "_stream_beside", staticmethod(lambda taken, device, lib: sim.new_stream()))
+        return sim
+    return make
+
+
+@pytest.mark.parametrize("policy", ["first:0", "first:1", "alternate", "random"])
+@pytest.mark.parametrize("depth,P", [(1, 2), (3, 4)])
+def test_every_interleaving_gives_the_sequential_loop(sim_env, policy, depth, P):
+    for seed in range(6 if policy in ("random", "alternate") else 1):
+        sim = sim_env(policy, seed)
+        stages = [_Stage(sim, depth), _Stage(sim, depth)]
+        fp = parallel.FramePipelinedStream(stages, P, "cpu", (33, 65))
+        # three calls without a join in between: an odd count (short last round), a single frame, an even run; then a joined call
+        plan, t, outs = [7, 1, 10, 5], 0, []
+        for i, n in enumerate(plan):
+            outs += fp.process(list(range(t, t + n)), first_frame=t, join=(i == len(plan) - 1))
+            t += n
+            if seed % 2 == 0 and i == 1:
+                sim.drain()                                           # sometimes the device catches up between two calls
+        sim.drain()
+        want, fifo = _sequential(t, depth)
+        assert [o.value for o in outs] == want, (policy, seed)
+        assert stages[0].fifo == stages[1].fifo == fifo and stages[0].pending is None and stages[1].pending is None
+
+
+def test_the_simulator_catches_a_missing_wait(sim_env, monkeypatch):
+    """The checker must be able to fail: without the wait for the peer's encode event, a schedule that runs lane 1 ahead pushes an entry
+    that has not been exported yet."""
+    sim = sim_env("first:1", 0)
+    stages = [_Stage(sim, 1), _Stage(sim, 1)]
+    fp = parallel.FramePipelinedStream(stages, 2, "cpu", (33, 65))
+    real_wait = _Stream.wait_event
+    skipped = {"n": 0}
+
+    def leaky(self, ev):
+        if self is not sim.main and skipped["n"] < 50:               # lane 1 stops waiting for anything
+            skipped["n"] += 1
+            return
+        real_wait(self, ev)
+    monkeypatch.setattr(_Stream, "wait_event", leaky)
+    outs = fp.process(list(range(6)), join=False)
+    failed = False
+    try:
+        sim.drain()
+        failed = [o.value for o in outs] != _sequential(6, 1)[0]
+    except AssertionError:
+        failed = True
+    assert failed and skipped["n"] > 0
