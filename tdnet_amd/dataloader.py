@@ -120,13 +120,16 @@ class DevicePrefetcher:
     def __len__(self):
         return len(self.items)
 
+    def _device_buffer(self, shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
     def __iter__(self):
         if not self.items:
             return
         dev, D = self.device, self.depth
         copy_s = torch.cuda.Stream(dev)
         shape = tuple(self.items[0][0].shape)
-        on_dev = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(D)]
+        on_dev = [self._device_buffer(shape) for _ in range(D)]
         landed = [None] * D                                            # the upload into slot k has arrived (copy stream)
         freed = [None] * D                                             # the consumer's stream has passed its last use of slot k
 

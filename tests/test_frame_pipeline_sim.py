@@ -1,4 +1,4 @@
-"""parallel.FramePipelinedStream without a GPU: its event / stream logic under a SCHEDULE SIMULATOR.
+"""parallel.FramePipelinedStream (and dataloader.DevicePrefetcher) without a GPU: their event / stream logic under a SCHEDULE SIMULATOR.
 
 The class only enqueues work: stage calls, event records, stream waits.  Here torch.cuda's streams and events are replaced by queues of
 deferred operations, the stages by a model of a handle (pending entry, FIFO of the last `depth` entries, output = function of the frame
@@ -230,3 +230,37 @@ def test_the_simulator_catches_a_missing_wait(sim_env, monkeypatch):
     except AssertionError:
         failed = True
     assert failed and skipped["n"] > 0
+
+
+class _DevBuf:
+    """A device buffer of DevicePrefetcher: copy_ is an asynchronous upload on the stream that is current when it is issued."""
+
+    def __init__(self, sim):
+        self.sim, self.value = sim, None
+
+    def copy_(self, img, non_blocking=False):
+        v = float(img.flatten()[0])
+        self.sim.enqueue(lambda: setattr(self, "value", v))
+        return self
+
+
+@pytest.mark.parametrize("policy", ["first:0", "first:1", "alternate", "random"])
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_prefetcher_never_overwrites_a_frame_in_use(sim_env, monkeypatch, policy, depth):
+    """dataloader.DevicePrefetcher: the consumer's work on frame i (enqueued on its own stream when the frame is yielded) must see frame
+    i whatever the interleaving of the copy stream and the consumer's stream -- the copy stream far ahead (uploads want to overwrite
+    buffers still unread) and far behind (the consumer wants frames that have not landed)."""
+    from tdnet_amd import dataloader
+    for seed in range(4 if policy in ("random", "alternate") else 1):
+        sim = sim_env(policy, seed)
+        monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: sim.new_stream())
+        monkeypatch.setattr(dataloader.DevicePrefetcher, "_device_buffer", lambda self, shape: _DevBuf(sim))
+        items = [[torch.full((1, 3, 2, 2), float(i)), "f%d" % i, "vid", (2, 2)] for i in range(11)]
+        seen = []
+        for i, (buf, name, folder, size) in enumerate(dataloader.DevicePrefetcher(items, "cuda", depth=depth)):
+            assert name == "f%d" % i
+            sim.enqueue(lambda b=buf: seen.append(b.value))          # the consumer's frame: reads the buffer when it EXECUTES
+            if seed % 2 and i % 3 == 0:
+                sim.drain()
+        sim.drain()
+        assert seen == [float(i) for i in range(11)], (policy, depth, seed, seen)
