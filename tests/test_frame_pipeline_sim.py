@@ -264,3 +264,41 @@ def test_prefetcher_never_overwrites_a_frame_in_use(sim_env, monkeypatch, policy
                 sim.drain()
         sim.drain()
         assert seen == [float(i) for i in range(11)], (policy, depth, seed, seen)
+
+
+@pytest.mark.parametrize("policy", ["first:0", "first:1", "alternate", "random"])
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+def test_batch_lanes_wait_for_the_input_and_join_the_caller(sim_env, policy, N):
+    """model/_base.py _for_each_sample: the odd samples of a batch run on a second stream.  Whatever the interleaving, a sample must not
+    start before the caller's stream has produced the input, and what the caller enqueues AFTER forward() must find every sample done."""
+    from tdnet_amd.model._base import _TDNetBase
+    for seed in range(3):
+        sim = sim_env(policy, seed)
+        m = object.__new__(_TDNetBase)
+        m._extra_streams, m._extra_streams_for = [], None
+
+        class Eng:
+            lib = None
+        engines = [Eng() for _ in range(N)]
+        m._engines_for_batch = lambda img: engines
+        by_raw = lambda raw: next(s for s in sim.streams if s.cuda_stream == raw)
+        checked = []
+        for rep in range(3):                                          # the second stream is placed once and reused
+            st = {"input": False, "done": set()}                      # this batch's own state
+            sim.enqueue(lambda st=st: st.__setitem__("input", True))  # the caller's stream produces the batch
+
+            def call(i, eng, raw, st=st):
+                def run():
+                    assert st["input"], "sample %d started before the input was ready" % i
+                    st["done"].add(i)
+                by_raw(raw).ops.append(("run", run))
+            m._for_each_sample(torch.zeros(N, 3, 2, 2), call)
+
+            def after(st=st):
+                assert st["done"] == set(range(N)), "the caller's stream ran ahead of samples %s" % (set(range(N)) - st["done"])
+                checked.append(rep)
+            sim.enqueue(after)
+            if seed == 1:
+                sim.drain()
+        sim.drain()
+        assert len(checked) == 3 and len(sim.streams) == (1 if N == 1 else 2)
