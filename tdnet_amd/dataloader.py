@@ -168,6 +168,10 @@ class LabelDownloader:
         self.stream = torch.cuda.Stream(self.device)
         self._slots, self._inflight, self._handed = [], [], []
 
+    @staticmethod
+    def _host_buffer(shape, dtype):
+        return torch.empty(shape, dtype=dtype).pin_memory()
+
     def _collect(self, block):
         self._slots.extend(self._handed)                              # the views handed out by the previous call expire now
         self._handed = []
@@ -187,7 +191,7 @@ class LabelDownloader:
                 buf = self._slots.pop(j)
                 break
         if buf is None:
-            buf = torch.empty(labels.shape, dtype=labels.dtype).pin_memory()
+            buf = self._host_buffer(labels.shape, labels.dtype)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):

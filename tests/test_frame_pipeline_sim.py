@@ -302,3 +302,49 @@ def test_batch_lanes_wait_for_the_input_and_join_the_caller(sim_env, policy, N):
                 sim.drain()
         sim.drain()
         assert len(checked) == 3 and len(sim.streams) == (1 if N == 1 else 2)
+
+
+class _Labels:
+    """A device label map as LabelDownloader sees it."""
+    shape, dtype = (1, 2, 2), torch.int32
+
+    def __init__(self, sim, value):
+        self.sim, self.value = sim, None
+        sim.enqueue(lambda: setattr(self, "value", value))           # the frame's kernel writes it when the caller's stream gets there
+
+    def record_stream(self, s):
+        pass
+
+
+class _HostBuf:
+    shape, dtype = (1, 2, 2), torch.int32
+
+    def __init__(self, sim):
+        self.sim, self.value = sim, None
+
+    def copy_(self, labels, non_blocking=False):
+        self.sim.enqueue(lambda: setattr(self, "value", labels.value))
+        return self
+
+    def numpy(self):
+        return self.value
+
+
+@pytest.mark.parametrize("policy", ["first:0", "first:1", "alternate", "random"])
+def test_label_downloader_returns_every_map_once_and_in_order(sim_env, monkeypatch, policy):
+    """dataloader.LabelDownloader: the download of frame t must wait for frame t's kernel, results come back in order, exactly once, and
+    a pinned buffer is not reused for a new download while its previous content has not been handed to the caller."""
+    from tdnet_amd import dataloader
+    for seed in range(3):
+        sim = sim_env(policy, seed)
+        monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: sim.new_stream())
+        monkeypatch.setattr(dataloader.LabelDownloader, "_host_buffer", staticmethod(lambda shape, dtype: _HostBuf(sim)))
+        down = dataloader.LabelDownloader("cuda", depth=3)
+        got = []
+        for t in range(13):
+            for tag, arr in down.submit(_Labels(sim, 100 + t), t):
+                got.append((tag, arr))                                # consumed at once, as the contract asks
+            if seed == 1 and t % 4 == 0:
+                sim.drain()
+        got += [(tag, arr) for tag, arr in down.drain()]
+        assert got == [(t, 100 + t) for t in range(13)], (policy, seed, got)
