@@ -71,14 +71,11 @@ def parse_args(argv=None):
                     help="TEST ONLY: this rank scales one weight tensor by 1.001 after the broadcast; the N-rank line must then say "
                          "ranks_agree false and the run must exit non-zero (tests/test_bench_launch.py)")
     ap.add_argument("--conv-pipeline", type=int, default=None, help="tuning: 0 one-stage / 1 two-stage conv prefetch")
-    ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 1 Winograd F(2x2,3x3) for layers 3-4 + head, 3 F(4x4,3x3) for layers 2-4 + head (default: library default)")
+    ap.add_argument("--winograd", type=int, default=None, help="conv algorithm: 0 direct, 3 Winograd F(4x4,3x3) for layers 2-4 + head (default: library default), 4 F(4x4,3x3) for every stride-1 3x3")
     ap.add_argument("--attention", type=int, default=None, help="0 exact two-pass softmax, 1 single pass (lazily moved reference), 2 the same with one barrier per key tile (library default)")
-    ap.add_argument("--stagger", type=int, default=None, help="tuning: start delay of co-resident workgroups (tdnet_opts.stagger)")
     ap.add_argument("--fusion", type=int, default=None, help="bit mask of launch-level fusions (include/tdnet.h tdnet_opts.fusion)")
     ap.add_argument("--gemm-persistent", type=int, default=None, help="tuning: 1 persistent GEMM on a full wave of workgroups (default), 0 one tile per workgroup, n > 1 grid forced to n")
     ap.add_argument("--overlap", type=int, default=None, help="bit mask (include/tdnet.h tdnet_opts.overlap): 1 = layers 3-4 as two row-parity chains on two streams, 2 = low-register Winograd transforms everywhere, bits 4-5 = channels per lane")
-    ap.add_argument("--cu-reserve", type=int, default=None, help="tdnet_opts.cu_reserve: CUs reserved for the Winograd transforms of layers 3-4 (the GEMMs get the rest; 0 = off)")
-    ap.add_argument("--cu-mode", type=int, default=None, help="tdnet_opts.cu_mode (1 = transform stream unmasked, 2 = per-XCD mask layout)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16 MFMA, fp32 accumulate (BASELINE "
                          "config 5); parity vs the fp32 CPU path is gated at 3e-2 / 99.5 % of the labels / mIoU 0.99 (tests/test_gpu_fp16.py)")
@@ -300,7 +297,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
     if dom_n > 0 and dom_ms > 0:
         ach = dom_fl / (dom_ms * 1e-3) / 1e12
         leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> / k_conv_dma_h3n<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA; since round 4 incl. the 128-channel layers of small maps)" if precision == "fp16"
-                           else "k_gemm_dma<0> / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
+                           else "k_gemm_dma / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
                            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / (2 * P)}
     if cpu_frames > 0:
@@ -397,8 +394,8 @@ def main():
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
 
-    kopts = {"winograd": args.winograd, "pipeline": args.conv_pipeline, "attention": args.attention, "fusion": args.fusion, "stagger": args.stagger, "overlap": args.overlap, "gemm_persistent": args.gemm_persistent,
-             "cu_reserve": args.cu_reserve, "cu_mode": args.cu_mode, "precision": 1 if args.precision == "fp16" else None}
+    kopts = {"winograd": args.winograd, "pipeline": args.conv_pipeline, "attention": args.attention, "fusion": args.fusion, "overlap": args.overlap, "gemm_persistent": args.gemm_persistent,
+             "precision": 1 if args.precision == "fp16" else None}
     kopts = {k: v for k, v in kopts.items() if v is not None}
     if args.backbone is None:
         args.backbone = "resnet101" if args.model == "psp" else "resnet18"
@@ -665,8 +662,8 @@ def main():
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:
-                    gk, dom_regex = ("k_gemm_dma<0> (LDS-DMA-fed, tdnet_opts.overlap bit 8) / k_gemm_persistent<*,*,*,*,ROLE=1>",
-                                     r"k_gemm_dma<0>|k_gemm_persistent<\d+, \d+, \d+, \d+, 1>")
+                    gk, dom_regex = ("k_gemm_dma (LDS-DMA-fed, tdnet_opts.overlap bit 8) / k_gemm_persistent<*,*,*,*,ROLE=1>",
+                                     r"k_gemm_dma\(|k_gemm_persistent<\d+, \d+, \d+, \d+, 1>")
                 else:
                     gk, dom_regex = "k_conv_igemm<.,.,.,.,1> (batched)", r"k_conv_igemm<\d+, \d+, \d+, \d+, 1, false"
                 kname = (gk + ": the %d batched GEMMs of the Winograd F(%s,3x3) convs of layers %s + head, fp32 MFMA; FLOP = executed "
@@ -735,7 +732,7 @@ def main():
             psteps, pwarm = 4, P + 2
             child = ["--pmc-child", "--steps", str(psteps), "--warmup", str(pwarm), "--no-cpu-baseline", "--no-pmc", "--model", args.model,
                      "--backbone", args.backbone, "--size", args.size, "--precision", args.precision, "--clips-per-gpu", "1"]
-            for k_, v_ in (("--winograd", args.winograd), ("--conv-pipeline", args.conv_pipeline), ("--attention", args.attention), ("--fusion", args.fusion), ("--stagger", args.stagger), ("--overlap", args.overlap), ("--gemm-persistent", args.gemm_persistent), ("--cu-reserve", args.cu_reserve), ("--cu-mode", args.cu_mode)):
+            for k_, v_ in (("--winograd", args.winograd), ("--conv-pipeline", args.conv_pipeline), ("--attention", args.attention), ("--fusion", args.fusion), ("--overlap", args.overlap), ("--gemm-persistent", args.gemm_persistent)):
                 if v_ is not None:
                     child += [k_, str(v_)]
             per_launch, per_frame, detail = measure_traffic(child, dom_regex, psteps + pwarm)

@@ -11,7 +11,13 @@
  *   - every function returns 0 on success, <0 on error; tdnet_last_error() gives the message (thread-local).
  *   - "dev" pointers are device (HBM) pointers owned by the caller; the handle owns weights, workspace and
  *     the K/Q/V FIFO.  One handle per video stream and per GPU; a handle is not thread-safe.
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  The frame calls (tdnet_forward*, tdnet_encode,
+ *     tdnet_propagate*, tdnet_cache_*) only ENQUEUE work and never synchronise with the host -- with one exception a caller can
+ *     remove: a handle whose frame uses a second internal stream (row-parity chains) checks ONCE per caller stream that this stream
+ *     sits on another hardware queue than the caller's (two 40-us spin kernels, a host synchronisation of both streams).
+ *     tdnet_warmup(h, stream) does that check explicitly; a frame call on a stream tdnet_warmup has not seen does it lazily
+ *     (skipped while the stream is being captured into a hipGraph).  tdnet_finalize_weights, tdnet_create_shared, tdnet_get_stage
+ *     and the tdnet_op_* / tdnet_bench_* entries synchronise.
  *   - all tensors are fp32.  Image in / logits out are NCHW like the reference; internal layout is NHWC.
  */
 #ifndef TDNET_H
@@ -45,19 +51,17 @@ typedef struct tdnet_cfg {
                                        (profiles/r04j_*, r04x_*) */
 #define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
-    int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 1 = Winograd F(2x2,3x3) for the wide stride-1 3x3
-                                convs (Cin >= 256, Cout >= 128), 2 = F(2x2,3x3) for every stride-1 3x3 (test hook), 3 (default) =
-                                F(4x4,3x3) for the stride-1 3x3 convs with Cin, Cout >= 128 (ResNet layers 2-4 + FCN head), 4 = F(4x4,3x3)
-                                for every stride-1 3x3 (test hook).  All fp32.                                                    */
+    int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 3 (default) = Winograd F(4x4,3x3) for the stride-1 3x3
+                                convs with Cin, Cout >= 128 (ResNet layers 2-4 + FCN head), 4 = F(4x4,3x3) for every stride-1 3x3 (test
+                                hook).  All fp32.  (1, 2 were F(2x2,3x3), removed in round 5; they are read as 3, 4.)                  */
     int32_t precision;       /* 0 = fp32 MFMA (default; the only mode the 1e-3 logits gate applies to), 1 = fp16 MFMA with fp32
                                 accumulation (BASELINE config 5)                                                                 */
     int32_t pipeline;        /* conv software pipeline: 0 = one-stage prefetch, 1 (default) = two-stage                           */
     int32_t gemm_persistent; /* 1 (default) = stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel,
                                 0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */
-    int32_t stagger;         /* start delay (x512 cycles, 0 = off) of every odd group of 256 conv workgroups                      */
+    int32_t reserved0;       /* must be 0 (rounds 1-4: `stagger`, a start delay of co-resident workgroups; measured neutral, removed) */
     int32_t attention;       /* 0 = exact two-pass softmax (row maxima first), 1 = single pass, lazily moved reference, 2 (default) = the same pipelined to one barrier per key tile        */
-    int32_t fusion;          /* bit mask of launch-level fusions / overlaps, each measured on its own; default 2|4|32 = the three
-                                that pay on MI355X (1, 8, 16 measured neutral to slightly negative and stay off):
+    int32_t fusion;          /* bit mask of launch-level fusions / overlaps, each measured on its own; default 2|4|32 (+ 8192|32768 in fp16 mode):
                                 1 = Encoding's q / k projections (w_qs, w_ks: small, latency-bound) on the side stream beside w_vs,
                                 2 = LayerNorm strip statistics written by the attention epilogue (no separate pass over the map),
                                 4 = LayerNorm normalisation applied inside the head's Winograd input transform (no `ln` map in HBM),
@@ -75,42 +79,26 @@ typedef struct tdnet_opts {
                                 1024 = precision 1 only: no 256 x 256 tiles in the LDS-DMA conv kernel (A/B),
                                 2048 = precision 1 only: the LDS-DMA conv stages its activation operand tap by tap (k_conv_dma_h) instead of
                                      one LDS image per kernel row shared by the row's three taps (k_conv_dma_h3) -- A/B,
-                                4096 = precision 1 only: the 64 -> 64-channel 3x3 convs (ResNet layer1) on persistent workgroups with the weights
-                                     resident in LDS (k_conv_dma_w64; measured no faster than the per-tile kernel: one wave per SIMD),
+                                4096 = (removed in round 5, ignored: layer1 on persistent workgroups with the weights resident in LDS; no faster),
                                 8192 = precision 1 only (default): the 128 / 192 x 128 tiles of the LDS-DMA conv with four dedicated LOADER waves per
                                      workgroup (k_conv_dma_h3p: the matrix waves never issue vector memory inside the K loop); bit-identical,
                                 32768 = precision 1 only (default): on maps of <= 16384 output pixels the 3x3 "same" convs with <= 256 output channels run on
                                      NARROW tiles (128 / 192 rows x 64 channels, k_conv_dma_h3n: half the weight bytes per K step and CU); bit-identical.
-                                     (16384 was an experiment removed in round 4 -- loader / matrix waves handing buffers over through LDS flags,
-                                     slower -- and is ignored.)                                                                              */
-    int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), only with winograd >= 3 on BasicBlock backbones:
-                                1 = the trailing run of even-dilation Winograd convs (ResNet layers 3-4: resnet.py:181-198) is split into its
+                                     (16384 was an experiment removed in round 4 and is ignored.)                                          */
+    int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
+                                1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent
-                                    chains -- on two HIP streams: the HBM-bound transforms of one chain run under the MFMA-bound GEMMs of
-                                    the other (low-register transform kernels that fit beside three resident GEMM workgroups per CU),
+                                    chains -- on two HIP streams.  fp32 (winograd >= 3): the HBM-bound transforms of one chain run under the
+                                    MFMA-bound GEMMs of the other,
                                 2 = the low-register transform kernels for every F(4x4) conv, chained or not,
-                                4 = with bit 1: the second chain starts half a conv late (when the first chain's first input transform is
-                                    done), so that one chain's transforms meet the other's GEMMs instead of its transforms,
                                 8 = the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h: no staging registers, 82 VGPRs),
-                                64 = with bits 1 and 8: the transforms of layer4 ride INSIDE the other chain's GEMM launches, in the instruction
-                                     stream of its matrix waves, everything on one stream (td_gemm_dma.h TT = 1 / 2).  Measured: -4 %; the fp32
-                                     MFMA leaves its SIMD no VALU issue to spare.  Opt-in experiment,
-                                128 = the cache-only attention chain of the NEXT frame (it needs only cached entries) is launched at the end of
-                                      this frame, beside the HBM-bound LayerNorm / head / classifier / upsample, assuming pos_id + 1 on an
-                                      untouched FIFO (checked at the next call; otherwise the chain is launched again as before),
-                                bits 4-5 = channels per lane of those kernels: 0 -> 1, 1 -> 2, 2 -> 4                                       */
-    int32_t cu_reserve;      /* > 0, with overlap bit 1: the chip is PARTITIONED for the run of row-parity convs (round 4).  The Winograd GEMMs of both
-                                chains go to one HIP stream whose queue is restricted (hipExtStreamCreateWithCUMask) to all but `cu_reserve` CUs,
-                                the HBM-bound transforms of both chains to a second stream restricted to the reserved CUs (cu_reserve / 8 per
-                                XCD), software-pipelined with events: out(E,i), in(E,i+1) run while G(O,i) holds the matrix pipes, and so on.  The
-                                workgroup dispatcher does not admit a kernel that ARRIVES beside a persistent one; two queues
-                                with disjoint CU sets do not need it to.  0 (default) = off; a multiple of 8 in 8..128                        */
-    int32_t cu_mode;         /* bits, with cu_reserve: 1 = the transform stream is NOT masked (may also use what the GEMM leaves),
-                                2 = mask words laid out per XCD (bits [32 x, 32 x + cu_reserve / 8) of XCD x) instead of the low cu_reserve bits
-                                    (the driver interleaves mask bit i onto XCD i mod 8; tools/cu_mask_probe.hip checks which holds),
-                                4 = diagnostic: the same event-ordered pipeline on two PLAIN streams (no CU masks at all)                          */
-    int32_t reserved[6];     /* must be 0                                                                                        */
+                                bits 4-5 = channels per lane of the chunked transform kernels: 0 -> 1, 1 -> 2, 2 -> 4.
+                                (4 = staggered start of the second chain, 64 = transforms riding inside the other chain's GEMM launches,
+                                 128 = the next frame's cache-only chain launched at the end of this one: measured neutral to negative in
+                                 rounds 3-4, removed in round 5 and ignored; DESIGN_experiments.md 4.1d, 8.)                                  */
+    int32_t reserved[8];     /* must be 0 (rounds 4: cu_reserve / cu_mode, the CU-mask-partitioned pipeline, -2.5x, removed)       */
 } tdnet_opts;
+#define TDNET_OVERLAP_MASK 0x3b    /* the bits of tdnet_opts.overlap that exist: 1 | 2 | 8 | 16 | 32 */
 void tdnet_opts_default(tdnet_opts* o);
 
 /* ---- lifecycle: replaces the nn.Module constructor + load_state_dict (td4_psp18.py:32-120, :232-240) ---------- */
@@ -123,8 +111,21 @@ void tdnet_destroy(tdnet_t* h);
  * data in the reference's own layout (conv OIHW).  Unknown names and wrong sizes are errors (strict=True,
  * td4_psp18.py:237); unused reference tensors (pretrainedN.fc.*, *.num_batches_tracked) are accepted and ignored. */
 int  tdnet_set_weight(tdnet_t* h, const char* name, const float* host, size_t count);
-/* Folds BN (fp64), repacks to the kernels' layouts, uploads.  Fails listing the first missing tensor.            */
+/* Folds BN (fp64), repacks to the kernels' layouts, uploads; then allocates the handle's workspace, FIFO and streams.
+ * Fails listing the first missing tensor.  Synchronises the device.                                               */
 int  tdnet_finalize_weights(tdnet_t* h);
+/* A further handle on the SAME weight block as `weights_of` (which must be finalized): own workspace, own K/Q/V FIFO, own
+ * streams -- another video stream on this GPU, the samples 1..N-1 of a batch (the reference's batch shares one nn.Module's
+ * parameters: td4_psp18.py:216-229), or the second lane of a frame-pipelined clip -- without a second copy of the packed weights
+ * and without folding / packing / uploading them again.  `opts` must be NULL (inherit) or equal to the block's options: the
+ * packing depends on them.  The block is reference-counted: handles may be destroyed in any order, the weights go with the last. */
+int  tdnet_create_shared(const tdnet_t* weights_of, const tdnet_opts* opts /* NULL = inherit */, tdnet_t** out);
+/* One-time placement of the handle's internal streams for frames that will arrive on `stream` (see "Conventions"): host-
+ * synchronising, idempotent per stream.  Call it before capturing frames into a hipGraph or before a latency-critical first frame. */
+int  tdnet_warmup(tdnet_t* h, void* stream);
+/* HBM held by the weight block (*weights_bytes, shared) and by this handle alone (*handle_bytes: workspace + FIFO).  Returns the
+ * number of handles currently sharing the block, <0 on error.                                                             */
+int  tdnet_memory_bytes(const tdnet_t* h, size_t* weights_bytes, size_t* handle_bytes);
 
 /* ---- the hot path: replaces model(image, pos_id) (td4_psp18.py:216-229 / td2_psp50.py:146-155) ---------------- */
 /* img_nchw_dev [1,3,H,W] -> logits_nchw_dev [1,nclass,H,W].  Mutates the K/Q/V FIFO exactly like
@@ -172,6 +173,9 @@ double tdnet_last_ms(const tdnet_t* h, int which);
 /* same selection: summed algorithmic FLOP / number of launches of that family in the last forward.              */
 double tdnet_last_flops(const tdnet_t* h, int which);
 double tdnet_last_launches(const tdnet_t* h, int which);
+/* Kernel launches the last tdnet_forward* / tdnet_encode of this handle enqueued (all streams; device copies included: none in a
+ * steady-state frame).  Counted in the launch macro itself, profiling on or off.                                      */
+int    tdnet_last_launch_count(const tdnet_t* h);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of
  * `iters` launches of one conv configuration (random data, tile as in tdnet_op_conv2d).                             */

@@ -21,12 +21,11 @@ class TdnetCfg(ctypes.Structure):
 class TdnetOpts(ctypes.Structure):
     """include/tdnet.h tdnet_opts: per-handle kernel configuration (nothing in the library is process-wide)."""
     _fields_ = [("winograd", ctypes.c_int32), ("precision", ctypes.c_int32), ("pipeline", ctypes.c_int32),
-                ("gemm_persistent", ctypes.c_int32), ("stagger", ctypes.c_int32), ("attention", ctypes.c_int32),
-                ("fusion", ctypes.c_int32), ("overlap", ctypes.c_int32), ("cu_reserve", ctypes.c_int32), ("cu_mode", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 6)]
+                ("gemm_persistent", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("attention", ctypes.c_int32),
+                ("fusion", ctypes.c_int32), ("overlap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
 
 class TdnetError(RuntimeError):
@@ -45,6 +44,10 @@ SYMBOLS = {
     "tdnet_destroy": (None, [c_void_p]),
     "tdnet_set_weight": (ctypes.c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.c_size_t]),
     "tdnet_finalize_weights": (ctypes.c_int, [c_void_p]),
+    "tdnet_create_shared": (ctypes.c_int, [c_void_p, c_opts_p, ctypes.POINTER(c_void_p)]),
+    "tdnet_warmup": (ctypes.c_int, [c_void_p, c_void_p]),
+    "tdnet_memory_bytes": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "tdnet_last_launch_count": (ctypes.c_int, [c_void_p]),
     "tdnet_forward": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
     "tdnet_argmax": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_forward_labels": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
@@ -109,7 +112,7 @@ class Lib:
         o = TdnetOpts()
         self.tdnet_opts_default(ctypes.byref(o))
         for k, v in kw.items():
-            if k not in dict(TdnetOpts._fields_) or k == "reserved":
+            if k not in dict(TdnetOpts._fields_) or k.startswith("reserved"):
                 raise TypeError("unknown tdnet_opts field %r" % k)
             if v is not None:
                 setattr(o, k, int(v))

@@ -42,7 +42,6 @@ struct ConvArgs {
     int nsteps;           // (Cin/32)*KS*KS, STEM: ceil(KS*KS/8)
     int act;              // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
     int tiles_n;          // CoutPad / BN
-    int stagger;          // start delay of every odd group of 256 workgroups, in units of 512 cycles (see k_conv_igemm)
     int nbatch;           // > 1: batched 1x1 GEMMs (Winograd), see k_conv_igemm
 };
 
@@ -229,14 +228,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm(ConvArgs p) {
     const int lin = td_xcd_remap(bid_in_batch, nblk);
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // De-phase the workgroups that share a CU.  All workgroups of a launch start together and run identical K loops, so
-    // two co-resident groups reach their barriers and load bursts at the same time and the MFMA pipe idles in both at once;
-    // the probe shows the first "round" of a launch running 15 % slower than later, naturally staggered rounds.  Groups
-    // b and b+256 land on the same CU in the first round (XCD = b%8, round-robin over its 32 CUs), so every odd group of
-    // 256 sleeps about half a K step (p.stagger x 512 cycles) once; the offset then persists (identical periods).
-    if ((blockIdx.x >> 8) & 1)
-        for (int i = 0; i < p.stagger; ++i) TD_SLEEP(8);               // 8 x 64 = 512 cycles per unit
 
     // ---- per-thread gather geometry: slot i -> row (tid>>3) + 32 i, k-group tid&7 ------------------------------
     const int a_row = tid >> 3, a_kq = tid & 7;

@@ -151,8 +151,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    if ((blockIdx.x >> 8) & 1)
-        for (int i = 0; i < p.stagger; ++i) TD_SLEEP(2);               // de-phase co-resident workgroups (td_conv.h); steps are 4x shorter here
 
     const int a_row = tid >> 3, a_kq = tid & 7;         // slot i -> row a_row + 32 i, channels a_kq*8 .. +7 of the 64-channel chunk
     int a_by[AL], a_bx[AL];

@@ -42,7 +42,6 @@ enum ConvDmaCode {
     CD_256_EARLY = 13,    // row-image kernel, 256 rows: four weight buffers, data lands one step early
     CD_192_EARLY = 14,    // ... 192 rows
     CD_128_EARLY = 15,    // ... 128 rows
-    CD_W64 = 16,          // 64 -> 64 channels: persistent workgroups, weights resident in LDS (k_conv_dma_w64)
     CD_128_P = 17,        // row-image kernel with four dedicated loader waves (k_conv_dma_h3p): 128 rows, eight matrix waves of 32 x 64
     CD_192_P = 18,        // ... 192 rows, six matrix waves of 64 x 64
     CD_256_P = 19,        // ... 256 rows, eight matrix waves of 64 x 64
@@ -934,201 +933,9 @@ static inline bool conv_launch_dma3n(ConvArgs a, int rh, int KS, bool out16, hip
     }
 }
 
-// ---- 64 -> 64 channels (ResNet layer1): the WEIGHTS stay in LDS, the workgroup walks its tiles ------------------------------------------
-// A 3x3 conv with 64 input and <= 64 output channels has 9 K steps and 72 KB of packed weights: a workgroup per 128 x 64 tile spent its
-// life in prologue and epilogue (25 us at 1024x2048 for 10 us of HBM traffic), re-fetching the same weights 1024 times.  Here a
-// persistent workgroup per CU loads the weights ONCE (72 DMA pieces), then streams row images (k_conv_dma_h3's layout: one image per
-// kernel row, three taps each) of its tiles through a ring of four LDS buffers, three images ahead -- across tile boundaries, so the
-// epilogue of a tile runs with the next tile's images already landing.  Four waves of 32 x 64; 24 MFMAs per wave and image.
-// MEASURED (profiles/r03x_*): 22.3 us against 22.9 for the per-tile kernel at 1024x2048, 13.3 against 13.0 at 720x960 -- no gain, with or
-// without a residual, with the epilogue's loads hoisted or not.  The 152 KB of LDS leave one workgroup = ONE wave per SIMD on the CU:
-// its DMA issue, fragment reads, MFMAs and barrier are a serial chain (~1.6 us per image), where the per-tile kernel has three workgroups
-// per CU covering each other.  Kept as an option (tdnet_opts.fusion bit 4096; tile code 30 of tdnet_op_conv2d_f16io) and tested.
-struct ConvDmaWGeom {
-    static constexpr int BM = 128, NW = 4, NAP = 5, CAP = NAP * NW * 8, NIMG = 4;
-    static constexpr int W_BYTES = 9 * 8 * 64 * 16, IMG_BYTES = CAP * 128, LDS_BYTES = W_BYTES + NIMG * IMG_BYTES;
-    static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
-};
-template <int OUT16>
-TD_KERNEL void TD_LAUNCH_BOUNDS(256, 1) k_conv_dma_w64(ConvArgs p) {
-    using G = ConvDmaWGeom;
-    constexpr int NAP = G::NAP, NW = G::NW;
-    TD_DYN_LDS(smem);
-    char* const ibase = smem + G::W_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
-    const int half = lane >> 5, l31 = lane & 31;
-    const int d = p.dil, Wh = p.W + 2 * d;
-    const int S = G::BM + 2 * d * ((G::BM - 2) / p.W + 2);
-    const int ntiles = (p.M + G::BM - 1) / G::BM;
-    const int first = td_xcd_remap(blockIdx.x, gridDim.x), stride = gridDim.x;
-    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * 64u * 2u);
-    const TdBuf w_buf = td_make_buf(p.wp, (unsigned)G::W_BYTES);
-
-    // image pieces of a tile: piece j of this wave = slots 8 (wave + NW j) .. + 7 (k_conv_dma_h3's geometry, Cin = 64: one chunk)
-    unsigned a_base[NAP], a_ok[NAP];
-    auto tile_geometry = [&](int tile) {
-        const int m0 = tile * G::BM;
-        const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
-        const int gs0 = oy0 * Wh + ox0;
-#pragma unroll
-        for (int j = 0; j < NAP; ++j) {
-            const int sl = 8 * (wave + NW * j) + (lane >> 3);
-            const int gs = gs0 + sl;
-            const int r = gs / Wh, ix = gs - r * Wh - d;
-            const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * 64u + (unsigned)kq * 8u) * 2u;
-            const bool xok = (unsigned)ix < (unsigned)p.W && sl < S && tile < ntiles;
-            a_ok[j] = 0u;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
-        }
-    };
-    auto issue_image_piece = [&](int q, int ky, int j) {               // piece j of image q (kernel row ky of the tile whose geometry is loaded)
-        const int delta = ((ky - 1) * d * p.W) * 64 * 2;
-        const bool ok = ((a_ok[j] >> ky) & 1u) != 0u;
-        td_buf_ld16_lds(in_buf, ibase + (q & 3) * G::IMG_BYTES + (wave + NW * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
-    };
-    unsigned a_rd[3];                                                  // this lane's row in the image, taps kx = 0 .. 2, k-group `half`
-    auto tile_reads = [&](int tile) {
-        const int m0 = tile * G::BM;
-        const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
-        const int m = m0 + wave * 32 + l31;
-        const int oy = m / p.W, ox = m - oy * p.W;
-        const int sm = (oy - oy0) * Wh + ox - ox0;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int sl = sm + kx * d;
-            a_rd[kx] = (unsigned)(sl * 128 + ((half ^ ((sl >> 1) & 7)) << 4));
-        }
-    };
-    const unsigned b_rd = (unsigned)(half * 1024 + l31 * 16);          // weights in LDS: [tap][kq][64 slots][16 B]
-
-    // ---- epilogue state hoisted out of the tile loop: a vector-memory load inside it would make the compiler drain the DMA queue
-    // (s_waitcnt vmcnt(0)) once per tile.  Same arithmetic as td_store_acc_h's fast path (lane pairs exchange so that a lane owns 4
-    // consecutive channels of one row): out = act(acc + bias + resid).
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    const int N = p.Cout;
-    const bool fast = (N & 3) == 0 && ((((size_t)p.out) | ((size_t)p.resid)) & 15) == 0 && (size_t)(p.M + 128) * N < (1u << 29);   // wave-uniform
-    const int odd = l31 & 1, chan = 4 * (l31 >> 1);
-    const bool cok = chan < N;
-    const float slope = td_act_slope(p.act);
-    constexpr unsigned EO = OUT16 ? 2u : 4u;
-    const unsigned elems = (unsigned)p.M * (unsigned)N;
-    const TdBuf out_buf = td_make_buf(p.out, elems * EO);
-    const TdBuf res_buf = td_make_buf(p.resid, p.resid ? elems * 2u : 0u);
-    const bool has_res = p.resid != nullptr;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (fast) {
-        const TdBuf bias_buf = td_make_buf(p.bias, (unsigned)N * 4u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = td_buf_ld1(bias_buf, cok ? (unsigned)(chan + e) * 4u : TD_BUF_OOB, 0u);
-    }
-
-    // prologue: the weights (18 pieces per wave), the three images of the first tile
-#pragma unroll
-    for (int i = 0; i < 18; ++i) {
-        const int pc = wave + NW * i;
-        td_buf_ld16_lds(w_buf, smem + pc * 1024, (unsigned)(pc * 1024 + lane * 16), 0u);
-    }
-    tile_geometry(first);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int j = 0; j < NAP; ++j) issue_image_piece(ky, ky, j);
-    TD_WAIT_VM_PIECES(2 * NAP);                                        // weights and image 0 (and the bias)
-    TD_BARRIER_RAW();
-
-    int q = 0;
-    for (int tile = first; tile < ntiles; tile += stride) {
-        tile_reads(tile);
-        tile_geometry(tile + stride);                                   // the images issued during this tile are the next tile's (zero fill past the end)
-        f32x16 acc[1][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-        const unsigned e0 = (unsigned)(tile * G::BM + wave * 32 + 4 * half + odd) * (unsigned)N + (unsigned)chan;
-        const unsigned base_o = cok ? e0 * EO : TD_BUF_OOB, base_r = cok ? e0 * 2u : TD_BUF_OOB;
-        f32x2 rraw[8];                                                  // the tile's residual (fp16 x 4 per row pair), requested during its first image
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp) rraw[rp] = f32x2{0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky, ++q) {                           // unrolled: the compiler counts the loads between the residual request and its use
-            const char* img = ibase + (q & 3) * G::IMG_BYTES;
-            const char* wt = smem + ky * 3 * 8192;
-            f16x8 af[2], bf[2][2];
-            af[0] = *reinterpret_cast<const f16x8*>(img + a_rd[0]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const f16x8*>(wt + b_rd + j * 512);
-#pragma unroll
-            for (int s = 0; s < 12; ++s) {                              // s = 4 kx + g
-                const int cur = s & 1;
-                if (s < 11) {
-                    const int kx1 = (s + 1) >> 2, g1 = (s + 1) & 3;
-                    af[cur ^ 1] = *reinterpret_cast<const f16x8*>(img + (a_rd[kx1] ^ (unsigned)(g1 << 5)));
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[cur ^ 1][j] = *reinterpret_cast<const f16x8*>(wt + kx1 * 8192 + g1 * 2048 + b_rd + j * 512);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[0][j] = td_mfma32_f16(af[cur], bf[cur][j], acc[0][j]);
-                TD_SCHED_FENCE();
-                if ((s & 1) == 0 && (s >> 1) < NAP) issue_image_piece(q + 3, ky, s >> 1);
-                if (ky == 0 && s == 11 && fast && has_res) {
-#pragma unroll
-                    for (int rp = 0; rp < 8; ++rp) {
-                        const int r = 2 * rp;
-                        rraw[rp] = td_buf_ld2(res_buf, base_r + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)N * 2u, 0u);
-                    }
-                }
-                TD_SCHED_FENCE();
-            }
-            // image q + 1 has landed; q + 2, q + 3 and the tile's 8 residual loads may fly (loads retire in order; stores of the previous
-            // tile that are still outstanding only make this wait longer)
-            if (fast && has_res) TD_WAIT_VM_PIECES(2 * NAP + 8); else TD_WAIT_VM_PIECES(2 * NAP);
-            TD_BARRIER_RAW();
-        }
-        if (fast) {
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-                const int r = 2 * rp;
-                const float a0 = acc[0][0][r], a1 = acc[0][1][r], c0 = acc[0][0][r + 1], c1 = acc[0][1][r + 1];
-                const float x = td_swap1(odd ? a0 : c0), y = td_swap1(odd ? a1 : c1);
-                f32x4 v;
-                if (odd) { v[0] = x; v[1] = y; v[2] = c0; v[3] = c1; }
-                else     { v[0] = a0; v[1] = a1; v[2] = x; v[3] = y; }
-                const f16x4 rh = __builtin_bit_cast(f16x4, rraw[rp]);
-                f32x4 rv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rv[e] = (float)rh[e];
-                v = v + bv + rv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = td_activate(v[e], slope);
-                const unsigned rows = (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)N;
-                if (OUT16) {
-                    f16x4 oh;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) oh[e] = (_Float16)v[e];
-                    td_buf_st2(out_buf, base_o + rows * EO, 0u, __builtin_bit_cast(f32x2, oh));
-                } else td_buf_st4(out_buf, base_o + rows * EO, v);
-            }
-        } else {
-            td_store_acc_h<1, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, tile * G::BM + wave * 32, 0, lane);
-        }
-    }
-    TD_WAIT_VM_PIECES(0);
-}
-static inline bool conv_dma_w64_supports(int Cin, int Cout, int CoutPad, int KS, int stride, int dil, int pad) {
-    return Cin == 64 && Cout <= 64 && CoutPad == 64 && KS == 3 && stride == 1 && pad == dil;
-}
-// false = not launched (the halo of this map width / dilation does not fit the image buffer): the caller uses the per-tile kernel
-static inline bool conv_launch_dma_w64(const ConvArgs& a, bool out16, hipStream_t s) {
-    if (a.Wo != a.W || conv_dma3_slots(ConvDmaWGeom::BM, a.W, a.dil) > ConvDmaWGeom::CAP) return false;
-    const int ntiles = (a.M + ConvDmaWGeom::BM - 1) / ConvDmaWGeom::BM;
-    const int grid = ntiles < TD_CUS ? ntiles : TD_CUS;
-    if (out16) TD_LAUNCH((k_conv_dma_w64<1>), dim3(grid), dim3(256), ConvDmaWGeom::LDS_BYTES, s, a);
-    else TD_LAUNCH((k_conv_dma_w64<0>), dim3(grid), dim3(256), ConvDmaWGeom::LDS_BYTES, s, a);
-    return true;
-}
+// (Rounds 3-4 carried k_conv_dma_w64 here: 64 -> 64 channels on persistent workgroups with the weights resident in LDS -- 152 KB of LDS,
+// one wave per SIMD; measured no faster than the per-tile kernel (22.3 vs 22.9 us at 1024x2048, 13.3 vs 13.0 at 720x960, profiles/r03x_*).
+// Removed in round 5; last commit 78dfa5a.)
 
 // Tile for an output of M pixels x Cout channels: CD_256 / CD_192 / CD_128 (256 / 192 / 128 rows x 128 channels), CD_256x256 (needs CoutPad
 // % 256 == 0: the caller says so), or CD_NONE = leave the conv on the register-staged kernel with its 64 x 128 tiles (many small workgroups).

@@ -21,7 +21,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define TD_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
 // all LDS is dynamic and 16-byte aligned (cdna_hip_programming.md Guideline 17)
 #define TD_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#define TD_LAUNCH(kern, grid, block, lds, stream, ...) hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__)
+// every launch of the library goes through this macro and is counted (per host thread): a frame's launch count is a number on the bench line
+static thread_local long td_launch_count = 0;
+#define TD_LAUNCH(kern, grid, block, lds, stream, ...) do { ++td_launch_count; hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__); } while (0)
 
 // D(32x32) += A(32x2) * B(2x32).  lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // D register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].

@@ -25,7 +25,6 @@ struct GemmArgs {
     int nbatch, act;
     int tiles_m, tiles_n; // per batch
     int MP;               // rows between consecutive batches of a and out (>= M; padded planes of the Winograd workspaces, td_wino.h)
-    int stagger;          // tdnet_opts.stagger (units of 1/8 tile): start delay of the co-resident workgroups, see the kernel
     int wshare = 0;       // nbatch > 1 with ONE weight set and bias for all batches: a 1x1 conv over a strided set of image rows (batch = row,
                           // M = W pixels, MP = row pitch in pixels) -- the downsample conv of one row-parity chain (td_model.hip); resid must be null
 #ifdef TD_GEMM_TRACE      // tools/gemm_trace.hip only: per workgroup 64 x u64 -- HW_ID, XCC_ID, start, then (end of K loop, end of epilogue) per tile
@@ -71,16 +70,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_persistent(GemmArgs p) {
     const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
     const int nsteps = p.K >> 5;
     if (my_tiles == 0) return;
-    // Optional (tdnet_opts.stagger, default 0): de-phase the workgroups that share a CU by a fraction of a TILE.  Workgroups b,
-    // b + 256, b + 512 land on the same CU; group j = b / 256 sleeps j * stagger/8 of a tile's MFMA time once.  Measured neutral:
-    // the groups drift apart on their own -- the SIMD issues the OLDER wave whenever several have an MFMA ready, so group 0 runs
-    // ~1.8x faster than group 2 -- and neither that, nor a dynamic tile list, nor s_setprio rotation changes the CU's aggregate
-    // rate (tools/gemm_trace.hip).
-    if (p.stagger > 0) {
-        const int j = (int)(blockIdx.x >> 8);
-        const int units = j * p.stagger * nsteps * (MT * NT * 16 * 64 / 8 / 64);   // (MFMA cycles of a tile per wave) / 8 per unit, in s_sleep(1) = 64 cycles
-        for (int i = 0; i < units; ++i) TD_SLEEP(1);
-    }
     const unsigned w_step_bytes = 8u * (unsigned)p.NPad * 16u;
     const unsigned a_bytes = (unsigned)p.M * (unsigned)p.K * 4u, w_bytes = (unsigned)nsteps * w_step_bytes;
 

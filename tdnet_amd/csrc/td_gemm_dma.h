@@ -1,22 +1,10 @@
-// td_gemm_dma.h -- the batched fp32-MFMA GEMM of the Winograd convs (td_gemm.h ROLE 1) with both operands fed by LDS-DMA, and
-// optionally Winograd transforms of OTHER data riding in the instruction stream of its matrix waves.
+// td_gemm_dma.h -- the batched fp32-MFMA GEMM of the Winograd convs (td_gemm.h ROLE 1) with both operands fed by LDS-DMA: no staging
+// registers (82 VGPRs, three workgroups per CU), +2.6 % in the frame over td_gemm.h (profiles/r03m_*).
 //
-// Why.  The transforms of a Winograd conv are HBM-bound, its GEMMs MFMA-bound, and on one stream they run in series:
-// 0.6 ms of a 3.7 ms frame with idle matrix pipes.  The workgroup dispatcher does not overlap them (a kernel that arrives while the
-// persistent GEMM holds the CUs is not admitted beside it), so the overlap has to be built INTO the GEMM's workgroups.  First attempt: a
-// fifth "rider" wave per workgroup doing transform units between the barriers (needs <= 96 VGPRs for three 5-wave workgroups per CU,
-// tools/occupancy_probe.hip; fed by DMA the GEMM needs 82).  Structure free (idle riders cost nothing), but a wave on a SIMD whose
-// matrix pipe is saturated gets ~1 VALU instruction per 26 cycles: 4.9 us per unit against a K step of 2.9 us, the rider paced the
-// barriers and every launch took the transform's stand-alone time longer (profiles/r03n_*).  A wave's OWN MFMA, though, leaves it ~13
-// issue slots per 64-cycle MFMA on paper, so the second attempt (this file, TT = 1 / 2) lets each MATRIX wave carry one transform unit at
-// a time: loads requested at the top of a K step, arithmetic and stores in the next step.  MEASURED (profiles/r03n_*): the same +22 us
-// per launch (GA 116, GB 71 us against 94 / 49 with the units disabled), and spreading the units evenly over the launch made it worse
-// (134 / 83: every step of every workgroup then has one late wave).  The cost is the transform's ~350 instructions per unit at ~22
-// cycles each wherever they run: the fp32 MFMA occupies its SIMD's issue port for its whole 64 cycles, and at 87 % matrix-pipe
-// utilisation a fifth of the cycles is all the VALU gets.  One channel per lane makes the transforms VALU-heavy (33 VALU per KB; the
-// stand-alone 4-channel kernels need 8 and are HBM-bound), and the 4-channel form does not fit the registers of a GEMM wave.  So on
-// this chip the transforms of an fp32 Winograd conv cannot hide under its own kind of GEMM: TT = 1 / 2 stay as a measured, opt-in
-// experiment (tdnet_opts.overlap bit 64); the default uses TT = 0, which is simply the faster GEMM (82 VGPRs, +2.6 % over td_gemm.h).
+// (Rounds 3-4 also carried two forms of this kernel in which Winograd transforms of OTHER data rode in a fifth wave / in the matrix
+// waves' own instruction stream -- TT = 1 / 2, tdnet_opts.overlap bit 64.  Measured -4 % in the frame: the fp32 MFMA occupies its SIMD's
+// issue port for its whole 64 cycles and leaves the VALU a fifth of them (DESIGN_experiments 4.1d, profiles/r03n_*).  Removed in round 5;
+// last commit with that code: 78dfa5a.)
 //
 //   out[b][m][n] = sum_k A[b][m][k] W[b][k][n]      (plain epilogue: bias, residual and activation belong to the output transform)
 //
@@ -30,23 +18,13 @@
 // issue: td_conv_hd.h), across tile boundaries (persistent tile list as in td_gemm.h); one bare barrier per step.
 #pragma once
 #include "td_gemm.h"
-#include "td_wino.h"
 
 struct GemmDmaGeom {
     static constexpr int BM = 64, BN = 128;
     static constexpr int A_BYTES = BM * 128, B_BYTES = 8 * BN * 16, BUF_BYTES = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF_BYTES;
 };
 
-// What rides in a launch: units [u0, u1) of an input transform OR of an output transform (td_wino.h WinoArgs of the chunk they belong
-// to; a unit = one (tile, 64-channel slice), one channel per lane).  Wave v of workgroup w takes the units 4 w + v, + 4 G, + 8 G, ...
-struct RiderArgs {
-    WinoArgs tin, tout;
-    int in_u0, in_u1, out_u0, out_u1;
-};
-
-// TT: 0 = GEMM only; 1 = units [in_u0, in_u1) of the input transform rw.tin ride along; 2 = units [out_u0, out_u1) of rw.tout
-template <int TT>
-TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p) {
     using G = GemmDmaGeom;
     TD_DYN_LDS(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = td_wave();
@@ -62,27 +40,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
     const int xcount = nq + (xcd < rem ? 1 : 0);
     const int my_tiles = q < xcount ? (xcount - q + G8 - 1) / G8 : 0;
 
-    // ---- the riding transform: this wave's units u_next, u_next + u_stride, ... ------------------------------------------------
-    WinoInRide ride_i;
-    WinoOutRide ride_o;
-    bool ride_pending = false;                                        // loads of a unit requested, not yet finished
-    const int u_stride = (int)gridDim.x * 4;
-    int u_next = (TT == 1 ? rw.in_u0 : rw.out_u0) + (int)blockIdx.x * 4 + wave;
-    const int u_end = TT == 1 ? rw.in_u1 : TT == 2 ? rw.out_u1 : 0;
-    auto ride_issue = [&]() {
-        if (TT == 0 || u_next >= u_end) return;                       // wave-uniform
-        if (TT == 1) td_wino4_in_issue(rw.tin, u_next, ride_i); else td_wino4_out_issue(rw.tout, u_next, ride_o);
-        u_next += u_stride;
-        ride_pending = true;
-    };
-    auto ride_finish = [&]() {
-        if (TT == 1) td_wino4_in_finish(rw.tin, ride_i); else if (TT == 2) td_wino4_out_finish(rw.tout, ride_o);
-        ride_pending = false;
-    };
-    if (my_tiles == 0) {                                              // no tile for this workgroup: its waves still do their units
-        while (TT && u_next < u_end) { ride_issue(); ride_finish(); }
-        return;
-    }
+    if (my_tiles == 0) return;
 
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
@@ -153,14 +111,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
             for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
     };
     // one K step on buffer `buf`; the six pieces of the next step go out after the MFMA half-groups (eight slots of four MFMAs)
-    auto compute = [&](int buf, int ibuf, auto with_ride) {
-        constexpr bool RIDE = TT != 0 && decltype(with_ride)::value;
+    auto compute = [&](int buf, int ibuf) {
         const char* base = smem + buf * G::BUF_BYTES;
         f32x4 af[2], bf[2][2];
-        // The riding unit's arithmetic and stores: independent of everything below.  Left to itself the compiler puts all ~350 of those
-        // instructions AHEAD of the step's first MFMA (the wave then reaches the barrier 2-3 k cycles late and paces its workgroup); the
-        // scheduling groups at the end of this block pin them BETWEEN the MFMAs, ten VALU and a store per MFMA.
-        if constexpr (RIDE) ride_finish();
         af[0] = *reinterpret_cast<const f32x4*>(base + a_rd[0]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(base + b_rd + j * 512);
@@ -177,26 +130,9 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
                 for (int s = 2 * h2; s < 2 * h2 + 2; ++s)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[0][j] = td_mfma32(af[g & 1][s], bf[g & 1][j][s], acc[0][j]);
-                if constexpr (!RIDE) TD_SCHED_FENCE();
+                TD_SCHED_FENCE();
                 if (2 * g + h2 < 6) issue_piece(ibuf, 2 * g + h2);
-                if constexpr (!RIDE) TD_SCHED_FENCE();
-            }
-        }
-        if constexpr (RIDE) {
-            TD_SCHED_GROUP(0x100, 3);                                 // the first fragments
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        TD_SCHED_GROUP(0x008, 1);                     // one MFMA ...
-                        TD_SCHED_GROUP(0x002, 10);                    // ... ten VALU of the riding unit in its shadow ...
-                        TD_SCHED_GROUP(0x040, 1);                     // ... and one of its stores
-                    }
-                    TD_SCHED_GROUP(0x020, 1);                         // the DMA piece of this half group
-                    if (h2 == 0 && g < 3) TD_SCHED_GROUP(0x100, 3);   // the next group's fragments
-                }
+                TD_SCHED_FENCE();
             }
         }
         issue_end();
@@ -213,21 +149,15 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_gemm_dma(GemmArgs p, RiderArgs rw) {
     int cb = 0;
     for (int t = 0; t < my_tiles; ++t) {
         for (int st = 0; st < nsteps; ++st) {
-            if (TT != 0 && ride_pending) compute(cb, cb ^ 1, std::true_type{});      // wave-uniform
-            else compute(cb, cb ^ 1, std::false_type{});
+            compute(cb, cb ^ 1);
             TD_WAIT_VM_PIECES(0);
             TD_BARRIER_RAW();
             cb ^= 1;
-            ride_issue();                                             // the next unit's loads: a whole K step ahead of their use
         }
         float* outb = p.out + (size_t)spos.b * p.MP * p.N;
         td_store_acc<1, 2, true, true>(acc, outb, p.bias, nullptr, p.M, p.N, 0, spos.tm * G::BM + wm * 32, spos.tn * G::BN + wn * 64, lane);
         zero_acc();
         advance(spos);
-    }
-    if (TT != 0) {                                                    // units left over when the tiles ran out (short launches): unhidden tail
-        if (ride_pending) ride_finish();
-        while (u_next < u_end) { ride_issue(); ride_finish(); }
     }
 }
 
@@ -235,9 +165,8 @@ static inline bool gemm_dma_supports(int K, int N, ConvTile tile) {
     const ConvTileDims d = conv_tile_dims(tile);                      // weights packed for a BN = 128 / two-wave-column tile
     return K % 32 == 0 && d.BN == 128 && d.WGN == 2 && N % 4 == 0;
 }
-// grid_cap > 0 forces the number of workgroups (tests); rw == nullptr: four waves, no rider
-// rw: one transform rides (its input OR its output units; a launch carries one kind); nullptr = GEMM only
-static inline void gemm_dma_launch(GemmArgs a, const RiderArgs* rw, int grid_cap, hipStream_t s) {
+// grid_cap > 0 forces the number of workgroups (tests)
+static inline void gemm_dma_launch(GemmArgs a, int grid_cap, hipStream_t s) {
     a.tiles_m = (a.M + 63) / 64;
     a.tiles_n = a.NPad / 128;
     const long total = (long)a.tiles_m * a.tiles_n * a.nbatch;
@@ -245,11 +174,5 @@ static inline void gemm_dma_launch(GemmArgs a, const RiderArgs* rw, int grid_cap
     if (grid > total) grid = total;
     // (A grid with the same number of tiles for every workgroup -- 576 instead of 768 for 1152 tiles -- measured 1 % SLOWER in the frame,
     // with and without the chains: 269.2 -> 266.5, 267.0 -> 264.9.  The half-empty last round overlaps the next launch's ramp.)
-    if (rw && rw->in_u1 > rw->in_u0) TD_LAUNCH((k_gemm_dma<1>), dim3((unsigned)grid), dim3(256), GemmDmaGeom::LDS_BYTES, s, a, *rw);
-    else if (rw && rw->out_u1 > rw->out_u0) TD_LAUNCH((k_gemm_dma<2>), dim3((unsigned)grid), dim3(256), GemmDmaGeom::LDS_BYTES, s, a, *rw);
-    else {
-        RiderArgs none;
-        none.in_u0 = none.in_u1 = none.out_u0 = none.out_u1 = 0;
-        TD_LAUNCH((k_gemm_dma<0>), dim3((unsigned)grid), dim3(256), GemmDmaGeom::LDS_BYTES, s, a, none);
-    }
+    TD_LAUNCH(k_gemm_dma, dim3((unsigned)grid), dim3(256), GemmDmaGeom::LDS_BYTES, s, a);
 }

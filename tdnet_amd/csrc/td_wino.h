@@ -1,10 +1,11 @@
-// td_wino.h -- Winograd F(2x2, 3x3) and F(4x4, 3x3) for the stride-1 dilated 3x3 convolutions of layers 3-4 and the head (fp32).
+// td_wino.h -- Winograd F(4x4, 3x3) for the stride-1 dilated 3x3 convolutions of layers 2-4 and the head (fp32).
 //
 // Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A  turns every m x m output tile into (m+2)^2 products per (ci, co) instead of
-// 9 m^2: 16 instead of 36 for m = 2 (2.25x fewer MACs), 36 instead of 144 for m = 4 (4x fewer).  The contraction becomes
-// (m+2)^2 independent [tiles x Cin] x [Cin x Cout] GEMMs on the persistent fp32-MFMA GEMM (td_gemm.h, nbatch = 16 / 36); the
-// input/output transforms are HBM-bound passes over V = [(m+2)^2][T][Cin] and M = [(m+2)^2][T][Cout], which are 4x / 2.25x the
-// size of the activation, so F(4x4) also moves 1.8x fewer transform bytes than F(2x2).
+// 9 m^2: 36 instead of 144 for m = 4 (4x fewer MACs).  The contraction becomes 36 independent [tiles x Cin] x [Cin x Cout] GEMMs on the
+// persistent fp32-MFMA GEMM (td_gemm.h / td_gemm_dma.h, nbatch = 36); the input/output transforms are HBM-bound passes over
+// V = [36][T][Cin] and M = [36][T][Cout], 2.25x the size of the activation.  (F(2x2): 16 products instead of 36, 4x the activation in
+// V / M -- rounds 1-4 carried it as tdnet_opts.winograd = 1 / 2; nothing routed to it since round 2 and it was removed in round 5,
+// last commit 78dfa5a.  Its numerics are still on record: tests/numerics_winograd.py)
 //
 // A conv with dilation d (resnet.py:32-37: 2, 4, 8, 16 here) is d*d independent dilation-1 convs on the sub-grids
 // {(py + d a, px + d b)}: a tile is (phase py, px; tile ty, tx) and its 4x4 input patch is read with stride d.
@@ -67,106 +68,6 @@ TD_DEV f32x4 td_wino_ld(const WinoArgs& p, const WinoBufs& w, int y, int x, int 
         z = (z - m4) * r4 * g + b;
     }
     return z;
-}
-
-// B^T d B for one 4x4 patch held as d[r][c] (each a float4 of channels)
-TD_DEV void td_wino_bt_d_b(const f32x4 (&d)[4][4], f32x4 (&v)[4][4]) {
-    f32x4 t[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {                                   // rows: B^T d
-        t[0][c] = d[0][c] - d[2][c];
-        t[1][c] = d[1][c] + d[2][c];
-        t[2][c] = d[2][c] - d[1][c];
-        t[3][c] = d[1][c] - d[3][c];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                                   // columns: (.) B
-        v[r][0] = t[r][0] - t[r][2];
-        v[r][1] = t[r][1] + t[r][2];
-        v[r][2] = t[r][2] - t[r][1];
-        v[r][3] = t[r][1] - t[r][3];
-    }
-}
-
-// thread = (tile, 4 channels); lanes run over channels (coalesced float4)
-TD_KERNEL void k_wino_in(WinoArgs p) {
-    const int CV = p.C >> 2;
-    const WinoBufs wb = td_wino_bufs(p);
-    const long total = (long)p.T * CV;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int t = (int)(i / CV);
-        const int tx = t % p.TX; t /= p.TX;
-        const int ty = t % p.TY; t /= p.TY;
-        const int px = t % p.dil, py = t / p.dil;
-        f32x4 d[4][4], v[4][4];
-        f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, r4 = m4;
-        if (p.ln_mean) { m4 = td_ld4(p.ln_mean + cv * 4); r4 = td_ld4(p.ln_rstd + cv * 4); }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = py + p.dil * (2 * ty - 1 + r);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[r][c] = td_wino_ld(p, wb, y, px + p.dil * (2 * tx - 1 + c), cv, m4, r4);
-        }
-        td_wino_bt_d_b(d, v);
-        const size_t tile = (size_t)(i / CV);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) td_st4(p.V + ((size_t)(r * 4 + c) * p.TP + tile) * p.C + cv * 4, v[r][c]);
-    }
-}
-
-// thread = (tile, 4 output channels): Y = A^T m A, + bias (+ residual), activation, scatter to the 2x2 output pixels
-TD_KERNEL void k_wino_out(WinoArgs p) {
-    const int CV = p.Cout >> 2;
-    const WinoBufs wb = td_wino_bufs(p);
-    const float slope = td_act_slope(p.act);
-    const long total = (long)p.T * CV;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        const size_t tile = (size_t)(i / CV);
-        int t = (int)tile;
-        const int tx = t % p.TX; t /= p.TX;
-        const int ty = t % p.TY; t /= p.TY;
-        const int px = t % p.dil, py = t / p.dil;
-        unsigned off[2][2];                                           // byte offsets of the 2x2 output pixels (out-of-range: dropped / zeros)
-        f32x4 rs[2][2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int y = py + p.dil * (2 * ty + r), x = px + p.dil * (2 * tx + c);
-                off[r][c] = (y < p.H && x < p.W) ? (((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.Cout + (unsigned)cv * 4u) * 4u : TD_BUF_OOB;
-                rs[r][c] = td_buf_ld4(wb.resid, off[r][c], 0u);      // requested before the 16 planes: everything in flight together
-            }
-        f32x4 m[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) m[r][c] = td_ld4(p.Mb + ((size_t)(r * 4 + c) * p.TP + tile) * p.Cout + cv * 4);
-        f32x4 s[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {                                // A^T m
-            s[0][c] = m[0][c] + m[1][c] + m[2][c];
-            s[1][c] = m[1][c] - m[2][c] - m[3][c];
-        }
-        const f32x4 b = td_ld4(p.bias + cv * 4);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            f32x4 o2[2];
-            o2[0] = s[r][0] + s[r][1] + s[r][2];                      // (.) A
-            o2[1] = s[r][1] - s[r][2] - s[r][3];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x4 o = o2[c] + b;
-                o = o + rs[r][c];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = td_activate(o[e], slope);
-                td_buf_st4(wb.out, off[r][c], o);
-            }
-        }
-    }
 }
 
 // ---- F(4x4, 3x3): interpolation points 0, +-1, +-2, inf (Lavin & Gray) -----------------------------------------------------
@@ -348,8 +249,8 @@ TD_DEV WinoTile td_wino_unit_tile(const WinoArgs& p, int slices, int wv) {
 }
 
 // One unit = one wave's work: (tile, slice of 64 VW channels) of the input transform.  `mid()` is called between the issue of the 36
-// patch loads and their first use: a no-op in the transform kernels; in the rider wave of k_gemm_dma (td_gemm_dma.h) it is the
-// workgroup's barrier, so that the loads are in flight while the wave waits there.
+// patch loads and their first use and again between the two 1-D passes: a no-op in the transform kernels (a hook the round-3 rider
+// experiment used to park the wave on its workgroup's barrier with the loads in flight).
 template <int VW, typename Mid>
 TD_DEV void td_wino4_in_unit(const WinoArgs& p, int wv, Mid&& mid) {
     typedef WinoVec<VW> X;
@@ -374,9 +275,9 @@ TD_DEV void td_wino4_in_unit(const WinoArgs& p, int wv, Mid&& mid) {
             const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;          // wave-uniform
             const unsigned pix = (unsigned)y * (unsigned)p.W + (unsigned)x;
             T z = X::ld(wb.in, ok ? coff : TD_BUF_OOB, ok ? pix * (unsigned)p.C * 4u : 0u);
-            if (p.ln_mean) {                                         // uniform; the arithmetic of td_wino_ld / k_ln_apply, same order (the head conv only:
+            if (p.ln_mean) {                                         // uniform; the arithmetic of td_wino_ld / k_ln_apply, same order (the head conv only)
                 const float g = td_buf_ld1(wb.g, ok ? 0u : TD_BUF_OOB, ok ? pix * 4u : 0u), b = td_buf_ld1(wb.b, ok ? 0u : TD_BUF_OOB, ok ? pix * 4u : 0u);
-                z = (z - m4) * r4 * g + b;                           // never on a rider wave, so waiting for the loads here costs nothing)
+                z = (z - m4) * r4 * g + b;
             }
             dd[c][r] = z;
         }
@@ -390,7 +291,7 @@ TD_DEV void td_wino4_in_unit(const WinoArgs& p, int wv, Mid&& mid) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
     }
-    mid();                                                            // (a rider splits a unit over two barrier intervals)
+    mid();
     const unsigned plane = (unsigned)p.TP * (unsigned)p.C * 4u;
     const TdBuf vb = td_make_buf(p.V, 36u * plane);
     const unsigned voff = (unsigned)w.tl * (unsigned)p.C * 4u;
@@ -464,110 +365,6 @@ TD_DEV void td_wino4_out_unit(const WinoArgs& p, int wv, Mid&& mid) {
     }
 }
 
-// ---- the same units in two halves, one channel per lane, for the transforms that ride in the MATRIX waves of k_gemm_dma (td_gemm_dma.h):
-// *_issue requests the unit's loads into a register block that stays live across a K step; *_finish -- a step later, the data long
-// landed -- does the arithmetic and the stores, straight-line VALU / VMEM work the compiler threads between the step's MFMAs.
-struct WinoInRide { float d[6][6]; int wv; };                         // [c][r]
-struct WinoOutRide { float m[6][6]; float b; int wv; };          // the 16 residual values are requested in *_finish (its first instructions): 16 fewer live registers across the step
-TD_DEV void td_wino4_in_issue(const WinoArgs& p, int wv, WinoInRide& st) {
-    const int slices = (p.C + 63) / 64;
-    const WinoTile w = td_wino_unit_tile(p, slices, wv);
-    const TdBuf inb = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.C * 4u);
-    const int c0 = w.sl * 64 + (int)(threadIdx.x & 63);
-    const unsigned coff = c0 < p.C ? (unsigned)c0 * 4u : TD_BUF_OOB;
-    st.wv = wv;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const int x = w.px + p.dil * (4 * w.tx - 1 + c);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const int y = w.py + p.dil * (4 * w.ty - 1 + r);
-            const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            st.d[c][r] = td_buf_ld1(inb, ok ? coff : TD_BUF_OOB, ok ? ((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.C * 4u : 0u);
-        }
-    }
-}
-TD_DEV void td_wino4_in_finish(const WinoArgs& p, const WinoInRide& st) {
-    const int slices = (p.C + 63) / 64;
-    const int tl = st.wv / slices, sl = st.wv - tl * slices;
-    const int c0 = sl * 64 + (int)(threadIdx.x & 63);
-    const unsigned coff = c0 < p.C ? (unsigned)c0 * 4u : TD_BUF_OOB;
-    float tm[6][6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        float col[6];
-        td_wino4_bt_t(st.d[c], col);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) tm[r][c] = col[r];
-    }
-    const unsigned plane = (unsigned)p.TP * (unsigned)p.C * 4u;
-    const TdBuf vb = td_make_buf(p.V, 36u * plane);
-    const unsigned voff = (unsigned)tl * (unsigned)p.C * 4u;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        float v[6];
-        td_wino4_bt_t(tm[r], v);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) td_buf_st1(vb, coff, (unsigned)(r * 6 + c) * plane + voff, v[c]);
-    }
-}
-TD_DEV void td_wino4_out_issue(const WinoArgs& p, int wv, WinoOutRide& st) {
-    const int slices = (p.Cout + 63) / 64;
-    const WinoTile w = td_wino_unit_tile(p, slices, wv);
-    const int c0 = w.sl * 64 + (int)(threadIdx.x & 63);
-    const unsigned coff = c0 < p.Cout ? (unsigned)c0 * 4u : TD_BUF_OOB;
-    st.wv = wv;
-    const unsigned plane = (unsigned)p.TP * (unsigned)p.Cout * 4u;
-    const TdBuf mb = td_make_buf(p.Mb, 36u * plane);
-    const unsigned moff = (unsigned)w.tl * (unsigned)p.Cout * 4u;
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int r = 0; r < 6; ++r) st.m[c][r] = td_buf_ld1(mb, coff, (unsigned)(r * 6 + c) * plane + moff);
-    const TdBuf bbuf = td_make_buf(p.bias, (unsigned)p.Cout * 4u);
-    st.b = td_buf_ld1(bbuf, coff, 0u);
-}
-TD_DEV void td_wino4_out_finish(const WinoArgs& p, const WinoOutRide& st) {
-    const int slices = (p.Cout + 63) / 64;
-    const WinoTile w = td_wino_unit_tile(p, slices, st.wv);
-    const unsigned pixn = (unsigned)p.H * (unsigned)p.W;
-    const TdBuf outb = td_make_buf(p.out, pixn * (unsigned)p.Cout * 4u);
-    const TdBuf resb = td_make_buf(p.resid, p.resid ? pixn * (unsigned)p.Cout * 4u : 0u);
-    const float slope = td_act_slope(p.act);
-    const int c0 = w.sl * 64 + (int)(threadIdx.x & 63);
-    const unsigned coff = c0 < p.Cout ? (unsigned)c0 * 4u : TD_BUF_OOB;
-    float rs[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int y = w.py + p.dil * (4 * w.ty + r), x = w.px + p.dil * (4 * w.tx + c);
-            const bool ok = y < p.H && x < p.W;
-            rs[r][c] = td_buf_ld1(resb, ok ? coff : TD_BUF_OOB, ok ? ((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.Cout * 4u : 0u);
-        }
-    float sm[4][6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        float col[4];
-        td_wino4_at_t(st.m[c], col);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sm[r][c] = col[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float o4[4];
-        td_wino4_at_t(sm[r], o4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int y = w.py + p.dil * (4 * w.ty + r), x = w.px + p.dil * (4 * w.tx + c);
-            const bool ok = y < p.H && x < p.W;
-            float o = o4[c] + st.b;
-            o = o + rs[r][c];
-            td_buf_st1(outb, ok ? coff : TD_BUF_OOB, ok ? ((unsigned)y * (unsigned)p.W + (unsigned)x) * (unsigned)p.Cout * 4u : 0u, td_activate(o, slope));
-        }
-    }
-}
-
 template <int VW>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_in_c(WinoArgs p) {
     const int slices = (p.C + 64 * VW - 1) / (64 * VW);
@@ -600,11 +397,10 @@ static inline long wino_tiles_estimate(long M, int dil, int m) {
 
 // U = G g G^T (fp64) for every (co, ci): (m+2)^2 [Cout][Cin] matrices, matrix xi*(m+2)+nu first
 static inline void wino_transform_weights(const float* w, int Cout, int Cin, int m, std::vector<std::vector<float>>& U) {
-    static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     static const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     const int n = m + 2;
-    const double (*G)[3] = m == 2 ? G2 : G4;
+    const double (*G)[3] = G4;                                        // m == 4 only
     U.assign((size_t)n * n, std::vector<float>((size_t)Cout * Cin));
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci) {

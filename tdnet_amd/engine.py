@@ -20,15 +20,42 @@ def _ptr(a):
 
 
 class Engine:
-    def __init__(self, model, backbone, nclass, height, width, device=0, lib=None, opts=None):
+    def __init__(self, model, backbone, nclass, height, width, device=0, lib=None, opts=None, _shared_from=None):
         """opts: None (library defaults) or a dict of tdnet_opts fields (winograd=, precision=, pipeline=, ...): per handle."""
         self.lib = lib or _capi.lib()
         self.cfg = _capi.TdnetCfg(model, backbone, nclass, height, width, device)
         h = ctypes.c_void_p()
+        if _shared_from is not None:                                   # a further handle on the same weight block (tdnet_create_shared)
+            self.lib.check(self.lib.tdnet_create_shared(_shared_from.h, None, ctypes.byref(h)))
+            self.h = h
+            self.finalized = True
+            return
         o = self.lib.opts(**(opts or {}))
         self.lib.check(self.lib.tdnet_create_opts(ctypes.byref(self.cfg), ctypes.byref(o), ctypes.byref(h)))
         self.h = h
         self.finalized = False
+
+    def share(self):
+        """A new Engine on THIS engine's weights (one copy of the packed weights in HBM): own workspace, own K/Q/V FIFO, own streams.
+        The weight block is reference-counted in the library: either engine may be closed first."""
+        if not self.finalized:
+            raise _capi.TdnetError("share(): load_state_dict() first")
+        c = self.cfg
+        return Engine(c.model, c.backbone, c.nclass, c.height, c.width, c.device, lib=self.lib, _shared_from=self)
+
+    def warmup(self, stream=None):
+        """The one host-synchronising step of a handle (placement of its internal streams against `stream`), done now instead of
+        inside the first frame (include/tdnet.h "Conventions")."""
+        self.lib.check(self.lib.tdnet_warmup(self.h, stream))
+
+    def memory_bytes(self):
+        """(bytes of the shared weight block, bytes of this handle alone, handles sharing the block)."""
+        w, m = ctypes.c_size_t(), ctypes.c_size_t()
+        n = self.lib.check(self.lib.tdnet_memory_bytes(self.h, ctypes.byref(w), ctypes.byref(m)))
+        return w.value, m.value, n
+
+    def last_launch_count(self):
+        return self.lib.tdnet_last_launch_count(self.h)
 
     def close(self):
         if getattr(self, "h", None):

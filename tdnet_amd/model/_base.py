@@ -126,7 +126,9 @@ class _TDNetBase(nn.Module):
                                "streams of another batch size" % (self._batch, n))
         self._batch = n
         while len(self._extra_engines) < n - 1:
-            self._extra_engines.append(self._build_engine(H, W, img.device.index or 0, n))
+            # the samples of a batch share one nn.Module's parameters in the reference (td4_psp18.py:216-229): the extra handles share
+            # sample 0's weight block (include/tdnet.h tdnet_create_shared) -- own workspace + FIFO + streams, no second copy of the weights
+            self._extra_engines.append(first.share())
         return [first] + self._extra_engines[:n - 1]
 
     def ensure_engine(self, H, W, device):
@@ -177,6 +179,19 @@ class _TDNetBase(nn.Module):
             raise RuntimeError("Error(s) in loading state_dict for %s:\n\t%s" % (type(self).__name__, e))
         return eng
 
+    def share_weights_with(self, owner):
+        """Serve another stream of the SAME geometry from `owner`'s weight block instead of loading this instance's own copy: this
+        model's handle becomes a tdnet_create_shared handle of owner's (own workspace, FIFO and streams; include/tdnet.h).  Used for
+        the second lane of parallel.FramePipelinedStream and for clips sharing a GPU (bench.py --clips-per-gpu).  `owner` must have its
+        handle (ensure_engine / a first frame); either model may be closed first (the block is reference-counted)."""
+        if owner._engine is None:
+            raise RuntimeError("share_weights_with(): the owner has no handle yet -- call owner.ensure_engine(H, W, device) first")
+        self._close_engines()
+        self._state = owner._state
+        self._missing_keys = list(owner._missing_keys)
+        self._engine, self._engine_key = owner._engine.share(), owner._engine_key
+        return self
+
     # ---- nn.Module surface used by Testing/test.py:40-41,53 ------------------------------------------------------
     def _check_frame(self, img, pos_id):
         if not torch.is_tensor(img) or img.dim() != 4 or img.shape[1] != 3:
@@ -208,9 +223,19 @@ class _TDNetBase(nn.Module):
         ready = torch.cuda.Event()
         ready.record(cur)
         side.wait_event(ready)
-        for i, eng in enumerate(engines):
-            call(i, eng, (side if i & 1 else cur).cuda_stream)
-        cur.wait_stream(side)
+        try:
+            for i, eng in enumerate(engines):
+                call(i, eng, (side if i & 1 else cur).cuda_stream)
+        except BaseException:
+            # a sample failed (TdnetError from the C library): the samples before it have committed their frame, the ones after it
+            # have not -- the per-sample FIFOs are out of step.  Like FramePipelinedStream.process: every stream starts over.
+            for eng in engines:
+                eng.reset()
+            self._batch = None
+            raise
+        finally:
+            cur.wait_stream(side)                                      # whatever happened, the caller's stream is ordered behind the side lane:
+                                                                       # `out` and the temporary input were allocated on it and may be freed now
 
     @staticmethod
     def _stream_beside(taken, device, lib):

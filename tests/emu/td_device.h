@@ -97,8 +97,9 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds
 #define TD_DEV_MEMBER static inline
 #define TD_LAUNCH_BOUNDS(t, w)
 #define TD_DYN_LDS(name) char* name = tdemu::g_lds
+static thread_local long td_launch_count = 0;
 #define TD_LAUNCH(kern, grid, block, lds, stream, ...) \
-    tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds))
+    do { ++td_launch_count; tdemu::launch([=]() { kern(__VA_ARGS__); }, grid, block, (size_t)(lds)); } while (0)
 
 #define TD_SCHED_GROUP(mask, n) ((void)0)
 #define TD_SCHED_FENCE() ((void)0)

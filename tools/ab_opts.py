@@ -2,7 +2,7 @@
 """Same-process A/B of tdnet_opts variants on one workload (GPU box).
 
     python tools/ab_opts.py [--model td4] [--backbone resnet18] [--size 1024x2048] [--precision fp32|fp16] [--steps 60] [--rounds 3] \
-        "" "cu_reserve=32" "cu_reserve=32,cu_mode=1" "overlap=0"
+        "" "overlap=0" "overlap=33" "precision=1,overlap=0"
 
 One process, one set of synthetic weights and frames; per round every variant gets a fresh handle (an idle handle's streams slow a busy
 one: INTEGRATION.md 3), P + 4 warm-up frames and `steps` timed frames between two device synchronisations; the rounds interleave the

@@ -6,10 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tdnet_amd import _capi
 lib = _capi.lib(); torch.zeros(1, device="cuda")
-import sys as _s
-ST = int(_s.argv[1]) if len(_s.argv) > 1 else 0
-o = lib.opts(winograd=0, stagger=ST)
-print("stagger", ST)
+
+
+o = lib.opts(winograd=0)
+
 for tile in (3, 4):
     for H in (128, 512, 1024):                       # M = H * 256: 32768 (2 tiles of 128x128 per workgroup at N = 512), 131072, 262144
         row = []
