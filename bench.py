@@ -240,7 +240,7 @@ def logits_digest(out, torch):
 def profile_dominant(eng, step_one, nprof, sync, torch):
     """Profiled replay (HIP events around every launch on the forward's own streams): per-family [ms, FLOP, launches] sums."""
     eng.set_profiling(True)
-    acc = {k: [0.0, 0.0, 0.0] for k in (0, 1, 2, 3)}
+    acc = {k: [0.0, 0.0, 0.0] for k in (0, 1, 2, 3, 4)}
     sync()
     with torch.no_grad():
         for _ in range(nprof):
@@ -253,21 +253,41 @@ def profile_dominant(eng, step_one, nprof, sync, torch):
     return acc
 
 
-def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite, pipelined=False):
+def latency_synced(step_one, sync, nframes=20, skip=6):
+    """The reference's OWN measurement (Testing/test.py:46-59): synchronise, start the clock, one forward, synchronise, stop; the frames
+    i > 5 are averaged.  A per-frame LATENCY with the host in the loop, not a throughput: the partner of BASELINE.md's published
+    ms/frame figures.  Returns milliseconds per frame."""
+    tot, cnt = 0.0, 0
+    for i in range(nframes + skip):
+        sync()
+        t0 = time.perf_counter()
+        step_one()
+        sync()
+        dt = time.perf_counter() - t0
+        if i >= skip:
+            tot += dt
+            cnt += 1
+    return 1e3 * tot / max(cnt, 1)
+
+
+def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite, pipelined=False, published_ms=None):
     """One short leg for another BASELINE.json config on this GPU: frames/s over `steps` steady frames, the dominant kernel's roofline
     fraction (profiled replay) and parity against the CPU oracle on `cpu_frames` steady frames.  Own model, own clip, own oracle."""
     import numpy as np
     import torch
     from oracle import tdnet_ref                                          # checker only
     from tdnet_amd import arch, weights
-    from tdnet_amd.model import td2_psp50, td4_psp18
+    from tdnet_amd.model import pspnet, td2_psp50, td4_psp18
     H, W = size
     spec = arch.model_spec(model_name, 19, backbone)
     P = spec.path_num
     sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
     cls = td4_psp18.td4_psp18 if model_name == "td4" else td2_psp50.td2_psp50
     opts = {"precision": 1} if precision == "fp16" else {}
-    m = cls(nclass=19, path_num=P, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
+    if model_name == "psp":
+        m = pspnet.pspnet(nclass=19, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
+    else:
+        m = cls(nclass=19, path_num=P, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
     m.load_state_dict(sd)
     NF = 6
     clip = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=200)]
@@ -288,20 +308,27 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         dt = time.perf_counter() - t0
     eng = m.engine
     peak = PEAK_FP16_MFMA_TFLOPS if precision == "fp16" else PEAK_FP32_MFMA_TFLOPS
+    with torch.no_grad():
+        lat_ms = latency_synced(step, sync)
+    nlaunch = eng.last_launch_count()
+    wbytes, hbytes, _ = eng.memory_bytes()
     acc = profile_dominant(eng, step, 2 * P, sync, torch)
     dom_ms, dom_fl, dom_n = acc[3]
-    leg = {"config": tag, "workload": "%s-psp%s, %dx%d, %s" % (model_name, backbone[6:], H, W, precision), "reference": cite,
+    mname = ("psp%s" if model_name == "psp" else model_name + "-psp%s") % backbone[6:]
+    leg = {"config": tag, "workload": "%s, %dx%d, %s" % (mname, H, W, precision), "reference": cite,
            "value": round(steps / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
+           "latency_ms_synced": round(lat_ms, 4),
            "dtype": "f32" if precision == "fp32" else "f16 (fp16 MFMA, fp32 accumulate)", "kernel_opts": eng.opts(),
-           "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1)}
+           "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1), "launches_per_frame": nlaunch,
+           "memory": {"weights_bytes": wbytes, "handle_bytes": hbytes}}
+    if published_ms:
+        leg["published"] = {"ms_per_frame": published_ms, "hardware": "Titan Xp, PyTorch 1.1.0 + CUDA 10.0 (Testing/TEST_README.md:31-33)", "protocol": "test.py:46-59",
+                            "speedup_of_latency_ms_synced": round(published_ms / lat_ms, 2),
+                            "note": "other hardware, trained checkpoint vs synthetic weights of the same architecture: orientation, not vs_baseline"}
     if dom_n > 0 and dom_ms > 0:
-        ach = dom_fl / (dom_ms * 1e-3) / 1e12
-        leg["roofline"] = {"bound": "mfma", "kernel": "k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> / k_conv_dma_h3n<RH,..> / k_conv_dma_h<RH,3,..> / k_conv_igemm_h<128,128,2,2,3,..> (3x3 convs on fp16 maps, fp16 MFMA; since round 4 incl. the 128-channel layers of small maps)" if precision == "fp16"
-                           else "k_gemm_dma / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
-                           "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / (2 * P)}
+        leg["roofline"] = roofline_block(acc, precision == "fp16", peak, 2 * P)
     if cpu_frames > 0:
-        ref = tdnet_ref.TDNetRef(spec, sd)
+        ref = (tdnet_ref.PSPNetRef if model_name == "psp" else tdnet_ref.TDNetRef)(spec, sd)
         par, cpu_t, _ = parity_sample(m, ref, clip, P, P, cpu_frames, precision == "fp32", torch, np, tdnet_ref)
         leg["parity"] = par
         leg["cpu_baseline"] = {"value": round(cpu_frames / cpu_t, 4), "unit": "frames/s", "kind": "port", "sample": "%d steady-state frames" % cpu_frames}
@@ -314,13 +341,13 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
             m.reset()
             refs = [m(clip[t % NF], pos_id=t % P).clone() for t in range(nchk)]
             sync()
-            eng.close()
-            stages = []
-            for _ in range(2):
-                st_ = cls(nclass=19, path_num=P, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
-                st_.load_state_dict(sd)
-                stages.append(st_)
-            fp = parallel.FramePipelinedStream(stages, P, dev, (H, W))
+            m.reset()
+            t_l0 = time.perf_counter()
+            fp = parallel.FramePipelinedStream.from_model(m, P, dev, (H, W))      # lane 1 shares lane 0's weight block (tdnet_create_shared)
+            sync()
+            lane_s = time.perf_counter() - t_l0
+            stages = fp.stages
+            lane_w, lane_h, lane_refs = stages[1].engine.memory_bytes()
             outs = fp.process([clip[t % NF] for t in range(nchk)])
             same = all(torch.equal(x, y) for x, y in zip(outs, refs))
             del outs, refs
@@ -335,6 +362,8 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
             dt2 = time.perf_counter() - t0
         leg["two_frames_in_flight"] = {"value": round(2 * steps / dt2, 3), "unit": "frames/s", "frames": 2 * steps, "vs_one_handle": round(2 * steps / dt2 / leg["value"], 3),
                                        "bit_identical_to_one_handle": bool(same), "frames_compared": nchk,
+                                       "second_lane": {"shares_weight_block": lane_refs == 2, "extra_hbm_bytes": lane_h, "weight_block_bytes_shared": lane_w,
+                                                       "create_s": round(lane_s, 3)},
                                        "what": "ONE clip, two handles on two HIP streams of this process, frame t + 1 encoded beside frame t (bench.py --mode frame-pipelined); "
                                                "throughput of small maps that leave CUs idle, a frame's latency grows"}
         if not same:
@@ -347,6 +376,26 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         eng.close()
     del m
     return leg
+
+
+def roofline_block(acc, fp16, peak, nframes):
+    """The `roofline` object of a leg from a profiled replay (profile_dominant).  fp32: the dominant kernel = the Winograd GEMMs (executed
+    FLOP).  fp16 mode (since round 5): `frac` is over a FIXED set of layers -- every 3x3 conv that reads an fp16 map, whatever kernel it
+    is routed to (tdnet_last_ms which = 4) -- so that routing a layer to a faster kernel can only raise it; the round-3/4 figure over the
+    kernels selected by tile (which = 3: the LDS-DMA / 128x128-tile convs) is printed beside it."""
+    dom_ms, dom_fl, dom_n = acc[3]
+    ach = dom_fl / (dom_ms * 1e-3) / 1e12
+    if not fp16:
+        return {"bound": "mfma", "kernel": "k_gemm_dma / k_gemm_persistent<*,*,*,*,ROLE=1> (Winograd F(4x4) GEMMs, executed FLOP)",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nframes}
+    fx_ms, fx_fl, fx_n = acc[4]
+    fx = fx_fl / (fx_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "every 3x3 conv on an fp16 map (fixed layer set: k_conv_dma_h3n / _h3p / _h3 / _h<RH,3,..> / k_conv_igemm_h<..,3,true,..>), fp16 MFMA, fp32 accumulate",
+            "achieved": round(fx, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fx / peak, 4),
+            "avg_launch_ms": round(fx_ms / fx_n, 4), "launches_per_frame": fx_n / nframes,
+            "frac_round4_kernel_set": round(ach / peak, 4), "round4_kernel_set": "LDS-DMA + 128x128-tile 3x3 convs only (selected by kernel, %g launches per frame)" % (dom_n / nframes),
+            "note": "per-launch durations (HIP events on the launch's own stream); with the row-parity chains two launches share the chip"}
 
 
 def main():
@@ -414,7 +463,7 @@ def main():
         sd = dict(sd)
         sd[k0] = np.asarray(sd[k0], np.float32) * np.float32(1.001)
 
-    def make_model(opts):
+    def make_model(opts, load=True):
         from tdnet_amd.model import pspnet, td2_psp50, td4_psp18
         if args.model == "psp":                                                   # the reference's comparison model (test.py:34-38)
             m = pspnet.pspnet(nclass=19, model_path=None, backbone=args.backbone, kernel_opts=opts)
@@ -422,7 +471,8 @@ def main():
             cls = td4_psp18.td4_psp18 if args.model == "td4" else td2_psp50.td2_psp50
             m = cls(nclass=19, path_num=P, model_path=None, backbone=args.backbone, kernel_opts=opts)
         m = m.eval().to(dev)
-        m.load_state_dict(sd)
+        if load:
+            m.load_state_dict(sd)
         return m
 
     C = 1 if args.dry_run else max(1, args.clips_per_gpu)
@@ -432,7 +482,12 @@ def main():
     if args.dry_run:
         models, streams, clips = [None], [None], [[torch.zeros(1) for _ in range(NF)]]
     else:
-        models = [make_model(kopts) for _ in range(C)]                            # extra clips: own handle (weights + FIFO), own stream
+        # extra clips / the second lane of a frame-pipelined clip: own handle (workspace + FIFO + streams) on clip 0's WEIGHT BLOCK
+        # (include/tdnet.h tdnet_create_shared) -- one copy of the packed weights per GPU however many streams it serves
+        models = [make_model(kopts)]
+        models[0].ensure_engine(H, W, dev)
+        for _ in range(C - 1):
+            models.append(make_model(kopts, load=False).share_weights_with(models[0]))
         # two lanes whatever C (model/_base.py _for_each_sample): even clips on the current stream, odd ones on ONE more stream that is
         # checked to sit on another hardware queue; a third concurrently busy stream costs more than it fills
         from tdnet_amd import _capi
@@ -451,10 +506,19 @@ def main():
         clip = clips[0] = [torch.from_numpy(x).to(dev) for x in weights.synth_video(H, W, NF, seed=100)]   # the SAME stream on every rank
         C = 1
 
-    fpl = None
+    fpl, fpl_same = None, None
     if args.mode == "frame-pipelined" and not args.dry_run:
         fpl = parallel.FramePipelinedStream(models[:2], P, dev, (H, W))
         C = 1
+        # the line says "bit-identical outputs": hold the two-lane path to ONE handle on a replay from an empty FIFO, in this run
+        with torch.no_grad():
+            nchk_ = P + 4
+            one = [models[0](clip[t % NF], pos_id=t % P).clone() for t in range(nchk_)]
+            models[0].reset()
+            two = fpl.process([clip[t % NF] for t in range(nchk_)])
+            fpl_same = all(torch.equal(x, y) for x, y in zip(one, two))
+            del one, two
+            fpl.reset()
     FR = C * (2 if fpl is not None else 1)                            # frames per step and rank
 
     def step(ms=None, n_clips=None):
@@ -548,8 +612,9 @@ def main():
            "hw_queues": __import__("tdnet_amd").hw_queue_note(),
            "config": {"workload": "%s, %dx%d Cityscapes-shaped synthetic stream, %d-frame feature cache, %d clip%s per GPU"
                                   % (mname, H, W, spec.fifo, C, "" if C == 1 else "s (concurrent HIP streams)"),
-                      "parallelism": ("clip-parallel x%d, RCCL weight broadcast only; each clip with TWO FRAMES IN FLIGHT (two handles on two HIP "
-                                      "streams, cache entries handed over between encode and propagate; bit-identical outputs)" % world) if fpl is not None else
+                      "parallelism": ("clip-parallel x%d, RCCL weight broadcast only; each clip with TWO FRAMES IN FLIGHT (two handles sharing one weight block on two "
+                                      "HIP streams, cache entries handed over between encode and propagate; outputs held bit for bit to one handle in this run: "
+                                      "see two_lanes_bit_identical_to_one_handle)" % world) if fpl is not None else
                                      ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else
                                      ("path-parallel x%d: one stream, one all-gather of %d cache entries per round" % (world, world)),
                       "target_fps_per_gpu": 30}}
@@ -559,6 +624,10 @@ def main():
                             "unit": "frames/s", "ms_per_step": round(1e3 * sustained[1] / sustained[0], 4),
                             "note": "the same timed loop (barrier + synchronize on both sides, max over ranks) over >= 0.5 s, because --steps %d "
                                     "is a %.0f-ms window; `value` above is exactly --steps frames" % (args.steps, 1e3 * tmax)}
+    if fpl is not None:
+        res["two_lanes_bit_identical_to_one_handle"] = bool(fpl_same)
+        if not fpl_same:
+            res["FAILED"] = "frame-pipelined outputs differ from the single handle's"
     if pp is not None:
         res["scaling"] = "strong"
     if args.share_gpu:
@@ -569,7 +638,7 @@ def main():
         res["dry_run"] = True
         res["metric"] = "DRY RUN (launch plumbing only, no model): " + res["metric"]
 
-    exit_code = 0
+    exit_code = 5 if (fpl is not None and not fpl_same) else 0
     # ---- N > 1: the line must be able to FAIL.  Every rank replays RANK 0's clip for P + 2 frames and contributes a 64-bit digest of each
     # frame's logits bits plus its label histogram; MIN and MAX all-reduces must coincide (every rank bit-identical to rank 0, whose
     # output is held to the CPU oracle below), and the 19x19 confusion matrices (each rank's labels vs the oracle's) are
@@ -651,14 +720,25 @@ def main():
                 for _ in range(P + 2):
                     step(n_clips=1)
             sync()
+        # the reference's own protocol (test.py:46-59: a device synchronisation on both sides of every frame, frames i > 5 averaged),
+        # clip 0 alone -- the like-for-like partner of BASELINE.md's published ms/frame -- beside the throughput `value`
+        if pp is None and fpl is None:
+            with torch.no_grad():
+                res["latency_ms_synced"] = round(latency_synced(lambda: step(n_clips=1), sync), 4)
+            res["latency_note"] = ("latency_ms_synced = Testing/test.py:46-59's loop (synchronise, start, forward, synchronise; frames i > 5 averaged), one "
+                                   "clip, frames resident in HBM; `value` = K frames back to back between one pair of synchronisations (throughput)")
+        wbytes, hbytes, nshare = eng.memory_bytes()
+        res["memory"] = {"weights_bytes": wbytes, "handle_bytes": hbytes, "handles_on_this_weight_block": nshare,
+                         "note": "a further stream on this GPU (batch sample, clip, pipeline lane) costs handle_bytes only: tdnet_create_shared"}
         acc = profile_dominant(eng, lambda: step(n_clips=1), nprof, sync, torch)   # the replay runs clip 0 alone: per-launch durations
+        res["launches_per_frame"] = eng.last_launch_count()
         dom_ms, dom_fl, dom_n = acc[3]
         dom_regex = None
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             if opts["precision"]:
                 kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> (dedicated loader waves) / k_conv_dma_h3n<RH,..> (narrow tiles) / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
-                                    "k_conv_igemm_h<128,128,2,2,3,...> where the register-staged kernel is kept"), r"k_conv_dma_h3[a-z]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<128, 128, 2, 2, 3"
+                                    "k_conv_igemm_h<..,3,true,..> where the register-staged kernel is kept"), r"k_conv_dma_h3[a-z]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<\d+, \d+, \d, \d, 3, true"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:
@@ -675,6 +755,9 @@ def main():
                                "frac": round(achieved / peak, 4), "traffic": None,
                                "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nprof,
                                "gflop_per_launch": round(dom_fl / dom_n / 1e9, 2)}
+            if opts["precision"] and acc[4][2] > 0:                    # fp16 mode: the FIXED layer set is the headline fraction (roofline_block)
+                res["roofline"].update(roofline_block(acc, True, peak, nprof))
+                res["roofline"]["traffic"] = None
         # With the row-parity chains (tdnet_opts.overlap) two launches of the dominant kernel are in flight at a time, each progressing at
         # about half speed: `frac` (per-launch durations, the figure rocprofv3's kernel stats reproduce) then understates the kernel.
         # The same replay on a handle WITHOUT the chains gives the kernel's own rate, reported beside it.
@@ -774,7 +857,15 @@ def main():
                                  "td2_psp50(backbone='resnet18', path_num=2), Testing/model/pspnet/td2_psp50.py:52-58"),
                 other_config_leg("configs[4]", "td2", "resnet34", (720, 960), "fp16", 40, ncpu, dev, sync,
                                  "td2-bise34 does not exist in the reference (SURVEY 0): td2_psp50(backbone='resnet34') is its stand-in; "
-                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path", pipelined=True)]
+                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path", pipelined=True),
+                # the configurations the reference SHIPS and publishes numbers for, at its native 769x1537 (Testing/test.py:22-38, TEST_README.md:31-33)
+                other_config_leg("native td4-psp18", "td4", "resnet18", (769, 1537), "fp32", 40, ncpu, dev, sync,
+                                 "test.py:24-26 `--model td4-psp18` at 769x1537; TEST_README.md:33 publishes 85 ms/frame (Titan Xp)", published_ms=85.0),
+                other_config_leg("native td2-psp50", "td2", "resnet50", (769, 1537), "fp32", 30, ncpu, dev, sync,
+                                 "test.py:28-32 `--model td2-psp50` at 769x1537; TEST_README.md:32 publishes 180 ms/frame (Titan Xp)", published_ms=180.0),
+                other_config_leg("native psp101", "psp", "resnet101", (769, 1537), "fp32", 20, min(ncpu, 3), dev, sync,
+                                 "test.py:34-38 `--model psp101` at 769x1537; TEST_README.md:31 publishes 360 ms/frame (Titan Xp); CPU leg: 3 frames "
+                                 "(the stateless ResNet-101 frame is the most expensive on the host)", published_ms=360.0)]
             if any(l.get("parity", {}).get("FAILED") for l in res["other_configs"]):
                 exit_code = 3
     if rank == 0:

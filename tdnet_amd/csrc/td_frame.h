@@ -70,7 +70,38 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
     prof_end(n, s);
     return 0;
 }
+// The same run in the fp16 mode (tdnet_opts.precision = 1, round 5): the convs are DIRECT fp16 LDS-DMA convs, each launched on one row
+// class of its map (td_launch.h run_conv_rows_h: a half-height map with twice the row pitch; identical products, bit-identical rows).  A
+// conv of a small map is a grid of ~230 workgroups of one K-loop latency chain each and a kernel boundary costs a tenth of it; two chains
+// on two hardware queues put one chain's ramp-down / dispatch / ramp-up under the other's K loops.  The last conv of the backbone writes
+// the fp32 c4 (its residual is an fp16 map), as in the unchained sequence.
+static int run_parity_chains_h(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
+    const int sb = n->seg_block, nblk = (int)L.blocks.size();
+    hipStream_t st[2] = {s, n->chain2};
+    {   // the part of the first block that precedes the run: its downsample, and conv1 when the run starts at conv2
+        BlockLayers& B = L.blocks[sb];
+        if (n->seg_conv == 1) TD_TRY(run_conv(n, B.c1, n->bx, h, w, nullptr, n->seg_t[sb], s));
+        if (B.has_ds) TD_TRY(run_conv(n, B.ds, n->bx, h, w, nullptr, n->seg_r[sb], s));
+    }
+    TD_HIP(hipEventRecord(n->ev_cfork, s));
+    TD_HIP(hipStreamWaitEvent(n->chain2, n->ev_cfork, 0));
+    for (int b = sb; b < nblk; ++b) {
+        BlockLayers& B = L.blocks[b];
+        const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
+        for (int c = 0; c < 2; ++c) {
+            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_conv_rows_h(n, B.c1, xin, h, w, nullptr, n->seg_t[b], 2, c, st[c]));
+            if (B.has_ds && b > sb) TD_TRY(run_conv_rows_h(n, B.ds, xin, h, w, nullptr, n->seg_r[b], 2, c, st[c]));
+        }
+        for (int c = 0; c < 2; ++c)
+            TD_TRY(run_conv_rows_h(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], 2, c, st[c]));
+    }
+    TD_HIP(hipEventRecord(n->ev_cjoin, n->chain2));
+    TD_HIP(hipStreamWaitEvent(s, n->ev_cjoin, 0));
+    return 0;
+}
+
 static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
+    if (n->act16) return run_parity_chains_h(n, L, h, w, s);
     const int sb = n->seg_block, nblk = (int)L.blocks.size();
     hipStream_t st[2] = {s, n->chain2};
     float* Vw[2] = {n->wino_v, n->wino_v2};
@@ -85,15 +116,21 @@ static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t 
     for (int b = sb; b < nblk; ++b) {
         BlockLayers& B = L.blocks[b];
         const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
+        // chain c = the rows of parity c.  A conv whose layer asks for four classes (overlap bit 64: rows mod 4, dilation a multiple of 4) runs
+        // the classes c and c + 2 one after the other on chain c's stream, each class transform -> GEMMs -> transform through the chain's workspaces
         for (int c = 0; c < 2; ++c) {
-            WinoChunk ck; ck.ny = 2; ck.cy = c;
-            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+            if (!(b == sb && n->seg_conv == 1))
+                for (int cy = c; cy < B.c1.chunks; cy += 2) {
+                    WinoChunk ck; ck.ny = B.c1.chunks; ck.cy = cy;
+                    TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+                }
             if (B.has_ds && b > sb) TD_TRY(run_ds_rows(n, B.ds, xin, h, w, n->seg_r[b], 2, c, st[c]));
         }
-        for (int c = 0; c < 2; ++c) {
-            WinoChunk ck; ck.ny = 2; ck.cy = c;
-            TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c]));
-        }
+        for (int c = 0; c < 2; ++c)
+            for (int cy = c; cy < B.c2.chunks; cy += 2) {
+                WinoChunk ck; ck.ny = B.c2.chunks; ck.cy = cy;
+                TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+            }
     }
     TD_HIP(hipEventRecord(n->ev_cjoin, n->chain2));
     TD_HIP(hipStreamWaitEvent(s, n->ev_cjoin, 0));

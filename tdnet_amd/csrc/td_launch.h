@@ -111,6 +111,48 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     return 0;
 }
 
+// The fp16 LDS-DMA conv of layer L on the arguments a: a cascade of kernel forms for the SAME tile, each falling back to the next when
+// the conv does not qualify (not a 3x3 "same" conv, halo wider than the form's image buffer): narrow tiles -> loader waves -> row
+// images (one LDS image per kernel ROW, k_conv_dma_h3) -> tap by tap.
+static void launch_conv_dma_forms(const ConvLayer& L, const ConvArgs& a, hipStream_t s) {
+    int rh = L.rh;
+    bool done = false;
+    const bool is192 = rh == CD_192_P || rh == CD_192_N, is256 = rh == CD_256_P || rh == CD_256_N;
+    if (rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {        // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
+        done = !L.rowimg_off && conv_launch_dma3n(a, rh, L.KS, L.out16, s);
+        if (!done) rh = is192 ? CD_192_P : is256 ? CD_256_P : CD_128_P;
+    }
+    if (!done && (rh == CD_128_P || rh == CD_192_P || rh == CD_256_P)) {                              // dedicated loader waves (k_conv_dma_h3p)
+        done = !L.rowimg_off && conv_launch_dma3p(a, rh, L.KS, L.out16, s);
+        if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
+    }
+    if (!done && (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s))) conv_launch_dma(a, rh, L.KS, L.out16, s);
+}
+
+// The fp16 LDS-DMA conv of layer L (stride 1, fp16 maps in and out of HBM) on the image rows y = ny i + cy ONLY: a sub-map of
+// ceil((H - cy) / ny) rows with the row pitch ny W and the row dilation dil / ny (td_conv.h ConvArgs.rp / dy).  With ny | dil the conv
+// maps such a row class onto itself, so the classes of a run of convs are independent chains (td_frame.h run_parity_chains_h).  Same
+// kernels, same products in the same order as the whole-map conv: the rows it writes are bit-identical.
+static int run_conv_rows_h(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, int ny, int cy, hipStream_t s) {
+    if (!L.h16 || !L.rh || !L.in16 || L.stride != 1 || L.stem || (L.KS == 3 && L.dil % ny) || (L.KS != 1 && L.KS != 3))
+        return td_fail("internal: this conv cannot run on a row class of its map");
+    const int Hc = (H - cy + ny - 1) / ny;
+    if (Hc <= 0) return 0;
+    const size_t in_row = (size_t)cy * W * L.Cin, out_row = (size_t)cy * W * L.Cout;   // in ELEMENTS; the maps are fp16 except a fp32 output (out16 false)
+    const _Float16* in_h = reinterpret_cast<const _Float16*>(in) + in_row;
+    const _Float16* res_h = resid ? reinterpret_cast<const _Float16*>(resid) + out_row : nullptr;
+    void* out_p = L.out16 ? (void*)(reinterpret_cast<_Float16*>(out) + out_row) : (void*)(out + out_row);
+    ConvArgs a;
+    a.in = reinterpret_cast<const float*>(in_h); a.wp = L.d_wp; a.bias = L.d_bias; a.resid = reinterpret_cast<const float*>(res_h); a.out = reinterpret_cast<float*>(out_p);
+    a.H = Hc; a.W = W; a.Cin = L.Cin; a.Wo = W; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.stride = 1; a.dil = L.dil; a.pad = L.pad; a.M = Hc * W; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.nbatch = 1;
+    a.rp = ny * W; a.dy = L.KS == 3 ? L.dil / ny : 1;
+    prof_begin(n, 0, L.KS == 3 ? 1 | 4 : 0, L.flops_per_pixel() * a.M, s);
+    launch_conv_dma_forms(L, a, s);
+    prof_end(n, s);
+    return 0;
+}
+
 // out[Ho*Wo][Cout] = act(conv(in[H][W][Cin]) + bias (+ resid))
 static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
                     int* Ho_out = nullptr, int* Wo_out = nullptr, const LnFuse* lnf = nullptr) {
@@ -119,7 +161,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     if (L.wino) {
         if (Ho_out) *Ho_out = H;
         if (Wo_out) *Wo_out = W;
-        if (L.chunks > 1 && !n) {                                      // operator tests: the chunks one after the other on one stream
+        if (L.chunks > 1 && (!n || !n->ws_ready)) {                    // operator tests and probes: the chunks one after the other on one stream
             for (int c = 0; c < L.chunks; ++c) {
                 WinoChunk ck; ck.ny = L.chunks; ck.cy = c;
                 TD_TRY(run_wino(n, L, in, H, W, resid, out, s, lnf, ck, nullptr, nullptr));
@@ -132,24 +174,11 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;
     a.H = H; a.W = W; a.Cin = L.Cin; a.Wo = Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.stride = L.stride; a.dil = L.dil; a.pad = L.pad; a.M = Ho * Wo; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.nbatch = 1;
-    prof_begin(n, 0, (L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || L.rh) && L.KS == 3 && !L.stem, L.flops_per_pixel() * a.M, s);
+    // dominant: bits 0-1 = 1 for the 128x128-tile / LDS-DMA 3x3 convs (the kernel set of rounds 3-4), bit 2 = EVERY 3x3 conv that reads an fp16 map
+    // (the fixed set of the fp16 mode's roofline since round 5: routing a layer to another kernel does not change it)
+    prof_begin(n, 0, (((L.tile == CT_128x128 || L.tile == CT_128x128_DEEP || L.rh) && L.KS == 3 && !L.stem) ? 1 : 0) | ((L.h16 && L.in16 && L.KS == 3 && !L.stem) ? 4 : 0), L.flops_per_pixel() * a.M, s);
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
-    else if (L.h16 && L.rh) {                                         // 3x3 stride 1: one LDS image per kernel ROW (k_conv_dma_h3) where the halo fits
-        // A cascade of kernel forms for the SAME tile, each falling back to the next when the conv does not qualify (not a 3x3 "same" conv,
-        // halo wider than the form's image buffer): narrow tiles -> loader waves -> row images -> tap by tap.
-        int rh = L.rh;
-        bool done = false;
-        const bool is192 = rh == CD_192_P || rh == CD_192_N, is256 = rh == CD_256_P || rh == CD_256_N;
-        if (rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {        // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
-            done = !L.rowimg_off && conv_launch_dma3n(a, rh, L.KS, L.out16, s);
-            if (!done) rh = is192 ? CD_192_P : is256 ? CD_256_P : CD_128_P;
-        }
-        if (!done && (rh == CD_128_P || rh == CD_192_P || rh == CD_256_P)) {                              // dedicated loader waves (k_conv_dma_h3p)
-            done = !L.rowimg_off && conv_launch_dma3p(a, rh, L.KS, L.out16, s);
-            if (!done) rh = is192 ? CD_192 : is256 ? CD_256 : CD_128_8W;
-        }
-        if (!done && (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s))) conv_launch_dma(a, rh, L.KS, L.out16, s);
-    }
+    else if (L.h16 && L.rh) launch_conv_dma_forms(L, a, s);
     else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;

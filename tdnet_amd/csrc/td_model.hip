@@ -339,16 +339,17 @@ extern "C" int tdnet_set_profiling(tdnet_t* n, int on) {
     n->nrec = 0;
     return 0;
 }
-// which: 0 conv/GEMM kernels, 1 attention kernels, 2 everything else, 3 the dominant kernel only (128x128-tile 3x3 igemm).
+// which: 0 conv/GEMM kernels, 1 attention kernels, 2 everything else, 3 the dominant kernel only (128x128-tile 3x3 igemm / LDS-DMA conv /
+// Winograd GEMM), 4 every 3x3 conv that reads an fp16 map (the fp16 mode's fixed roofline set).
 // mode : 0 -> summed device ms, 1 -> summed algorithmic FLOP, 2 -> launch count
 static double prof_query(const tdnet* n, int which, int mode) {
     if (!n || !n->prof || n->nrec == 0) return -1.0;
     double ms = 0.0, fl = 0.0, cnt = 0.0;
     int domkind = 1;                                                   // the Winograd GEMM is the dominant kernel whenever it runs
-    for (size_t i = 0; i < n->nrec; ++i) if (n->recs[i].dominant == 2) domkind = 2;
+    for (size_t i = 0; i < n->nrec; ++i) if ((n->recs[i].dominant & 3) == 2) domkind = 2;
     for (size_t i = 0; i < n->nrec; ++i) {
         const ProfRec& r = n->recs[i];
-        const bool take = which == 3 ? (r.family == 0 && r.dominant == domkind) : r.family == which;
+        const bool take = which == 3 ? (r.family == 0 && (r.dominant & 3) == domkind) : which == 4 ? (r.family == 0 && (r.dominant & 4) != 0) : r.family == which;
         if (!take) continue;
         if (mode == 0) {
             hipEventSynchronize(r.e1);

@@ -21,7 +21,7 @@ extern "C" int tdnet_op_conv2d(const float* in, int H, int W, int Cin, const flo
     const int pad = dil * (KS / 2);
     const long M = (long)out_size(H, KS, stride, dil, pad) * out_size(W, KS, stride, dil, pad);
     // tdnet_opts.overlap bit 1: an even-dilation Winograd conv runs as its two row-parity chunks (here one after the other)
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M, o, tile < 0 ? -1 : tile, (o.overlap & 1) ? 2 : 1)) return -1;
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, act, false, M, o, tile < 0 ? -1 : tile, !(o.overlap & 1) ? 1 : ((o.overlap & 64) && dil % 4 == 0) ? 4 : 2)) return -1;
     int rc = run_conv(nullptr, L, in, H, W, resid, out, (hipStream_t)stream);
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = td_fail("tdnet_op_conv2d: device error");
     free_conv_layer(L);
@@ -243,7 +243,8 @@ extern "C" double tdnet_bench_conv(int H, int W, int Cin, int Cout, int KS, int 
     for (auto& v : x) v = rnd();
     const int pad_ = dil * (KS / 2);
     const long M_ = (long)out_size(H, KS, stride, dil, pad_) * out_size(W, KS, stride, dil, pad_);
-    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, M_, o, tile)) return -1.0;   // tile -1: the heuristic's choice for this M
+    // tile -1: the heuristic's choice for this M; overlap bit 1 (+ 64): the conv as its 2 (4) row classes one after the other on the stream
+    if (make_conv_layer(L, w, b, Cout, Cin, KS, stride, dil, 1, false, M_, o, tile, !(o.overlap & 1) ? 1 : ((o.overlap & 64) && dil % 4 == 0) ? 4 : 2)) return -1.0;
     float *din = nullptr, *dout = nullptr;
     if (upload(&din, x)) return -1.0;
     const int Ho = out_size(H, KS, stride, dil, L.pad), Wo = out_size(W, KS, stride, dil, L.pad);

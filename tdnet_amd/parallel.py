@@ -226,6 +226,21 @@ class PathParallelStream:
             self._buf = torch.zeros(self.world, nq + nk + nv, dtype=torch.float32, device=self.device)
         return self._buf
 
+    @classmethod
+    def from_model(cls, model, path_num, device, frame_size, lanes=2):
+        """`lanes` lanes on ONE weight block: lane 0 is `model` itself, every further lane an instance of the same class whose handle is a
+        tdnet_create_shared handle of model's (own workspace, K/Q/V FIFO and streams; no second copy of the packed weights, no second
+        fold / pack / upload -- the reference's module is one set of parameters too).  model.share_weights_with documents the ownership."""
+        H, Wd = int(frame_size[0]), int(frame_size[1])
+        model.ensure_engine(H, Wd, device)
+        stages = [model]
+        for _ in range(lanes - 1):
+            kw = dict(nclass=model.nclass, model_path=None, backbone=model.backbone, kernel_opts=model.kernel_opts, synthetic_seed=model.synthetic_seed)
+            if getattr(model, "_model_id", None) != 1:
+                kw["path_num"] = model.path_num
+            stages.append(type(model)(**kw).eval().share_weights_with(model))
+        return cls(stages, path_num, device, frame_size)
+
     def _split(self, row):
         nq, nk, nv = self._sizes
         return row[:nq], row[nq:nq + nk], row[nq + nk:]
@@ -296,6 +311,21 @@ class FramePipelinedStream:
         self._done = [[None] * self.W, [None] * self.W]
         self._lanes, self._lanes_for, self._round = None, None, 0
 
+    @classmethod
+    def from_model(cls, model, path_num, device, frame_size, lanes=2):
+        """`lanes` lanes on ONE weight block: lane 0 is `model` itself, every further lane an instance of the same class whose handle is a
+        tdnet_create_shared handle of model's (own workspace, K/Q/V FIFO and streams; no second copy of the packed weights, no second
+        fold / pack / upload -- the reference's module is one set of parameters too).  model.share_weights_with documents the ownership."""
+        H, Wd = int(frame_size[0]), int(frame_size[1])
+        model.ensure_engine(H, Wd, device)
+        stages = [model]
+        for _ in range(lanes - 1):
+            kw = dict(nclass=model.nclass, model_path=None, backbone=model.backbone, kernel_opts=model.kernel_opts, synthetic_seed=model.synthetic_seed)
+            if getattr(model, "_model_id", None) != 1:
+                kw["path_num"] = model.path_num
+            stages.append(type(model)(**kw).eval().share_weights_with(model))
+        return cls(stages, path_num, device, frame_size)
+
     def _split(self, row):
         nq, nk, nv = self._sizes
         return row[:nq], row[nq:nq + nk], row[nq + nk:]
@@ -357,6 +387,10 @@ class FramePipelinedStream:
                     for i in range(W):
                         if i != j and done[i] is not None:
                             lanes[j].wait_event(done[i])               # lane i has read this row (two rounds ago)
+                    if j:
+                        # the frame is the caller's tensor, read here on ANOTHER stream: tell the allocator (and any producer that recycles
+                        # buffers by stream order, e.g. dataloader.DevicePrefetcher's `freed` events are on the caller's stream only)
+                        frames[r0 + j].record_stream(lanes[j])
                     self.stages[j].encode(frames[r0 + j], pos_id=(first_frame + r0 + j) % self.P)
                     self.stages[j].cache_export(*self._split(buf[j]))
                     e = torch.cuda.Event()
@@ -374,6 +408,9 @@ class FramePipelinedStream:
                             self.stages[j].cache_push(*self._split(buf[i]))
                     done[j] = torch.cuda.Event()
                     done[j].record(lanes[j])
+        # (Inputs and join=False: lane 0 IS the caller's stream and waits for enc[i] of every other lane before it pushes that lane's entry, so
+        # the caller's stream is already ordered behind every lane's only READ of its input frame -- a producer that recycles frame buffers in
+        # the caller's stream order, like dataloader.DevicePrefetcher, cannot overwrite a frame a lane still reads.)
         if join:
             self.join()
         return outs

@@ -353,6 +353,19 @@ def test_batch_of_streams_and_non_strict_loading():
         for t in range(T):
             out = m6(torch.cat([a[t], b[t], c[t]], 0), pos_id=t % 4)
             assert torch.equal(out[0:2], refs[t]) and torch.equal(out[2:3], mc(c[t], pos_id=t % 4)), t
+        # the samples of a batch share ONE weight block (include/tdnet.h tdnet_create_shared; td4_psp18.py:216-229: one module, N samples):
+        # three handles on m6's block, each costing only its workspace + FIFO; the block outlives the handle that loaded it
+        wb, hb, refs_n = m6.engine.memory_bytes()
+        assert refs_n == 3 and wb > 50e6 and all(e.memory_bytes() == (wb, hb, 3) for e in m6._extra_engines)
+        survivor = m6._extra_engines.pop()
+        m6._close_engines()                                             # the owner and one sharer go first
+        assert survivor.memory_bytes() == (wb, hb, 1)
+        o1 = torch.empty((1, 19, H, W), device="cuda")
+        survivor.reset()
+        survivor.warmup(torch.cuda.current_stream().cuda_stream)       # explicit placement of its internal streams (host-synchronising, once)
+        survivor.forward(a[0].data_ptr(), 0, o1.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(o1, make_model("td4", "resnet18", seed=4)(a[0], pos_id=0))
+        survivor.close()
         lab = m2.forward_labels(torch.cat([a[0], b[0]], 0), pos_id=(T % 4))
         assert lab.shape == (2, H, W)
         with pytest.raises(RuntimeError, match="batch size"):

@@ -60,6 +60,7 @@ def main():
     variants = [parse_variant(v) for v in a.variants]
     fps = [[] for _ in variants]
     host_us = [[] for _ in variants]
+    launches = [0] * len(variants)
     ident = [None] * len(variants)
     ref_out = None
     for r in range(a.rounds):
@@ -92,15 +93,16 @@ def main():
                         torch.cuda.synchronize(dev)
                 torch.cuda.synchronize(dev)
                 fps[i].append(a.steps / (time.perf_counter() - t0))
+                launches[i] = m.engine.last_launch_count()
             m.engine.close()
             del m
     print("%s-psp%s %dx%d %s, %d steps x %d rounds (interleaved), frames/s:" % (a.model, a.backbone[6:], H, W, a.precision + (", device synchronised after every frame" if a.sync_each else ""), a.steps, a.rounds))
     rows = []
-    for v, f, idn, hu in zip(a.variants, fps, ident, host_us):
+    for v, f, idn, hu, nl in zip(a.variants, fps, ident, host_us, launches):
         med = statistics.median(f)
         rows.append({"variant": v or "(default)", "fps_median": round(med, 2), "fps_rounds": [round(x, 2) for x in f], "vs_first": idn,
-                     "host_enqueue_us_per_frame": round(statistics.median(hu), 1), "sync_each_frame": bool(a.sync_each)})
-        print("  %-44s median %8.2f   rounds %s   host enqueue %6.0f us/frame   %s" % (v or "(default)", med, " ".join("%.1f" % x for x in f), statistics.median(hu), idn))
+                     "host_enqueue_us_per_frame": round(statistics.median(hu), 1), "sync_each_frame": bool(a.sync_each), "launches_per_frame": nl})
+        print("  %-44s median %8.2f   rounds %s   host enqueue %6.0f us/frame   %3d launches/frame   %s" % (v or "(default)", med, " ".join("%.1f" % x for x in f), statistics.median(hu), nl, idn))
     if a.json:
         with open(a.json, "a") as f:
             for row in rows:
