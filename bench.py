@@ -432,7 +432,9 @@ def main():
     allowed0 = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
     aff = None
     if world > 1:
-        aff = parallel.pin_rank(local_rank, world, device_indices=[0] * world if (args.share_gpu or args.dry_run) else None)
+        # ranks of THIS node share its cores: LOCAL_WORLD_SIZE (torch.distributed.run exports it), not the global world size
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        aff = parallel.pin_rank(local_rank, local_world, device_indices=[0] * local_world if (args.share_gpu or args.dry_run) else None)
     ones = parallel.allreduce_sum(torch.ones(1, dtype=torch.float64, device=dev))
     world_seen = int(round(ones.item()))
     if world_seen != args.gpus:

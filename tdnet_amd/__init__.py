@@ -16,7 +16,11 @@ HIP runtime initialises, so it has to be in the environment before the first GPU
 import os
 
 _PRESET = os.environ.get("GPU_MAX_HW_QUEUES")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# Opt-out for an embedding application that manages its own environment: TDNET_NO_ENV_DEFAULTS=1 leaves os.environ untouched (the C library
+# still says once on stderr when the variable is unset or > 3; README.md "Process-wide side effect").  bench.py, tests/conftest.py and
+# __graft_entry__.py export the variable themselves, before any import.
+if not os.environ.get("TDNET_NO_ENV_DEFAULTS"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 
 def hw_queue_note():
@@ -30,6 +34,8 @@ def hw_queue_note():
     v = os.environ.get("GPU_MAX_HW_QUEUES")
     if late:
         return "GPU_MAX_HW_QUEUES=%s set AFTER the HIP runtime started (no effect: import tdnet_amd before the first GPU call, or export it)" % v
+    if v is None:
+        return "GPU_MAX_HW_QUEUES not set (TDNET_NO_ENV_DEFAULTS: HIP's default of 4 hardware queues per priority class applies)"
     return "GPU_MAX_HW_QUEUES=%s (%s)" % (v, "from the environment" if _PRESET is not None else "set by tdnet_amd at import")
 
 

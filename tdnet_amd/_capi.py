@@ -22,7 +22,7 @@ class TdnetOpts(ctypes.Structure):
     """include/tdnet.h tdnet_opts: per-handle kernel configuration (nothing in the library is process-wide)."""
     _fields_ = [("winograd", ctypes.c_int32), ("precision", ctypes.c_int32), ("pipeline", ctypes.c_int32),
                 ("gemm_persistent", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("attention", ctypes.c_int32),
-                ("fusion", ctypes.c_int32), ("overlap", ctypes.c_int32), ("chain_rows", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
+                ("fusion", ctypes.c_int32), ("overlap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 8)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

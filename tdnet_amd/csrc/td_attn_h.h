@@ -273,11 +273,17 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_attention_h(AttnArgsH p) {
 
 static inline int attn_lkpad(int Lk) { return (Lk + 127) / 128 * 128; }
 
-// vt: workspace of DV * attn_lkpad(Lk) halfs (the caller's; filled here from vp on the same stream)
-static inline int attn_launch_h(const AttnArgs& a, int DV, _Float16* vt, hipStream_t s) {
+// V' [Lk][DV] fp32 -> the re-tiled fp16 operand of k_attention_h.  A launch of its own so that the caller can put it where V' is PRODUCED
+// (the side stream, under the backbone) instead of in front of the attention that consumes it (td_frame.h launch_chain).
+static inline void attn_prepare_vt_h(const float* vp, int Lk, int DV, _Float16* vt, hipStream_t s) {
+    const int LkPad = attn_lkpad(Lk);
+    TD_LAUNCH(k_attn_vt_h, dim3(LkPad / 64, DV / 64), dim3(256), 64 * 65 * 4, s, vp, vt, Lk, LkPad, DV);
+}
+// vt: workspace of DV * attn_lkpad(Lk) halfs (the caller's; filled here from vp on the same stream unless vt_ready says it already holds a.vp)
+static inline int attn_launch_h(const AttnArgs& a, int DV, _Float16* vt, hipStream_t s, bool vt_ready = false) {
     const int LkPad = attn_lkpad(a.Lk);
     if (DV != 128 && (DV < 512 || DV % 512)) return -1;
-    TD_LAUNCH(k_attn_vt_h, dim3(LkPad / 64, DV / 64), dim3(256), 64 * 65 * 4, s, a.vp, vt, a.Lk, LkPad, DV);
+    if (!vt_ready) attn_prepare_vt_h(a.vp, a.Lk, DV, vt, s);
     AttnArgsH h;
     h.q = a.q; h.k = a.k; h.vt = vt; h.bias = a.bias; h.resid = a.resid; h.out = a.out; h.Lq = a.Lq; h.Lk = a.Lk; h.LkPad = LkPad;
     h.scale_log2e = a.scale_log2e; h.ln_part = a.ln_part; h.ldv = DV;

@@ -43,11 +43,6 @@ struct ConvArgs {
     int act;              // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
     int tiles_n;          // CoutPad / BN
     int nbatch;           // > 1: batched 1x1 GEMMs (Winograd), see k_conv_igemm
-    // Row-parity sub-map (fp16 LDS-DMA kernels of td_conv_hd.h only; 0 = off): the conv runs on the rows y = ny i + cy of a map -- `in`,
-    // `resid`, `out` point at row cy, H is the number of such rows, rp = ny W is the pitch between them in pixels, dy = dil / ny the
-    // kernel's row dilation counted in sub-map rows (columns keep `dil` and `pad`).  A dilated conv with ny | dil maps such a row class onto
-    // itself (td_frame.h run_parity_chains_h).
-    int rp = 0, dy = 0;
 };
 
 // bijective "block b runs on XCD b%8" -> contiguous range of tiles per XCD (cdna_hip_programming.md T1)

@@ -38,10 +38,9 @@ TD_DEV f16x8 td_cvt8(f32x4 lo, f32x4 hi) {
 
 // Epilogue of the fp16-MFMA kernels: out[m][n] = act(acc + bias[n] (+ resid[m][n])), resid fp16 when RES16, out fp16 when OUT16.
 // Same lane-pair exchange as td_store_acc (NT == 2): a lane ends up with 4 consecutive channels of one row.
-// PITCH (the row-parity sub-maps of the LDS-DMA kernels, ConvArgs.rp): tile row m = oy W + ox lives at pixel oy RP + ox of out / resid.
-template <int MT, int NT, bool OUT16, bool RES16, bool PITCH = false>
+template <int MT, int NT, bool OUT16, bool RES16>
 TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float* bias, const void* residv, int M, int N, int act,
-                           int m_base, int n_base, int lane, int W = 0, int RP = 0) {
+                           int m_base, int n_base, int lane) {
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int half = lane >> 5, l31 = lane & 31;
     const float slope = td_act_slope(act);
@@ -50,15 +49,13 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
     _Float16* outh = reinterpret_cast<_Float16*>(outv);
     const float* resf = reinterpret_cast<const float*>(residv);
     const _Float16* resh = reinterpret_cast<const _Float16*>(residv);
-    static_assert(!PITCH || NT == 2, "pitched stores: the lane-pair epilogue only");
-    if (PITCH || (NT == 2 && (N & 3) == 0 && ((((size_t)outv) | ((size_t)residv)) & 15) == 0 && (size_t)(M + 128) * N < (1u << 29))) {   // wave-uniform
+    if (NT == 2 && (N & 3) == 0 && ((((size_t)outv) | ((size_t)residv)) & 15) == 0 && (size_t)(M + 128) * N < (1u << 29)) {   // wave-uniform
         // as td_store_acc16 (td_conv.h): buffer-addressed, the 8 residual vectors of a 32-row group requested together, no predicates
         const int odd = l31 & 1;
         const int chan = n_base + 4 * (l31 >> 1);
         const bool cok = chan < N;
         constexpr unsigned EO = OUT16 ? 2u : 4u, ER = RES16 ? 2u : 4u;
-        // PITCH: the buffers end with the last pixel of the last sub-map row; a row m >= M lands at pixel >= Hc RP, past that end
-        const unsigned elems = PITCH ? ((unsigned)(M / W - 1) * (unsigned)RP + (unsigned)W) * (unsigned)N : (unsigned)M * (unsigned)N;
+        const unsigned elems = (unsigned)M * (unsigned)N;
         const TdBuf out_buf = td_make_buf(outf, elems * EO);
         const TdBuf res_buf = td_make_buf(resf, residv ? elems * ER : 0u);
         const TdBuf bias_buf = td_make_buf(bias, (unsigned)N * 4u);
@@ -74,21 +71,10 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             f32x4 rv[8];
-            unsigned prow[8];                                          // PITCH: element offset of the row's pixel relative to the un-pitched one
-            if constexpr (PITCH) {
-                const int mb = m_base + 4 * half + odd + i * 32;       // one division per 32-row block; the rows below it wrap at most once when W >= 32
-                const int oy0 = mb / W, ox0 = mb - oy0 * W;
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const int r = 2 * rp, x = ox0 + (r & 3) + 8 * (r >> 2);
-                    const int q = W >= 32 ? (x >= W ? 1 : 0) : x / W;
-                    prow[rp] = (unsigned)((oy0 + q) * (RP - W)) * (unsigned)N;
-                }
-            }
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
                 const int r = 2 * rp;
-                const unsigned rows = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)N + (PITCH ? prow[rp] : 0u);
+                const unsigned rows = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)N;
                 if (RES16) {
                     const f16x4 rh = __builtin_bit_cast(f16x4, td_buf_ld2(res_buf, base_r + rows * ER, 0u));
 #pragma unroll
@@ -107,7 +93,7 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
                 v = v + bv + rv[rp];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = activate(v[e]);
-                const unsigned rows = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)N + (PITCH ? prow[rp] : 0u);
+                const unsigned rows = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)N;
                 if (OUT16) {
                     f16x4 oh;
 #pragma unroll

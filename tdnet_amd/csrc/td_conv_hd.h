@@ -90,24 +90,23 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
 
     // ---- DMA geometry: A piece j of this wave = rows 8 (wave + NW j) .. + 7; lane l -> row + (l >> 3), LDS slot l & 7, which holds
     // the channels 8 kq .. 8 kq + 7 of the chunk with kq = slot ^ ((row >> 1) & 7) ------------------------------------------------
-    const int RP = p.rp ? p.rp : p.W, dyr = p.rp ? p.dy : p.dil, pady = p.rp ? (KS / 2) * p.dy : p.pad;   // row-parity sub-map (ConvArgs.rp)
     unsigned a_off[NA], a_taps[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const int row = 8 * (wave + NW * j) + (lane >> 3);
         const int m = m0 + row;
         const int oy = m / p.Wo, ox = m - oy * p.Wo;
-        const int by = (m < p.M) ? oy * p.stride - pady : -(1 << 28), bx = ox * p.stride - p.pad;
+        const int by = (m < p.M) ? oy * p.stride - p.pad : -(1 << 28), bx = ox * p.stride - p.pad;
         const int kq = (lane & 7) ^ ((row >> 1) & 7);
-        a_off[j] = (((unsigned)by * (unsigned)RP + (unsigned)bx) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+        a_off[j] = (((unsigned)by * (unsigned)p.W + (unsigned)bx) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
         a_taps[j] = 0u;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
-            const int iy = by + (t / KS) * dyr, ix = bx + (t % KS) * p.dil;
+            const int iy = by + (t / KS) * p.dil, ix = bx + (t % KS) * p.dil;
             a_taps[j] |= ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (1u << t) : 0u;
         }
     }
-    const TdBuf in_buf = td_make_buf(p.in, ((unsigned)(p.H - 1) * (unsigned)RP + (unsigned)p.W) * (unsigned)p.Cin * 2u);
+    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
     const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
     // B piece pb = (BN / 64) kq + q (64 consecutive packed slots of k-group kq); this wave stages pb = wave + NW jb
@@ -129,8 +128,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
     auto issue_begin = [&]() {
         i_live = l_step < p.nsteps;
         const int ky = l_tap / KS;
-        const int dy = ky * dyr, dx = (l_tap - ky * KS) * p.dil;
-        i_delta = (unsigned)((dy * RP + dx) * p.Cin + l_chunk * 64) * 2u;
+        const int dy = ky * p.dil, dx = (l_tap - ky * KS) * p.dil;
+        i_delta = (unsigned)((dy * p.W + dx) * p.Cin + l_chunk * 64) * 2u;
         i_wsoff = (unsigned)(i_live ? l_step : 0) * w_step_bytes;
     };
     auto issue_piece = [&](int buf, int pc) {                         // pc: compile-time piece number of this wave, 0..NPW-1
@@ -231,8 +230,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
     TD_WAIT_VM_PIECES(0);                                             // the surplus pieces must not land in an LDS that has been handed on
 
     if constexpr (NB == 1) {
-        if (p.rp) td_store_acc_h<MI, 2, OUT16, true, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane, p.Wo, p.rp);
-        else td_store_acc_h<MI, 2, OUT16, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+        td_store_acc_h<MI, 2, OUT16, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
     } else if constexpr (MI == 2) {
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) {                            // each 64-slot group is one wave-column of the weight packing: its own epilogue
@@ -241,8 +239,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h(ConvArgs p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) part[i][nt] = acc[i][2 * sb + nt];
-            if (p.rp) td_store_acc_h<2, 2, OUT16, true, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane, p.Wo, p.rp);
-            else td_store_acc_h<2, 2, OUT16, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane);
+            td_store_acc_h<2, 2, OUT16, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane);
         }
     }
 }
@@ -285,7 +282,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h3(ConvArgs p) {
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * G::BN;
     const int d = p.dil, Wh = p.W + 2 * d;
-    const int RP = p.rp ? p.rp : p.W, dyr = p.rp ? p.dy : d;           // row-parity sub-map (ConvArgs.rp): row pitch in pixels, row dilation
     const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
     const int gs0 = oy0 * Wh + ox0;                                   // halo-linear index of image slot 0
     const int S = BM + 2 * d * ((BM - 2) / p.W + 2);                  // slots any tile can need
@@ -298,13 +294,13 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h3(ConvArgs p) {
         const int gs = gs0 + sl;
         const int r = gs / Wh, ix = gs - r * Wh - d;
         const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-        a_base[j] = (((unsigned)r * (unsigned)RP + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+        a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
         const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
         a_ok[j] = 0u;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * dyr) < (unsigned)p.H) ? (1u << ky) : 0u;
+        for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
     }
-    const TdBuf in_buf = td_make_buf(p.in, ((unsigned)(p.H - 1) * (unsigned)RP + (unsigned)p.W) * (unsigned)p.Cin * 2u);
+    const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
     const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
     unsigned b_off[NBW];
@@ -317,7 +313,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h3(ConvArgs p) {
     const int nsuper = p.nsteps / 3;
     auto issue_image_piece = [&](int u, int j) {                      // piece j of the image of super-step u (chunk u / 3, kernel row u % 3)
         const int chunk = u / 3, ky = u - chunk * 3;
-        const int delta = (((ky - 1) * dyr * RP) * p.Cin + chunk * 64) * 2;
+        const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
         const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
         td_buf_ld16_lds(in_buf, smem + (u & 1) * G3::IMG_BYTES + (wave + NW * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
     };
@@ -516,8 +512,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h3(ConvArgs p) {
     TD_WAIT_VM_PIECES(0);                                             // the surplus (zero-fill) pieces must not land in an LDS that has been handed on
 
     if constexpr (NB == 1) {
-        if (p.rp) td_store_acc_h<MI, 2, OUT16 != 0, true, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane, p.W, p.rp);
-        else td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+        td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
     } else if constexpr (MI == 2) {
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) {
@@ -526,8 +521,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256 * RH / MI, 1) k_conv_dma_h3(ConvArgs p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) part[i][nt] = acc[i][2 * sb + nt];
-            if (p.rp) td_store_acc_h<2, 2, OUT16 != 0, true, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane, p.W, p.rp);
-            else td_store_acc_h<2, 2, OUT16 != 0, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane);
+            td_store_acc_h<2, 2, OUT16 != 0, true>(part, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 64, n0 + wn * 64 * NB + sb * 64, lane);
         }
     }
 }
@@ -611,7 +605,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * G::BN;
     const int d = p.dil, Wh = p.W + 2 * d;
-    const int RP = p.rp ? p.rp : p.W, dyr = p.rp ? p.dy : d;           // row-parity sub-map (ConvArgs.rp): row pitch in pixels, row dilation
     const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
     const int gs0 = oy0 * Wh + ox0;                                   // halo-linear index of image slot 0
     const int S = BM + 2 * d * ((BM - 2) / p.W + 2);                  // slots any tile can need
@@ -627,13 +620,13 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p
             const int gs = gs0 + sl;
             const int r = gs / Wh, ix = gs - r * Wh - d;
             const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-            a_base[j] = (((unsigned)r * (unsigned)RP + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
             const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
             a_ok[j] = 0u;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * dyr) < (unsigned)p.H) ? (1u << ky) : 0u;
+            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
         }
-        const TdBuf in_buf = td_make_buf(p.in, ((unsigned)(p.H - 1) * (unsigned)RP + (unsigned)p.W) * (unsigned)p.Cin * 2u);
+        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
         const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
         const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
         unsigned b_off[WPP];
@@ -644,7 +637,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p
         }
         auto issue_image_piece = [&](int u, int j) {                  // u: super-step = (64-channel chunk, kernel row)
             const int chunk = u / 3, ky = u - chunk * 3;
-            const int delta = (((ky - 1) * dyr * RP) * p.Cin + chunk * 64) * 2;
+            const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
             const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
             td_buf_ld16_lds(in_buf, smem + (u & 1) * GP::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
         };
@@ -754,8 +747,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH * (2 / MI) + NP), 1) k_conv_dma_h3p
         TD_BARRIER_RAW();
         TD_P_STAMP(3 * u + 2, 3);
     }
-    if (p.rp) td_store_acc_h<MI, 2, OUT16 != 0, true, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane, p.W, p.rp);
-    else td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    td_store_acc_h<MI, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * 32 * MI, n0 + wn * 64, lane);
 }
 template <int RH, int MI, int NP, int IP>
 static inline bool conv_launch_dma3p_t(const ConvArgs& a, bool out16, hipStream_t s) {
@@ -809,7 +801,6 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * GN::BN;
     const int d = p.dil, Wh = p.W + 2 * d;
-    const int RP = p.rp ? p.rp : p.W, dyr = p.rp ? p.dy : d;           // row-parity sub-map (ConvArgs.rp): row pitch in pixels, row dilation
     const int oy0 = m0 / p.W, ox0 = m0 - oy0 * p.W;
     const int gs0 = oy0 * Wh + ox0;
     const int S = BM + 2 * d * ((BM - 2) / p.W + 2);
@@ -824,13 +815,13 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
             const int gs = gs0 + sl;
             const int r = gs / Wh, ix = gs - r * Wh - d;
             const int kq = (lane & 7) ^ ((sl >> 1) & 7);
-            a_base[j] = (((unsigned)r * (unsigned)RP + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
+            a_base[j] = (((unsigned)r * (unsigned)p.W + (unsigned)ix) * (unsigned)p.Cin + (unsigned)kq * 8u) * 2u;
             const bool xok = (unsigned)ix < (unsigned)p.W && sl < S;
             a_ok[j] = 0u;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * dyr) < (unsigned)p.H) ? (1u << ky) : 0u;
+            for (int ky = 0; ky < 3; ++ky) a_ok[j] |= (xok && (unsigned)(r + (ky - 1) * d) < (unsigned)p.H) ? (1u << ky) : 0u;
         }
-        const TdBuf in_buf = td_make_buf(p.in, ((unsigned)(p.H - 1) * (unsigned)RP + (unsigned)p.W) * (unsigned)p.Cin * 2u);
+        const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 2u);
         const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
         const unsigned w_step_bytes = 8u * (unsigned)p.CoutPad * 16u;
         unsigned b_off[WPP];
@@ -838,7 +829,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
         for (int jb = 0; jb < WPP; ++jb) b_off[jb] = (unsigned)((pw + NP * jb) * p.CoutPad + n0 + lane) * 16u;   // piece = k-group kq: 64 packed slots
         auto issue_image_piece = [&](int u, int j) {
             const int chunk = u / 3, ky = u - chunk * 3;
-            const int delta = (((ky - 1) * dyr * RP) * p.Cin + chunk * 64) * 2;
+            const int delta = (((ky - 1) * d * p.W) * p.Cin + chunk * 64) * 2;
             const bool ok = u < nsuper && ((a_ok[j] >> ky) & 1u) != 0u;
             td_buf_ld16_lds(in_buf, smem + (u & 1) * GN::IMG_BYTES + (pw + NP * j) * 1024, ok ? a_base[j] + (unsigned)delta : TD_BUF_OOB, 0u);
         };
@@ -919,8 +910,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
         mma(std::integral_constant<int, 2>{}, img, wbase + 2 * GN::B_BYTES);
         TD_BARRIER_RAW();
     }
-    if (p.rp) td_store_acc_h<1, 2, OUT16 != 0, true, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wave * 32, n0, lane, p.W, p.rp);
-    else td_store_acc_h<1, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wave * 32, n0, lane);
+    td_store_acc_h<1, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wave * 32, n0, lane);
 }
 template <int RH, int NP, int IP>
 static inline bool conv_launch_dma3n_t(const ConvArgs& a, bool out16, hipStream_t s) {

@@ -48,6 +48,13 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s, float* vp, int e
     } else {
         TD_TRY(run_conv(n, L.atn[0].fc, n->slots[e0].v, 1, n->Lk, nullptr, vp, c));
     }
+    // fp16 mode: the final attention reads V' re-tiled and rounded to fp16 (td_attn_h.h).  That pass depends on V' alone: it runs HERE, on
+    // the side stream under the backbone, not in front of the final attention on the critical path (round 5: one 7-us kernel + a boundary)
+    if (n->vt16) {
+        prof_begin(n, 2, false, 0, c);
+        attn_prepare_vt_h(vp, n->Lk, DV, n->vt16, c);
+        prof_end(n, c);
+    }
     TD_HIP(hipEventRecord(n->ev_join, c));
     return 0;
 }
@@ -70,38 +77,11 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
     prof_end(n, s);
     return 0;
 }
-// The same run in the fp16 mode (tdnet_opts.precision = 1, round 5): the convs are DIRECT fp16 LDS-DMA convs, each launched on one row
-// class of its map (td_launch.h run_conv_rows_h: a half-height map with twice the row pitch; identical products, bit-identical rows).  A
-// conv of a small map is a grid of ~230 workgroups of one K-loop latency chain each and a kernel boundary costs a tenth of it; two chains
-// on two hardware queues put one chain's ramp-down / dispatch / ramp-up under the other's K loops.  The last conv of the backbone writes
-// the fp32 c4 (its residual is an fp16 map), as in the unchained sequence.
-static int run_parity_chains_h(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
-    const int sb = n->seg_block, nblk = (int)L.blocks.size();
-    hipStream_t st[2] = {s, n->chain2};
-    {   // the part of the first block that precedes the run: its downsample, and conv1 when the run starts at conv2
-        BlockLayers& B = L.blocks[sb];
-        if (n->seg_conv == 1) TD_TRY(run_conv(n, B.c1, n->bx, h, w, nullptr, n->seg_t[sb], s));
-        if (B.has_ds) TD_TRY(run_conv(n, B.ds, n->bx, h, w, nullptr, n->seg_r[sb], s));
-    }
-    TD_HIP(hipEventRecord(n->ev_cfork, s));
-    TD_HIP(hipStreamWaitEvent(n->chain2, n->ev_cfork, 0));
-    for (int b = sb; b < nblk; ++b) {
-        BlockLayers& B = L.blocks[b];
-        const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
-        for (int c = 0; c < 2; ++c) {
-            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_conv_rows_h(n, B.c1, xin, h, w, nullptr, n->seg_t[b], 2, c, st[c]));
-            if (B.has_ds && b > sb) TD_TRY(run_conv_rows_h(n, B.ds, xin, h, w, nullptr, n->seg_r[b], 2, c, st[c]));
-        }
-        for (int c = 0; c < 2; ++c)
-            TD_TRY(run_conv_rows_h(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], 2, c, st[c]));
-    }
-    TD_HIP(hipEventRecord(n->ev_cjoin, n->chain2));
-    TD_HIP(hipStreamWaitEvent(s, n->ev_cjoin, 0));
-    return 0;
-}
-
+// (Round 5 also ran this run in the fp16 mode -- the direct fp16 LDS-DMA convs on the two row classes of their maps, two chains on two
+// streams, bit-identical -- and measured 1121 -> 1050 frames/s at 720x960: a half-height conv takes exactly as long as the whole one (a
+// workgroup's time is its K-loop latency chain; the chip has CUs to spare either way), the two chains run in lockstep, nothing overlaps.
+// profiles/r05a_*row_parity_chains*; removed, last commit with that code: 8dff3b9.)
 static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
-    if (n->act16) return run_parity_chains_h(n, L, h, w, s);
     const int sb = n->seg_block, nblk = (int)L.blocks.size();
     hipStream_t st[2] = {s, n->chain2};
     float* Vw[2] = {n->wino_v, n->wino_v2};
@@ -116,21 +96,15 @@ static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t 
     for (int b = sb; b < nblk; ++b) {
         BlockLayers& B = L.blocks[b];
         const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
-        // chain c = the rows of parity c.  A conv whose layer asks for four classes (overlap bit 64: rows mod 4, dilation a multiple of 4) runs
-        // the classes c and c + 2 one after the other on chain c's stream, each class transform -> GEMMs -> transform through the chain's workspaces
         for (int c = 0; c < 2; ++c) {
-            if (!(b == sb && n->seg_conv == 1))
-                for (int cy = c; cy < B.c1.chunks; cy += 2) {
-                    WinoChunk ck; ck.ny = B.c1.chunks; ck.cy = cy;
-                    TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
-                }
+            WinoChunk ck; ck.ny = 2; ck.cy = c;
+            if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
             if (B.has_ds && b > sb) TD_TRY(run_ds_rows(n, B.ds, xin, h, w, n->seg_r[b], 2, c, st[c]));
         }
-        for (int c = 0; c < 2; ++c)
-            for (int cy = c; cy < B.c2.chunks; cy += 2) {
-                WinoChunk ck; ck.ny = B.c2.chunks; ck.cy = cy;
-                TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c]));
-            }
+        for (int c = 0; c < 2; ++c) {
+            WinoChunk ck; ck.ny = 2; ck.cy = c;
+            TD_TRY(run_wino(n, B.c2, n->seg_t[b], h, w, B.has_ds ? n->seg_r[b] : xin, n->seg_x[b], st[c], nullptr, ck, Vw[c], Mw[c]));
+        }
     }
     TD_HIP(hipEventRecord(n->ev_cjoin, n->chain2));
     TD_HIP(hipStreamWaitEvent(s, n->ev_cjoin, 0));
@@ -201,17 +175,22 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     TD_TRY(run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, qs));
     TD_TRY(run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, qs));
     TD_TRY(run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, qs));
-    prof_begin(n, 2, false, 0, qs);
-    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, qs, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
-    prof_end(n, qs);
-    if (beside) {
+    if (!beside) {                                                    // one stream: both cache entries (q_, v_) in one launch
+        prof_begin(n, 2, false, 0, s);
+        TD_LAUNCH(k_subsample2, dim3(td_grid_for((long)n->Lk * (16 + DV / 4))), dim3(256), 0, s, (const float*)n->q_cur, cs.q, 64, (const float*)n->v_cur, cs.v, DV,
+                  n->w, n->hk, n->wk, 4);
+        prof_end(n, s);
+    } else {
+        prof_begin(n, 2, false, 0, qs);
+        TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * 16)), dim3(256), 0, qs, (const float*)n->q_cur, cs.q, n->w, 64, n->hk, n->wk, 4);
+        prof_end(n, qs);
         TD_HIP(hipEventRecord(n->ev_join2, qs));
         TD_TRY(run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s));
+        prof_begin(n, 2, false, 0, s);
+        TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
+        prof_end(n, s);
+        TD_HIP(hipStreamWaitEvent(s, n->ev_join2, 0));
     }
-    prof_begin(n, 2, false, 0, s);
-    TD_LAUNCH(k_subsample, dim3(td_grid_for((long)n->Lk * (DV / 4))), dim3(256), 0, s, (const float*)n->v_cur, cs.v, n->w, DV, n->hk, n->wk, 4);
-    prof_end(n, s);
-    if (beside) TD_HIP(hipStreamWaitEvent(s, n->ev_join2, 0));
     n->pending_slot = slot;
     return n->failed ? -1 : 0;
 }
@@ -228,7 +207,7 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
         const AtnLayer& A = L.atn[n->P == 4 ? 2 : 0];                   // td4_psp18.py:147 / td2_psp50.py:120
         stats_nstr = (n->opts.fusion & 2) ? attn_strips(n->Lq, DV) : 0;                                         // LayerNorm strip statistics from the epilogue
         if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention,
-                          stats_nstr ? n->ln_part : nullptr)) return -1;                                                  // v4 + v_cur
+                          stats_nstr ? n->ln_part : nullptr, nullptr, false, /*vt_ready=*/n->vt16 != nullptr)) return -1;       // v4 + v_cur
         feat = n->feat;
     }
     // (warm-up, td4_psp18.py:142-143: feat = v_cur -- read in place; rounds 1-4 copied it into n->feat, a device copy per warm-up frame)

@@ -151,7 +151,6 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     d.overlap = d.overlap < 0 ? 0 : d.overlap & TDNET_OVERLAP_MASK;
     if (((d.overlap >> 4) & 3) == 3) d.overlap &= ~0x30;
     d.reserved0 = 0;
-    d.chain_rows = (d.chain_rows >= 2 && d.chain_rows <= 4) ? d.chain_rows : 0;
     for (int& r : d.reserved) r = 0;
     return d;
 }

@@ -129,30 +129,6 @@ static void launch_conv_dma_forms(const ConvLayer& L, const ConvArgs& a, hipStre
     if (!done && (L.rowimg_off || !conv_launch_dma3(a, rh, L.KS, L.out16, s))) conv_launch_dma(a, rh, L.KS, L.out16, s);
 }
 
-// The fp16 LDS-DMA conv of layer L (stride 1, fp16 maps in and out of HBM) on the image rows y = ny i + cy ONLY: a sub-map of
-// ceil((H - cy) / ny) rows with the row pitch ny W and the row dilation dil / ny (td_conv.h ConvArgs.rp / dy).  With ny | dil the conv
-// maps such a row class onto itself, so the classes of a run of convs are independent chains (td_frame.h run_parity_chains_h).  Same
-// kernels, same products in the same order as the whole-map conv: the rows it writes are bit-identical.
-static int run_conv_rows_h(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, int ny, int cy, hipStream_t s) {
-    if (!L.h16 || !L.rh || !L.in16 || L.stride != 1 || L.stem || (L.KS == 3 && L.dil % ny) || (L.KS != 1 && L.KS != 3))
-        return td_fail("internal: this conv cannot run on a row class of its map");
-    const int Hc = (H - cy + ny - 1) / ny;
-    if (Hc <= 0) return 0;
-    const size_t in_row = (size_t)cy * W * L.Cin, out_row = (size_t)cy * W * L.Cout;   // in ELEMENTS; the maps are fp16 except a fp32 output (out16 false)
-    const _Float16* in_h = reinterpret_cast<const _Float16*>(in) + in_row;
-    const _Float16* res_h = resid ? reinterpret_cast<const _Float16*>(resid) + out_row : nullptr;
-    void* out_p = L.out16 ? (void*)(reinterpret_cast<_Float16*>(out) + out_row) : (void*)(out + out_row);
-    ConvArgs a;
-    a.in = reinterpret_cast<const float*>(in_h); a.wp = L.d_wp; a.bias = L.d_bias; a.resid = reinterpret_cast<const float*>(res_h); a.out = reinterpret_cast<float*>(out_p);
-    a.H = Hc; a.W = W; a.Cin = L.Cin; a.Wo = W; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.stride = 1; a.dil = L.dil; a.pad = L.pad; a.M = Hc * W; a.nsteps = L.nsteps; a.act = L.act; a.tiles_n = 0; a.nbatch = 1;
-    a.rp = ny * W; a.dy = L.KS == 3 ? L.dil / ny : 1;
-    prof_begin(n, 0, L.KS == 3 ? 1 | 4 : 0, L.flops_per_pixel() * a.M, s);
-    launch_conv_dma_forms(L, a, s);
-    prof_end(n, s);
-    return 0;
-}
-
 // out[Ho*Wo][Cout] = act(conv(in[H][W][Cin]) + bias (+ resid))
 static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
                     int* Ho_out = nullptr, int* Wo_out = nullptr, const LnFuse* lnf = nullptr) {
@@ -196,7 +172,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
                          int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,
-                         _Float16* vt16 = nullptr, bool slices = false) {
+                         _Float16* vt16 = nullptr, bool slices = false, bool vt_ready = false) {
     if (n && n->vt16) vt16 = n->vt16;
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
@@ -204,7 +180,7 @@ static int run_attention(tdnet* n, const float* q, const float* k, const float* 
     a.ln_part = ln_part; a.ln_nstr = 0;
     if (n && (probe_skip() & 4) && Lq > Lk) return 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
+    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s, vt_ready) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);
     return 0;
@@ -235,11 +211,9 @@ static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int 
                     float* rowpart, float* pooled, float* ppmfeat, float* z, hipStream_t s) {
     prof_begin(n, 2, false, 0, s);
     const PpmAtoms at = ppm_atoms(w);                                 // the row is read once: atoms between the bin edges of all four levels
-    TD_LAUNCH(k_ppm_rowsum, dim3(h * at.n), dim3(C / 4), 0, s, c4, rowpart, w, C, at);
-    float* rowbins = rowpart + (size_t)h * 24 * C;                    // [h][12][C] behind the (at most 23) atoms per row
-    TD_LAUNCH(k_ppm_rowbins, dim3(h * 12), dim3(C / 4), 0, s, (const float*)rowpart, rowbins, C, at);
-    TD_LAUNCH(k_ppm_bins, dim3(50), dim3(C / 4), 0, s, (const float*)rowbins, pooled, h, w, C);
-    TD_LAUNCH(k_ppm_conv, dim3(50 * (FS / 64)), dim3(256), 256 * 4, s, (const float*)pooled, wgt, bias, ppmfeat, C, FS);
+    (void)pooled;
+    TD_LAUNCH(k_ppm_rowbins, dim3(h * ((C + 511) / 512)), dim3(1024), at.n * 512 * 4, s, c4, rowpart, w, C, at);   // rowpart: [h][12][C] row bins
+    TD_LAUNCH(k_ppm_pool_conv, dim3(50 * (FS / 64)), dim3(256), (256 + C) * 4, s, (const float*)rowpart, wgt, bias, ppmfeat, h, w, C, FS);
     TD_LAUNCH(k_ppm_assemble, dim3(td_grid_for((long)h * w * (C / 4))), dim3(256), 0, s, c4, (const float*)ppmfeat, z, h, w, C,
               pid * XS, XS, FS);
     prof_end(n, s);

@@ -179,59 +179,66 @@ static inline PpmAtoms ppm_atoms(int w) {
         }
     return a;
 }
-// grid = h rows x at.n atoms, block = C/4 threads; rowpart [h][at.n][C]
-TD_KERNEL void k_ppm_rowsum(const float* __restrict__ c4, float* __restrict__ rowpart, int w, int C, PpmAtoms at) {
-    const int y = blockIdx.x / at.n, a = blockIdx.x % at.n, cv = threadIdx.x;
-    const float* row = c4 + (size_t)y * w * C + cv * 4;
-    const int lo = at.edge[a], hi = at.edge[a + 1];
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+// One launch per ROW GROUP (round 5; rounds 2-4: k_ppm_rowsum + k_ppm_rowbins, two launches through a [h][atoms][C] buffer in HBM).
+// grid = h rows x C / 512 channel groups, block = 1024 = 128 channel vectors x 8 atom slots: thread (cv, as) sums the atoms as, as + 8,
+// ... of its row for its four channels (an atom = a run of columns, summed left to right) into LDS, then the 12 x-bins of the row are
+// runs of consecutive atoms, added in atom order.  Same sums in the same order as the two kernels it replaces: bit-identical rowbins.
+TD_KERNEL void TD_LAUNCH_BOUNDS(1024, 1) k_ppm_rowbins(const float* __restrict__ c4, float* __restrict__ rowbins, int w, int C, PpmAtoms at) {
+    TD_DYN_LDS(smem);
+    float* atoms = reinterpret_cast<float*>(smem);                 // [at.n][512]
+    const int groups = (C + 511) / 512, y = blockIdx.x / groups, cg = blockIdx.x % groups;
+    const int cv = threadIdx.x & 127, as = threadIdx.x >> 7, c = cg * 512 + cv * 4;
+    const bool cok = c < C;
+    const float* row = c4 + (size_t)y * w * C + c;
+    for (int a = as; a < at.n; a += 8) {
+        const int lo = at.edge[a], hi = at.edge[a + 1];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (cok) {
 #pragma unroll 8
-    for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
-    td_st4(rowpart + ((size_t)y * at.n + a) * C + cv * 4, s);
+            for (int x = lo; x < hi; ++x) s = s + td_ld4(row + (size_t)x * C);
+        }
+        td_st4(atoms + a * 512 + cv * 4, s);
+    }
+    __syncthreads();
+    for (int b = as; b < 12; b += 8) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int a = at.lo[b]; a < at.hi[b]; ++a) s = s + td_ld4(atoms + a * 512 + cv * 4);
+        if (cok) td_st4(rowbins + ((size_t)y * 12 + b) * C + c, s);
+    }
 }
-// grid = h rows x 12 x-bins, block = C/4: rowbins [h][12][C] = the bin's run of atoms (at most 23 loads, all in flight together)
-TD_KERNEL void k_ppm_rowbins(const float* __restrict__ rowpart, float* __restrict__ rowbins, int C, PpmAtoms at) {
-    const int y = blockIdx.x / 12, b = blockIdx.x % 12, cv = threadIdx.x;
-    const int alo = at.lo[b], ahi = at.hi[b];
-    const TdBuf buf = td_make_buf(rowpart + (size_t)y * at.n * C, (unsigned)at.n * (unsigned)C * 4u);
-    f32x4 v[23];
-#pragma unroll
-    for (int k = 0; k < 23; ++k) v[k] = td_buf_ld4(buf, alo + k < ahi ? ((unsigned)(alo + k) * (unsigned)C + (unsigned)cv * 4u) * 4u : TD_BUF_OOB, 0u);
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 23; ++k) s = s + v[k];                        // atoms past the bin read as zeros
-    td_st4(rowbins + ((size_t)y * 12 + b) * C + cv * 4, s);
-}
-// grid = 50 bins, block = C/4; pooled [50][C] = mean over the bin.  bin order: level-major, then by, then bx.
-TD_KERNEL void k_ppm_bins(const float* __restrict__ rowbins, float* __restrict__ pooled, int h, int w, int C) {
-    int bin = blockIdx.x, o = 1, xoff = 0;
-    if (bin >= 14) { o = 6; xoff = 6; bin -= 14; }
-    else if (bin >= 5) { o = 3; xoff = 3; bin -= 5; }
-    else if (bin >= 1) { o = 2; xoff = 1; bin -= 1; }
-    const int by = bin / o, bx = bin % o, cv = threadIdx.x;
-    const int ylo = td_bin_lo(by, h, o), yhi = td_bin_hi(by, h, o);
-    const int cnt = (yhi - ylo) * (td_bin_hi(bx, w, o) - td_bin_lo(bx, w, o));
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowbins + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
-    td_st4(pooled + (size_t)blockIdx.x * C + cv * 4, s * (1.0f / (float)cnt));
-}
-// pyramid 1x1 conv (BN folded) + ReLU on the 50 pooled vectors, only the FS channels this path keeps:
-// feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][c][f] pooled[bin][c]).  grid = 50 bins x FS/64 channel groups, block = 256:
-// thread (f, slice) sums a quarter of the input channels with 8 loads in flight, LDS combines the four slices in a fixed order.
-TD_KERNEL void k_ppm_conv(const float* __restrict__ pooled, const float* __restrict__ wgt, const float* __restrict__ bias,
-                          float* __restrict__ feat, int C, int FS) {
+// Pooling + pyramid 1x1 conv in one launch (round 5; rounds 2-4: k_ppm_bins + k_ppm_conv through a [50][C] buffer in HBM).
+// grid = 50 bins x FS / 64 channel groups, block = 256.  Phase 1: the bin's mean over its rows of the row bins (bin order: level-major,
+// then by, then bx; rows added top to bottom) into LDS.  Phase 2: the pyramid conv (BN folded) + ReLU on that vector, only the FS channels
+// this path keeps: feat[bin][f] = relu(b[lvl][f] + sum_c W[lvl][c][f] pooled[c]) -- thread (f, slice) sums a quarter of the input channels
+// with 8 loads in flight, LDS combines the four slices in a fixed order.  Same arithmetic as the two kernels it replaces: bit-identical feat.
+TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* __restrict__ wgt, const float* __restrict__ bias,
+                               float* __restrict__ feat, int h, int w, int C, int FS) {
     TD_DYN_LDS(smem);
     float* red = reinterpret_cast<float*>(smem);               // [4][64]
+    float* pv = red + 256;                                      // [C]: the pooled vector of this bin
     const int groups = FS >> 6, bin = blockIdx.x / groups, fl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int f = (blockIdx.x % groups) * 64 + fl;
     const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
+    {
+        const int o = lvl == 0 ? 1 : lvl == 1 ? 2 : lvl == 2 ? 3 : 6, xoff = lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 3 : 6;
+        const int lb = bin - (lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 5 : 14);
+        const int by = lb / o, bx = lb % o;
+        const int ylo = td_bin_lo(by, h, o), yhi = td_bin_hi(by, h, o);
+        const int cnt = (yhi - ylo) * (td_bin_hi(bx, w, o) - td_bin_lo(bx, w, o));
+        for (int cv = threadIdx.x; cv < (C >> 2); cv += blockDim.x) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowbins + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
+            td_st4(pv + cv * 4, s * (1.0f / (float)cnt));
+        }
+    }
+    __syncthreads();
     const int cq = C >> 2;
     const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
-    const float* pv = pooled + (size_t)bin * C + sl * cq;
+    const float* pp = pv + sl * cq;
     float s = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pv[c], s);
+    for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pp[c], s);
     red[sl * 64 + fl] = s;
     __syncthreads();
     if (sl == 0) {
@@ -520,6 +527,21 @@ TD_KERNEL void k_subsample(const float* __restrict__ in, float* __restrict__ out
         const long pix = i / CV;
         const int ox = (int)(pix % wo), oy = (int)(pix / wo);
         td_st4(out + (size_t)pix * C + cv * 4, td_ld4(in + ((size_t)(oy * stride) * w + ox * stride) * C + cv * 4));
+    }
+}
+// Both cache entries of a frame in ONE launch (round 5): q_ = q_cur[::4, ::4] (C1 channels) and v_ = v_cur[::4, ::4] (C2 channels) --
+// Encoding(pre=True)'s q_ and v_ are the stride-4 sub-sample of the full-resolution projections (transformer.py:34-50).
+TD_KERNEL void k_subsample2(const float* __restrict__ in1, float* __restrict__ out1, int C1, const float* __restrict__ in2,
+                            float* __restrict__ out2, int C2, int w, int ho, int wo, int stride) {
+    const int CV1 = C1 >> 2, CV = (C1 + C2) >> 2;
+    const long total = (long)ho * wo * CV;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const long pix = i / CV;
+        const int ox = (int)(pix % wo), oy = (int)(pix / wo);
+        const size_t src = (size_t)(oy * stride) * w + ox * stride;
+        if (cv < CV1) td_st4(out1 + (size_t)pix * C1 + cv * 4, td_ld4(in1 + src * C1 + cv * 4));
+        else td_st4(out2 + (size_t)pix * C2 + (cv - CV1) * 4, td_ld4(in2 + src * C2 + (cv - CV1) * 4));
     }
 }
 // fp32 <-> fp16 copies (test entry tdnet_op_conv2d_f16io only: the product path never converts whole maps)

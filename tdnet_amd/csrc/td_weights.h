@@ -46,9 +46,6 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         return 0;
     }
     L.h16 = o.precision && !stem && Cin % 64 == 0;
-    // a conv inside the fp16 row-parity chains.  Its tile stays the one picked for the WHOLE map: the two chains run side by side, the chip sees
-    // the whole map's workgroups either way (tdnet_opts.chain_rows overrides, for A/B)
-    if (L.h16 && chunks > 1) L.chunks = chunks;
     const bool stem16 = o.precision && stem && KS == 7 && stride == 2 && Cout <= 64;    // fp16-MFMA stem (td_conv_h.h)
     const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && o.gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
     L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout, deep) : conv_pick_tile((int)M, Cout, deep);
@@ -204,27 +201,22 @@ static Folded fold(tdnet* n, const std::string& wkey, const std::string& bkey, c
 // EVEN dilation reads, for an output row y, only the input rows y + k * dil: rows of y's parity.  So from the first such conv to the end
 // of the backbone (ResNet-18/34: layer3.0.conv2 .. layer4.1.conv2, dilations 2,2,2,4,4,8,4 -- resnet.py:181-198) the even and the odd
 // rows are two INDEPENDENT chains of convs (residual adds and the 1x1 downsample are pixel-wise), each with half the Winograd tiles.
-static bool conv_chainable(int cin, int cout, int stride, int dil, const tdnet_opts& o) {
-    // precision 1: the direct fp16 LDS-DMA conv on a row class of its map (td_launch.h run_conv_rows_h); fp32: a Winograd chunk
-    if (o.precision) return stride == 1 && dil % 2 == 0 && cin % 64 == 0 && cout >= 128;
+static bool conv_chainable(int cin, int cout, int stride, int dil) {
     return stride == 1 && dil % 2 == 0 && cin >= 128 && cout >= 128 && gemm_supports(cin) && cout % 4 == 0;
 }
+// (fp32 Winograd convs only.  The fp16 mode's direct convs were tried as row classes too in round 5 and lost: td_frame.h.)
 static void plan_chains(tdnet* n) {
     n->seg_block = -1; n->seg_conv = 0;
     const tdnet_opts& o = n->opts;
-    if (!(o.overlap & 1) || n->deep) return;
-    if (o.precision) {
-        // small maps only by default: there a conv's grid leaves CUs idle and a kernel boundary is a tenth of a kernel
-        if ((o.fusion & 128) || (n->Lq > 16384 && !(o.overlap & 4))) return;
-    } else if (o.winograd < 3 || !o.gemm_persistent) return;
+    if (!(o.overlap & 1) || o.winograd < 3 || o.precision || !o.gemm_persistent || n->deep) return;
     int sb = -1, sc = 0;
     for (int b = (int)n->bspec.size() - 1; b >= 0; --b) {
         const BlockSpec& S = n->bspec[b];
-        if (S.bott || !conv_chainable(S.cout, S.cout, 1, S.dil2, o)) break;
+        if (S.bott || !conv_chainable(S.cout, S.cout, 1, S.dil2)) break;
         sb = b; sc = 1;
-        if (!conv_chainable(S.cin, S.cout, S.stride, S.dil1, o)) break;
+        if (!conv_chainable(S.cin, S.cout, S.stride, S.dil1)) break;
         sb = b; sc = 0;
-        if (S.ds && !(S.stride == 1 && (o.precision ? S.cin % 64 == 0 : gemm_supports(S.cin)))) break;   // an earlier start would put this block's downsample inside the chains
+        if (S.ds && !(S.stride == 1 && gemm_supports(S.cin))) break;   // an earlier start would put this block's downsample inside the chains
     }
     n->seg_block = sb; n->seg_conv = sc;
 }
@@ -277,7 +269,7 @@ static int alloc_workspace(tdnet* n) {
         n->wino_v_floats = vmax; n->wino_m_floats = mmax;
         if (vmax && (dev_alloc(&n->wino_v, vmax) || dev_alloc(&n->wino_m, mmax))) return -1;
         if (n->seg_block >= 0) {                                       // chain 1's own workspaces (a chunk is never larger than the conv) + the run's maps
-            if (vmax && (dev_alloc(&n->wino_v2, vmax) || dev_alloc(&n->wino_m2, mmax))) return -1;   // (fp16 chains: direct convs, no Winograd workspace)
+            if (dev_alloc(&n->wino_v2, vmax) || dev_alloc(&n->wino_m2, mmax)) return -1;
             const size_t nb = L0.blocks.size();
             n->seg_t.assign(nb, nullptr); n->seg_r.assign(nb, nullptr); n->seg_x.assign(nb, nullptr);
             for (size_t b = (size_t)n->seg_block; b < nb; ++b) {
@@ -343,9 +335,7 @@ static int finalize_block(tdnet* n) {
         int ch = n->H2, cw = n->W2;
         for (size_t bsi = 0; bsi < n->bspec.size(); ++bsi) {
             const BlockSpec& s = n->bspec[bsi];
-            // row classes of conv1 / conv2 inside the run: even / odd rows; with overlap bit 64 (fp32) rows mod 4 where the dilation allows
-            const bool mod4 = (n->opts.overlap & 64) && !n->opts.precision;
-            const int k1 = !in_chain(n, (int)bsi, 0) ? 1 : (mod4 && s.dil1 % 4 == 0) ? 4 : 2, k2 = !in_chain(n, (int)bsi, 1) ? 1 : (mod4 && s.dil2 % 4 == 0) ? 4 : 2;
+            const int k1 = in_chain(n, (int)bsi, 0) ? 2 : 1, k2 = in_chain(n, (int)bsi, 1) ? 2 : 1;   // row-parity chunks of conv1 / conv2
             BlockLayers B;
             const std::string bp = pre + "." + s.name;
             const int oh = out_size(ch, 3, s.stride, s.dil1, s.dil1), ow = out_size(cw, 3, s.stride, s.dil1, s.dil1);
@@ -368,8 +358,7 @@ static int finalize_block(tdnet* n) {
             B.has_ds = s.ds;
             if (s.ds) {
                 Folded fd = fold(n, bp + ".downsample.0.weight", "", bp + ".downsample.1", s.cout);
-                // (fp16 chains: the downsample of a block inside the run works on row classes too -- the first block's precedes the run)
-                if (make_conv_layer(B.ds, fd.w, fd.b, s.cout, s.cin, 1, s.stride, 1, 0, false, M, n->opts, -1, (n->opts.precision && (int)bsi > n->seg_block && k1 > 1) ? 2 : 1)) return -1;
+                if (make_conv_layer(B.ds, fd.w, fd.b, s.cout, s.cin, 1, s.stride, 1, 0, false, M, n->opts)) return -1;
             }
             L.blocks.push_back(B);
             ch = oh; cw = ow;
@@ -481,11 +470,7 @@ static int finalize_block(tdnet* n) {
                     // channels, k_conv_dma_h3n) -- half the weight bytes per K step and CU, the term that dominates there: 128 channels
                     // 13.8 -> 10.3 us, 256 channels 20.6 -> 19.8 us isolated (profiles/r04u_*).  No gain at 32768 pixels.
                     const bool same3 = c.KS == 3 && c.stride == 1 && c.pad == c.dil;
-                    if (c.chunks > 1 && n->opts.chain_rows)             // A/B hook: the tile of the convs inside the fp16 row-parity chains
-                        c.rh = !same3 ? (n->opts.chain_rows == 2 ? CD_128 : n->opts.chain_rows == 3 ? CD_192 : CD_256)
-                             : c.Cout <= 256 ? (n->opts.chain_rows == 2 ? CD_128_N : n->opts.chain_rows == 3 ? CD_192_N : CD_256_N)
-                                             : (n->opts.chain_rows == 2 ? CD_128_P : n->opts.chain_rows == 3 ? CD_192_P : CD_256_P);
-                    else if ((n->opts.fusion & 32768) && same3 && c.M_out <= 16384 && c.Cout <= 256)
+                    if ((n->opts.fusion & 32768) && same3 && c.M_out <= 16384 && c.Cout <= 256)
                         c.rh = c.Cout <= 128 ? CD_128_N : CD_192_N;       // (256 channels on 128 x 64 tiles as well: 2.1 % instead of 2.6 % in the frame)
                     else if (n->opts.fusion & 8192)                     // the 128- and 192-row tiles with four dedicated loader waves (k_conv_dma_h3p):
                         c.rh = c.rh == CD_128 ? CD_128_P : c.rh == CD_192 ? CD_192_P : c.rh;
@@ -499,22 +484,6 @@ static int finalize_block(tdnet* n) {
             // applied to the fp32 map while staging it -- and the conv runs on the LDS-DMA kernel (1024x2048: 77 -> 46 us).
             if (n->cfg.model != 1 && L.head3.h16 && !L.head3.wino) { L.head3.in16 = true; dma(L.head3); if (!L.head3.rh) L.head3.in16 = false; }
         }
-    // fp16 row-parity chains: every conv inside the run must be on the LDS-DMA kernels (the only ones that take a row class of a map)
-    if (n->opts.precision && n->seg_block >= 0) {
-        bool ok = n->act16;
-        for (auto& L : n->paths)
-            for (size_t bi = (size_t)n->seg_block; bi < L.blocks.size() && ok; ++bi) {
-                const BlockLayers& B = L.blocks[bi];
-                if (!((int)bi == n->seg_block && n->seg_conv == 1)) ok = ok && B.c1.rh != 0 && B.c1.chunks == 2;
-                ok = ok && B.c2.rh != 0 && B.c2.chunks == 2;
-                if (B.has_ds && (int)bi > n->seg_block) ok = ok && B.ds.rh != 0;
-            }
-        if (!ok) {
-            if (attempt == 1) return td_fail("internal: fp16 row-parity chains planned for convs that are not on the LDS-DMA kernels");
-            n->seg_block = -1; n->seg_conv = 0;
-            continue;
-        }
-    }
     break;
     }
     n->sd.clear();

@@ -305,43 +305,6 @@ def test_fp16_conv_with_dedicated_loader_waves(lib):
 
 
 
-@pytest.mark.parametrize("name,bb,H,W,variants", [("td2", "resnet34", 33, 65, [{}, {"chain_rows": 2}, {"chain_rows": 4}, {"chain_rows": 2, "fusion": 6 | 32 | 8192}]),
-                                                   ("td4", "resnet18", 65, 265, [{"chain_rows": 3}, {"chain_rows": 3, "fusion": 6 | 32 | 32768 | 2048}])])
-def test_fp16_row_parity_chains_are_bit_identical_to_the_unchained_backbone(lib, name, bb, H, W, variants):
-    """tdnet_opts.precision = 1 with overlap bit 1 (round 5): layers 3-4 as an even-row and an odd-row chain of DIRECT fp16 LDS-DMA convs,
-    each launched on one row class of its map (td_conv.h ConvArgs.rp / dy: row pitch 2 W, row dilation dil / 2; the pitched epilogue
-    of td_conv_h.h) -- narrow tiles, loader-wave tiles, row images and the tap-by-tap form, the 1x1 downsample of layer4.0 on row
-    classes, odd row counts (5 = 3 + 2, 9 = 5 + 4), a map narrower than a 32-row block (W = 9: the epilogue's division path) and a wider
-    one (W = 34: its single-wrap path).  Same products in the same order: logits and c4 must equal the unchained handle's bit for bit.
-    (Maps this small stay off the LDS-DMA kernels by the heuristic -- and then off the chains: variant {} checks that fallback --;
-    chain_rows forces the tiles.)"""
-    spec = arch.model_spec(name, 19, bb)
-    P = spec.path_num
-    h, w = arch.feat_size(H), arch.feat_size(W)
-    sd = weights.synth_state_dict(spec, h, w, 0)
-    frames = weights.synth_video(H, W, P + 2, seed=3)
-    ref = Engine(P, int(bb[6:]), 19, H, W, 0, lib=lib, opts={"precision": 1, "overlap": 0})
-    ref.load_state_dict(sd)
-    want, want_c4 = [], []
-    for t, x in enumerate(frames):
-        out = np.full((1, 19, H, W), 7e7, np.float32)
-        ref.forward(x, t % P, out)
-        want.append(out); want_c4.append(ref.stage("c4", (1, 512, h, w)))
-    n_ref = ref.last_launch_count()
-    ref.close()
-    for v in variants:
-        e = Engine(P, int(bb[6:]), 19, H, W, 0, lib=lib, opts=dict({"precision": 1}, **v))
-        assert e.opts()["overlap"] & 1
-        e.load_state_dict(sd)
-        for t, x in enumerate(frames):
-            out = np.full((1, 19, H, W), 7e7, np.float32)
-            e.forward(x, t % P, out)
-            assert np.array_equal(e.stage("c4", (1, 512, h, w)), want_c4[t]), (v, t)
-            assert np.array_equal(out, want[t]), (v, t, float(np.abs(out - want[t]).max()))
-        assert (e.last_launch_count() > n_ref) == ("chain_rows" in v), v         # forced tiles: the run really went out as two launches per conv
-        e.close()
-
-
 def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
     """Winograd F(4x4,3x3) (td_wino.h k_wino4_in / k_wino4_out, 36 batched GEMMs): every dilation, ragged sizes (tiles hanging
     over the image, images smaller than a tile), residual/activation variants, then the td4 pipeline with layers 3-4 and the
@@ -382,7 +345,7 @@ def test_winograd_chunked_low_register_transforms(lib):
             opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 2 | (vw << 4)})       # whole conv on the new kernels
             opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1 | (vw << 4)})       # even dilation: two chunks
             if a[6] % 4 == 0:
-                opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1 | 64 | (vw << 4)})  # dilation 4 / 8 / 16: four row classes mod 4 (round 5)
+                opcheck.conv(lib, MEM, *a, tol=2e-4, opts={"winograd": 4, "overlap": 1 | 64 | (vw << 4)})  # dilation 4 / 8 / 16: four row classes mod 4 (round 5's Infinity-Cache probe hook)
     opcheck.conv(lib, MEM, 12, 30, 64, 160, 3, 1, 4, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 1, "gemm_persistent": 3, "fusion": 64})
     # td_gemm_dma.h (overlap bit 8): the batched GEMMs fed by LDS-DMA -- K = 32 .. 256 (1 .. 8 steps), ragged M and N, several tiles per
     # workgroup (grid forced small), padded planes, whole convs and chunks; bit-identical to the register-staged GEMM
@@ -396,12 +359,10 @@ def test_winograd_chunked_low_register_transforms(lib):
 
 
 @pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 41}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
-                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td2", "resnet18", {"overlap": 1 | 8, "gemm_persistent": 5}),
-                                          ("td4", "resnet18", {"overlap": 41 | 64}), ("td2", "resnet34", {"overlap": 1 | 16 | 64})])
+                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td2", "resnet18", {"overlap": 1 | 8, "gemm_persistent": 5})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     """tdnet_opts.overlap: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows), 1 / 2 /
     4 channels per lane in the transforms, the LDS-DMA-fed GEMM (bit 8; 41 = the library default, also with several tiles per workgroup)
-    and layer 4 as FOUR row classes mod 4, two per chain (bit 64, round 5; 5 rows: classes of 2, 1, 1, 1 rows)
     against the reference goldens; `c4` is read from the run's own block buffers.  The feature map is 5 x 9 here: 3 even rows, 2 odd.
     (The schedules that lost in rounds 3-4 -- staggered start, riders, pre-launched chain, CU-mask partition -- were removed in round 5.)"""
     H, W = 33, 65
