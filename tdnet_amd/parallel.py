@@ -390,7 +390,8 @@ class FramePipelinedStream:
                     if j:
                         # the frame is the caller's tensor, read here on ANOTHER stream: tell the allocator (and any producer that recycles
                         # buffers by stream order, e.g. dataloader.DevicePrefetcher's `freed` events are on the caller's stream only)
-                        frames[r0 + j].record_stream(lanes[j])
+                        if hasattr(frames[r0 + j], "record_stream"):    # (the schedule simulator of tests/ feeds frame NUMBERS)
+                            frames[r0 + j].record_stream(lanes[j])
                     self.stages[j].encode(frames[r0 + j], pos_id=(first_frame + r0 + j) % self.P)
                     self.stages[j].cache_export(*self._split(buf[j]))
                     e = torch.cuda.Event()
