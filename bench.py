@@ -395,7 +395,7 @@ def roofline_block(acc, fp16, peak, nframes):
             "achieved": round(fx, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fx / peak, 4),
             "avg_launch_ms": round(fx_ms / fx_n, 4), "launches_per_frame": fx_n / nframes,
             "frac_round4_kernel_set": round(ach / peak, 4), "round4_kernel_set": "LDS-DMA + 128x128-tile 3x3 convs only (selected by kernel, %g launches per frame)" % (dom_n / nframes),
-            "note": "per-launch durations (HIP events on the launch's own stream); with the row-parity chains two launches share the chip"}
+            "note": "per-launch durations (HIP events on the launch's own stream)"}
 
 
 def main():

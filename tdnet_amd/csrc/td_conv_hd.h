@@ -47,7 +47,9 @@ enum ConvDmaCode {
     CD_256_P = 19,        // ... 256 rows, eight matrix waves of 64 x 64
     CD_128_N = 20,        // NARROW tiles, rows x 64 channels, loader waves (k_conv_dma_h3n): 128 rows
     CD_192_N = 21,        // ... 192 rows
-    CD_256_N = 22         // ... 256 rows
+    CD_256_N = 22,        // ... 256 rows
+    CD_64_N = 23,         // ... 64 rows (round 5)
+    CD_96_N = 24          // ... 96 rows (round 5)
 };
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
@@ -781,18 +783,20 @@ static inline bool conv_launch_dma3p(ConvArgs a, int rh, int KS, bool out16, hip
 // Same structure as k_conv_dma_h3p (four loader waves, one barrier per step, three weight buffers, two images); matrix waves of 32 x 64
 // stacked along the rows only.  A 64-column group of the packed weights is a wave column of the 128-wide packing: same products, same
 // order, bit-identical results.
-template <int RH, int NP, int IP>
+// W32 = matrix waves = 32-row blocks of the tile: 4 / 6 / 8 = 128 / 192 / 256 rows (round 4), 2 / 3 = 64 / 96 rows (round 5: grids of more
+// than one workgroup per CU on maps of ~10^4 pixels)
+template <int W32, int NP, int IP>
 struct ConvDmaNGeom {
-    static constexpr int BM = 64 * RH, BN = 64, NWC = 2 * RH;        // matrix waves: 32 rows x 64 channels each
+    static constexpr int BM = 32 * W32, BN = 64, NWC = W32;          // matrix waves: 32 rows x 64 channels each
     static constexpr int B_BYTES = 8 * BN * 16;                       // 8 KB per K step
     static constexpr int CAP = IP * NP * 8, IMG_BYTES = CAP * 128, LDS_BYTES = 2 * IMG_BYTES + 3 * B_BYTES;
     static constexpr int WPP = 8 / NP, SH0 = (IP + 1) / 2, SH1 = IP - SH0;
     static_assert(8 % NP == 0, "every loader stages the same number of weight pieces");
     static_assert(LDS_BYTES <= 160 * 1024 - 1024, "LDS budget");
 };
-template <int RH, int OUT16, int NP, int IP>
-TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p) {
-    using GN = ConvDmaNGeom<RH, NP, IP>;
+template <int W32, int OUT16, int NP, int IP>
+TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (W32 + NP), 1) k_conv_dma_h3n(ConvArgs p) {
+    using GN = ConvDmaNGeom<W32, NP, IP>;
     constexpr int NJ = 2, BM = GN::BM, NWC = GN::NWC, WPP = GN::WPP;
     TD_DYN_LDS(smem);
     char* const wbase = smem + 2 * GN::IMG_BYTES;
@@ -912,23 +916,25 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(64 * (2 * RH + NP), 1) k_conv_dma_h3n(ConvArgs p
     }
     td_store_acc_h<1, 2, OUT16 != 0, true>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wave * 32, n0, lane);
 }
-template <int RH, int NP, int IP>
+template <int W32, int NP, int IP>
 static inline bool conv_launch_dma3n_t(const ConvArgs& a, bool out16, hipStream_t s) {
-    using GN = ConvDmaNGeom<RH, NP, IP>;
+    using GN = ConvDmaNGeom<W32, NP, IP>;
     if (conv_dma3_slots(GN::BM, a.W, a.dil) > GN::CAP) return false;
     const int grid = ((a.M + GN::BM - 1) / GN::BM) * a.tiles_n;
-    if (out16) TD_LAUNCH((k_conv_dma_h3n<RH, 1, NP, IP>), dim3(grid), dim3(64 * (GN::NWC + NP)), GN::LDS_BYTES, s, a);
-    else TD_LAUNCH((k_conv_dma_h3n<RH, 0, NP, IP>), dim3(grid), dim3(64 * (GN::NWC + NP)), GN::LDS_BYTES, s, a);
+    if (out16) TD_LAUNCH((k_conv_dma_h3n<W32, 1, NP, IP>), dim3(grid), dim3(64 * (GN::NWC + NP)), GN::LDS_BYTES, s, a);
+    else TD_LAUNCH((k_conv_dma_h3n<W32, 0, NP, IP>), dim3(grid), dim3(64 * (GN::NWC + NP)), GN::LDS_BYTES, s, a);
     return true;
 }
-// rh: CD_128_N / CD_192_N / CD_256_N (rows x 64 channels); false = not launched
+// rh: CD_64_N / CD_96_N / CD_128_N / CD_192_N / CD_256_N (rows x 64 channels); false = not launched
 static inline bool conv_launch_dma3n(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
     if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
     a.tiles_n = (a.Cout + 63) / 64;                                   // (not CoutPad / 64: a 64-channel conv packed 128 wide has ONE column of work)
     switch (rh) {
-        case CD_128_N: return conv_launch_dma3n_t<2, 4, 5>(a, out16, s) || conv_launch_dma3n_t<2, 4, 6>(a, out16, s) || conv_launch_dma3n_t<2, 4, 8>(a, out16, s);
-        case CD_192_N: return conv_launch_dma3n_t<3, 4, 7>(a, out16, s) || conv_launch_dma3n_t<3, 4, 9>(a, out16, s);
-        case CD_256_N: return conv_launch_dma3n_t<4, 4, 9>(a, out16, s) || conv_launch_dma3n_t<4, 4, 11>(a, out16, s);
+        case CD_64_N: return conv_launch_dma3n_t<2, 4, 3>(a, out16, s) || conv_launch_dma3n_t<2, 4, 4>(a, out16, s) || conv_launch_dma3n_t<2, 4, 6>(a, out16, s);
+        case CD_96_N: return conv_launch_dma3n_t<3, 4, 4>(a, out16, s) || conv_launch_dma3n_t<3, 4, 5>(a, out16, s) || conv_launch_dma3n_t<3, 4, 7>(a, out16, s);
+        case CD_128_N: return conv_launch_dma3n_t<4, 4, 5>(a, out16, s) || conv_launch_dma3n_t<4, 4, 6>(a, out16, s) || conv_launch_dma3n_t<4, 4, 8>(a, out16, s);
+        case CD_192_N: return conv_launch_dma3n_t<6, 4, 7>(a, out16, s) || conv_launch_dma3n_t<6, 4, 9>(a, out16, s);
+        case CD_256_N: return conv_launch_dma3n_t<8, 4, 9>(a, out16, s) || conv_launch_dma3n_t<8, 4, 11>(a, out16, s);
         default: return false;
     }
 }

@@ -26,6 +26,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <cstdlib>
 #include <map>
