@@ -85,10 +85,9 @@ typedef struct tdnet_opts {
                                 32768 = precision 1 only (default): on maps of <= 16384 output pixels the 3x3 "same" convs with <= 256 output channels run on
                                      NARROW tiles (128 / 192 rows x 64 channels, k_conv_dma_h3n: half the weight bytes per K step and CU); bit-identical.
                                      (16384 was an experiment removed in round 4 and is ignored.)  Since round 5 bit 32768 also routes ResNet layer1
-                                     (64 -> 64 channels) to the narrow kernel: 11.9 -> 9.8 us isolated, 1090 -> 1121 frames/s at 720x960,
-                                65536 / 131072 / 262144 / 524288 = precision 1, round-5 A/B hooks on top of 32768 (maps <= 16384 pixels): narrow
-                                     192 x 64 tiles for the 512-channel convs too / 64-row tiles for <= 128 channels / 96-row tiles for 256 channels /
-                                     128-row instead of 192-row narrow tiles for 512 channels -- grids of more than one workgroup per CU.              */
+                                     (64 -> 64 channels) to the narrow kernel: 11.9 -> 9.8 us isolated, 1090 -> 1121 frames/s at 720x960.
+                                     (Round 5 also tried the narrow tiles on the 512-channel convs and 64- / 96-row narrow tiles: 1 - 7 % slower
+                                     in the frame, removed; profiles/r05c_*.)                                                               */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
                                 1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -47,9 +47,7 @@ enum ConvDmaCode {
     CD_256_P = 19,        // ... 256 rows, eight matrix waves of 64 x 64
     CD_128_N = 20,        // NARROW tiles, rows x 64 channels, loader waves (k_conv_dma_h3n): 128 rows
     CD_192_N = 21,        // ... 192 rows
-    CD_256_N = 22,        // ... 256 rows
-    CD_64_N = 23,         // ... 64 rows (round 5)
-    CD_96_N = 24          // ... 96 rows (round 5)
+    CD_256_N = 22         // ... 256 rows
 };
 template <int RH, int NB = 1, int MI = 2>
 struct ConvDmaGeom {
@@ -783,8 +781,9 @@ static inline bool conv_launch_dma3p(ConvArgs a, int rh, int KS, bool out16, hip
 // Same structure as k_conv_dma_h3p (four loader waves, one barrier per step, three weight buffers, two images); matrix waves of 32 x 64
 // stacked along the rows only.  A 64-column group of the packed weights is a wave column of the 128-wide packing: same products, same
 // order, bit-identical results.
-// W32 = matrix waves = 32-row blocks of the tile: 4 / 6 / 8 = 128 / 192 / 256 rows (round 4), 2 / 3 = 64 / 96 rows (round 5: grids of more
-// than one workgroup per CU on maps of ~10^4 pixels)
+// W32 = matrix waves = 32-row blocks of the tile: 4 / 6 / 8 = 128 / 192 / 256 rows.  (Round 5 also ran 2 / 3 = 64 / 96 rows -- grids of more than
+// one workgroup per CU on a 10^4-pixel map -- and the 512-channel convs on these tiles: bit-identical, 1 - 7 % SLOWER in the 720x960 frame
+// (profiles/r05c_*): two co-resident workgroups fetch twice the weights through the same CU and that, not latency, is the limit.  Removed.)
 template <int W32, int NP, int IP>
 struct ConvDmaNGeom {
     static constexpr int BM = 32 * W32, BN = 64, NWC = W32;          // matrix waves: 32 rows x 64 channels each
@@ -925,13 +924,11 @@ static inline bool conv_launch_dma3n_t(const ConvArgs& a, bool out16, hipStream_
     else TD_LAUNCH((k_conv_dma_h3n<W32, 0, NP, IP>), dim3(grid), dim3(64 * (GN::NWC + NP)), GN::LDS_BYTES, s, a);
     return true;
 }
-// rh: CD_64_N / CD_96_N / CD_128_N / CD_192_N / CD_256_N (rows x 64 channels); false = not launched
+// rh: CD_128_N / CD_192_N / CD_256_N (rows x 64 channels); false = not launched
 static inline bool conv_launch_dma3n(ConvArgs a, int rh, int KS, bool out16, hipStream_t s) {
     if (KS != 3 || a.stride != 1 || a.pad != a.dil || a.Wo != a.W || a.nsteps % 3) return false;
     a.tiles_n = (a.Cout + 63) / 64;                                   // (not CoutPad / 64: a 64-channel conv packed 128 wide has ONE column of work)
     switch (rh) {
-        case CD_64_N: return conv_launch_dma3n_t<2, 4, 3>(a, out16, s) || conv_launch_dma3n_t<2, 4, 4>(a, out16, s) || conv_launch_dma3n_t<2, 4, 6>(a, out16, s);
-        case CD_96_N: return conv_launch_dma3n_t<3, 4, 4>(a, out16, s) || conv_launch_dma3n_t<3, 4, 5>(a, out16, s) || conv_launch_dma3n_t<3, 4, 7>(a, out16, s);
         case CD_128_N: return conv_launch_dma3n_t<4, 4, 5>(a, out16, s) || conv_launch_dma3n_t<4, 4, 6>(a, out16, s) || conv_launch_dma3n_t<4, 4, 8>(a, out16, s);
         case CD_192_N: return conv_launch_dma3n_t<6, 4, 7>(a, out16, s) || conv_launch_dma3n_t<6, 4, 9>(a, out16, s);
         case CD_256_N: return conv_launch_dma3n_t<8, 4, 9>(a, out16, s) || conv_launch_dma3n_t<8, 4, 11>(a, out16, s);

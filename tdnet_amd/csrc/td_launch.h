@@ -118,7 +118,7 @@ static void launch_conv_dma_forms(const ConvLayer& L, const ConvArgs& a, hipStre
     int rh = L.rh;
     bool done = false;
     const bool is192 = rh == CD_192_P || rh == CD_192_N, is256 = rh == CD_256_P || rh == CD_256_N;
-    if (rh == CD_64_N || rh == CD_96_N || rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {   // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
+    if (rh == CD_128_N || rh == CD_192_N || rh == CD_256_N) {        // narrow tiles (rows x 64 channels) with loader waves (k_conv_dma_h3n)
         done = !L.rowimg_off && conv_launch_dma3n(a, rh, L.KS, L.out16, s);
         if (!done) rh = is192 ? CD_192_P : is256 ? CD_256_P : CD_128_P;
     }

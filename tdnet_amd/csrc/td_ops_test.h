@@ -41,13 +41,12 @@ extern "C" int tdnet_op_conv2d_f16io(const float* in, int H, int W, int Cin, con
     if (no_rowimg) tile -= 32;
     static const int code_of_tile[14] = {CD_128, CD_192, CD_256, CD_256x256, CD_128_4BUF, CD_128_2BUF, CD_128_8W,            // 16 .. 22
                                          CD_128_SUPER, CD_192_SUPER, CD_192_STEP, CD_128_STEP, CD_256_EARLY, CD_192_EARLY, CD_128_EARLY};   // 23 .. 29
-    static const int code_of_tile_p[8] = {CD_128_P, CD_192_P, CD_256_P,        // 31 .. 33: row images with four dedicated loader waves (k_conv_dma_h3p)
-                                          CD_128_N, CD_192_N, CD_256_N,        // 34 .. 36: narrow tiles, rows x 64 channels (k_conv_dma_h3n)
-                                          CD_64_N, CD_96_N};                   // 37, 38: 64 / 96 rows x 64 channels (round 5)
+    static const int code_of_tile_p[6] = {CD_128_P, CD_192_P, CD_256_P,        // 31 .. 33: row images with four dedicated loader waves (k_conv_dma_h3p)
+                                          CD_128_N, CD_192_N, CD_256_N};       // 34 .. 36: narrow tiles, rows x 64 channels (k_conv_dma_h3n)
     if (tile == 30) return td_fail("tdnet_op_conv2d_f16io: tile 30 (the weights-resident 64 -> 64 kernel) was removed in round 5");
-    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile >= 31 && tile <= 38 ? code_of_tile_p[tile - 31] : 0;
+    const int force_rh = tile >= 16 && tile <= 29 ? code_of_tile[tile - 16] : tile >= 31 && tile <= 36 ? code_of_tile_p[tile - 31] : 0;
     if (force_rh) tile = CT_128x128_DEEP;
-    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..38 (+ 32 for 16..29)", CT_COUNT);
+    if (tile >= CT_COUNT) return td_fail("tdnet_op_conv2d_f16io: tile must be < %d or 16..36 (+ 32 for 16..29)", CT_COUNT);
     hipStream_t s = (hipStream_t)stream;
     tdnet_opts o = opts_or_default(nullptr);
     o.precision = 1;

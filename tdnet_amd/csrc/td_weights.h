@@ -461,7 +461,7 @@ static int finalize_block(tdnet* n) {
                 // ResNet layer1 (64 -> 64 channels, 3x3): one narrow tile column of the 128-wide packing (make_conv_layer packed it that way).  Isolated
                 // 11.9 -> 9.8 us at 180x240, 22.0 -> 18.5 us at 256x512 against k_conv_igemm_h<128,64,..>, bit-identical (profiles/r04z_fp16_layer1_*; shipped in round 5)
                 if (c.Cout == 64 && c.CoutPad == 128 && c.KS == 3 && c.stride == 1 && c.pad == c.dil && (n->opts.fusion & 32768) && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile)) {
-                    c.rh = (n->opts.fusion & 131072) ? CD_64_N : CD_128_N;
+                    c.rh = CD_128_N;
                     return;
                 }
                 if (c.Cout >= 128 && conv_dma_supports(c.Cin, c.Cout, c.KS, c.tile)) {
@@ -470,12 +470,9 @@ static int finalize_block(tdnet* n) {
                     // channels, k_conv_dma_h3n) -- half the weight bytes per K step and CU, the term that dominates there: 128 channels
                     // 13.8 -> 10.3 us, 256 channels 20.6 -> 19.8 us isolated (profiles/r04u_*).  No gain at 32768 pixels.
                     const bool same3 = c.KS == 3 && c.stride == 1 && c.pad == c.dil;
-                    // round-5 A/B hooks (fusion bits 65536 / 131072 / 262144): narrow tiles for the 512-channel convs too; 64-row tiles for
-                    // <= 128 channels; 96-row tiles for 256 channels -- more than one workgroup per CU on a 10^4-pixel map
-                    const int fz = n->opts.fusion;
-                    if ((fz & 32768) && same3 && c.M_out <= 16384 && c.Cout <= ((fz & 65536) ? 512 : 256))
-                        c.rh = c.Cout <= 128 ? ((fz & 131072) ? CD_64_N : CD_128_N) : c.Cout <= 256 ? ((fz & 262144) ? CD_96_N : CD_192_N)
-                             : ((fz & 524288) ? CD_128_N : CD_192_N);     // (256 channels on 128 x 64 tiles as well: 2.1 % instead of 2.6 % in the frame)
+                    if ((n->opts.fusion & 32768) && same3 && c.M_out <= 16384 && c.Cout <= 256)
+                        c.rh = c.Cout <= 128 ? CD_128_N : CD_192_N;       // (256 channels on 128 x 64 tiles as well: 2.1 % instead of 2.6 % in the frame;
+                                                                          //  512 channels, 64- and 96-row tiles: slower, profiles/r05c_*)
                     else if (n->opts.fusion & 8192)                     // the 128- and 192-row tiles with four dedicated loader waves (k_conv_dma_h3p):
                         c.rh = c.rh == CD_128 ? CD_128_P : c.rh == CD_192 ? CD_192_P : c.rh;
                         // isolated 22.5 -> 21.0 / 57.8 -> 56.7 us; 256 rows: no gain (profiles/r04d_*).  (192 rows with TWELVE matrix waves of 32 x 64 -- three

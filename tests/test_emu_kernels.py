@@ -272,13 +272,12 @@ def test_fp16_conv_on_lds_dma(lib):
 def test_fp16_conv_with_dedicated_loader_waves(lib):
     """td_conv_hd.h k_conv_dma_h3p (round 4): the row-image conv with four LOADER waves per workgroup that only issue LDS-DMA, wait and
     meet the barrier, while the matrix waves only read fragments and multiply.  Tile codes 31 / 32 / 33 = 128 (eight matrix waves) / 192 /
-    256 rows; 34 / 35 / 36 = the NARROW tiles (rows x 64 channels, k_conv_dma_h3n: the default for small maps), 37 / 38 = 64 / 96 rows x 64
-    channels (round 5).  Same images, same weight
+    256 rows; 34 / 35 / 36 = the NARROW tiles (rows x 64 channels, k_conv_dma_h3n: the default for small maps).  Same images, same weight
     ring, same products in the same order as the tap-by-tap kernel (tile code 48 + ..): BIT FOR BIT, over tiles that span one to three
     image rows, halos of 1 .. 16 columns (each picks the smallest image buffer that holds it, or falls back to the plain kernel), ragged
     M, rows past the map; then residual / activation variants and the whole model with tdnet_opts.fusion bits 8192 / 32768 against the
     plain fp16 pipeline."""
-    for tile, plain in ((31, 54), (32, 49), (33, 50), (34, 54), (35, 49), (36, 50), (37, 54), (38, 54)):
+    for tile, plain in ((31, 54), (32, 49), (33, 50), (34, 54), (35, 49), (36, 50)):
         for H, W, Cin, Cout, dil in [(13, 21, 128, 256, 1), (10, 14, 128, 256, 4), (5, 300, 64, 256, 2), (3, 130, 64, 256, 8),
                                      (40, 7, 64, 256, 3), (9, 40, 192, 256, 16), (2, 2, 64, 256, 1), (23, 37, 64, 160, 2)]:
             _, a = opcheck.conv_f16io(lib, MEM, H, W, Cin, Cout, 3, 1, dil, 1, True, tile, want_out=True)
@@ -291,7 +290,7 @@ def test_fp16_conv_with_dedicated_loader_waves(lib):
     spec = arch.model_spec("td2", 19, "resnet34")
     sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
     outs = []
-    for fusion in (38, 38 | 8192, 38 | 8192 | 32768, 38 | 8192 | 32768 | 65536 | 131072 | 262144):
+    for fusion in (38, 38 | 8192, 38 | 8192 | 32768):
         e = Engine(2, 34, 19, H, W, 0, lib=lib, opts={"precision": 1, "fusion": fusion})
         e.load_state_dict(sd)
         o = []
@@ -301,7 +300,7 @@ def test_fp16_conv_with_dedicated_loader_waves(lib):
             o.append(out)
         outs.append(o)
         e.close()
-    assert all(np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) for a, b, c, d in zip(*outs))
+    assert all(np.array_equal(a, b) and np.array_equal(a, c) for a, b, c in zip(*outs))
 
 
 def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
