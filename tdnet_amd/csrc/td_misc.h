@@ -465,6 +465,20 @@ TD_KERNEL void k_upsample(const float* __restrict__ in, float* __restrict__ out,
         out[i] = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
     }
 }
+// Any W (769x1537, the reference's native size, is not a multiple of 4): one output per lane, grid = (ceil(W / 256), H, C) -- row and
+// channel from the block index, vertical coefficients wave-uniform, coalesced 4-byte stores.  Same expression as k_upsample: bit-identical.
+// (Round 5: the grid-stride k_upsample with its 64-bit div / mod per element took 70 us for the 90 MB of a 769x1537 frame.)
+TD_KERNEL void k_upsample_row(const float* __restrict__ in, float* __restrict__ out, int C, int h, int w, int H, int W) {
+    const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y, c = blockIdx.z;
+    if (X >= W) return;
+    const UpCoef cy = td_up_coef(Y, sy, h), cx = td_up_coef(X, sx, w);
+    const float* pl = in + (size_t)c * h * w;
+    const float v00 = pl[cy.i0 * w + cx.i0], v01 = pl[cy.i0 * w + cx.i1];
+    const float v10 = pl[cy.i1 * w + cx.i0], v11 = pl[cy.i1 * w + cx.i1];
+    out[((size_t)c * H + Y) * W + X] = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
+}
 // same arithmetic, 4 consecutive output columns per lane and one 16-byte store (W % 4 == 0): the 159 MB logits write
 // of a 1024x2048 frame is the largest single HBM stream of the path
 // grid = (ceil(W/4 / 256), H, C): the row and channel come from the block index (no 64-bit div/mod per thread), the row's
