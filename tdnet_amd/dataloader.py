@@ -110,7 +110,14 @@ class DevicePrefetcher:
     `depth` (>= 2, default 3) device buffers, reused round-robin: work enqueued on the yielded tensor BEFORE the next `depth - 1` requests
     is safe (the upload that overwrites it waits for an event recorded at that request); the frame loop's use (forward, then drop) fits,
     clone() to keep a frame longer.  Three rather than two, so that the upload of item i + 1 -- issued when item i is requested -- goes
-    into the buffer of item i - 2, whose frame has long finished: a pageable upload then never makes the host wait for frame i - 1."""
+    into the buffer of item i - 2, whose frame has long finished: a pageable upload then never makes the host wait for frame i - 1.
+
+    STREAM CONTRACT: "the consumer's last use" of a buffer is what the CURRENT stream has enqueued when the next item is requested (the
+    `freed` event is recorded there).  A consumer that reads the yielded tensor on ANOTHER stream must order that stream into the current one
+    before it asks for the next item (`current.wait_stream(other)`), or the upload `depth - 1` requests later may overwrite a frame still being
+    read.  The package's own multi-stream consumers do: a batch joins its side lane before forward() returns (model/_base.py), and
+    parallel.FramePipelinedStream's lane 0 -- the caller's stream -- waits for every other lane's encode (the only read of the input) inside
+    the round, with or without join."""
 
     def __init__(self, items, device, depth=3):
         self.items, self.device, self.depth = list(items), torch.device(device), max(2, int(depth))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU-box probe: direct vs Winograd F(2x2,3x3) vs F(4x4,3x3) time per layer shape (same launch path as the model)."""
+"""GPU-box probe: direct vs Winograd F(4x4,3x3) time per layer shape (same launch path as the model).  (F(2x2) left the library in round 5;
+its round-2/3 numbers are in profiles/r02*, r03*.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
@@ -12,8 +13,8 @@ SHAPES = [("layer4 512->512 d4", 128, 256, 512, 512, 4), ("layer4 512->512 d8", 
 for (nm, H, W, Cin, Cout, d) in SHAPES:
     gf = 2.0 * H * W * Cout * Cin * 9 / 1e9
     out = []
-    for mode in (0, 2, 4):
+    for mode in (0, 4):
         o = lib.opts(winograd=mode)
         ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 3, 1, d, -1, 20, ctypes.byref(o), None) for _ in range(2))
-        out.append("%s %.3f ms (%.0f TF eff.)" % ({0: "direct", 2: "F2", 4: "F4"}[mode], ms, gf / ms))
+        out.append("%s %.3f ms (%.0f TF eff.)" % ({0: "direct", 4: "F4"}[mode], ms, gf / ms))
     print("%-24s %6.1f GFLOP  %s" % (nm, gf, "   ".join(out)), flush=True)
