@@ -26,7 +26,7 @@ struct GemmArgs {
     int tiles_m, tiles_n; // per batch
     int MP;               // rows between consecutive batches of a and out (>= M; padded planes of the Winograd workspaces, td_wino.h)
     int wshare = 0;       // nbatch > 1 with ONE weight set and bias for all batches: a 1x1 conv over a strided set of image rows (batch = row,
-                          // M = W pixels, MP = row pitch in pixels) -- the downsample conv of one row-parity chain (td_model.hip); resid must be null
+                          // M = W pixels, MP = row pitch in pixels) -- the downsample conv of one row-parity chain (td_frame.h run_ds_rows); resid must be null
 #ifdef TD_GEMM_TRACE      // tools/gemm_trace.hip only: per workgroup 64 x u64 -- HW_ID, XCC_ID, start, then (end of K loop, end of epilogue) per tile
     unsigned long long* trace;   // in s_memrealtime ticks (100 MHz); TD_GEMM_TRACE == 2: the end of every two-step period as well
 #endif

@@ -251,7 +251,7 @@ static int run_classifier(tdnet* n, const float* x, int HW, int C, int NC, const
 }
 
 static void launch_upsample(const float* in, int C, int h, int w, int H, int W, float* out, hipStream_t s) {
-    if (W % 4 == 0 && H <= 65535 && C <= 65535) TD_LAUNCH(k_upsample_x4, dim3((W / 4 + 255) / 256, H, C), dim3(256), 0, s, in, out, C, h, w, H, W);
-    else if (H <= 65535 && C <= 65535) TD_LAUNCH(k_upsample_row, dim3((W + 255) / 256, H, C), dim3(256), 0, s, in, out, C, h, w, H, W);
+    if (W % 4 == 0 && ((size_t)out & 15) == 0 && H <= 65535 && C <= 65535) TD_LAUNCH(k_upsample_x4, dim3((W / 4 + 255) / 256, H, C), dim3(256), 0, s, in, out, C, h, w, H, W);
+    else if (H <= 65535 && C <= 65535) TD_LAUNCH(k_upsample_row, dim3((W / 4 + 2 + 255) / 256, H, C), dim3(256), 0, s, in, out, C, h, w, H, W);
     else TD_LAUNCH(k_upsample, dim3(td_grid_for((long)C * H * W, 256, 256 * 16)), dim3(256), 0, s, in, out, C, h, w, H, W);
 }

@@ -465,19 +465,35 @@ TD_KERNEL void k_upsample(const float* __restrict__ in, float* __restrict__ out,
         out[i] = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
     }
 }
-// Any W (769x1537, the reference's native size, is not a multiple of 4): one output per lane, grid = (ceil(W / 256), H, C) -- row and
-// channel from the block index, vertical coefficients wave-uniform, coalesced 4-byte stores.  Same expression as k_upsample: bit-identical.
-// (Round 5: the grid-stride k_upsample with its 64-bit div / mod per element took 70 us for the 90 MB of a 769x1537 frame.)
+// Any W (769x1537, the reference's native size, is not a multiple of 4, so the rows of the [C][H][W] output start at every alignment).
+// grid = (ceil((W / 4 + 2) / 256), H, C): row and channel from the block index, vertical coefficients wave-uniform.  Lane q >= 1 of a row
+// writes the 16-byte ALIGNED quad X0 + 4 (q - 1) .. + 3 with one store, X0 = the row's first aligned column; lane 0 writes the X0 head
+// elements, the lane of the last (partial) quad its tail, as scalars.  Same expression per element as k_upsample: bit-identical.
+// (Round 5: the grid-stride k_upsample with a 64-bit div / mod per element took 70 us for the 90 MB of a 769x1537 frame, one 4-byte store
+// per lane 48 us.)
 TD_KERNEL void k_upsample_row(const float* __restrict__ in, float* __restrict__ out, int C, int h, int w, int H, int W) {
     const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y, c = blockIdx.z;
-    if (X >= W) return;
-    const UpCoef cy = td_up_coef(Y, sy, h), cx = td_up_coef(X, sx, w);
-    const float* pl = in + (size_t)c * h * w;
-    const float v00 = pl[cy.i0 * w + cx.i0], v01 = pl[cy.i0 * w + cx.i1];
-    const float v10 = pl[cy.i1 * w + cx.i0], v11 = pl[cy.i1 * w + cx.i1];
-    out[((size_t)c * H + Y) * W + X] = (1.f - cy.l) * ((1.f - cx.l) * v00 + cx.l * v01) + cy.l * ((1.f - cx.l) * v10 + cx.l * v11);
+    const int q = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y, c = blockIdx.z;
+    float* orow = out + ((size_t)c * H + Y) * W;
+    const int X0 = (int)((4u - (unsigned)(((size_t)orow >> 2) & 3u)) & 3u);      // columns before the first 16-byte boundary of this row
+    const int xa = q == 0 ? 0 : X0 + 4 * (q - 1), xb = q == 0 ? (X0 < W ? X0 : W) : (xa + 4 < W ? xa + 4 : W);
+    if (xa >= xb) return;
+    const UpCoef cy = td_up_coef(Y, sy, h);
+    const float* r0 = in + ((size_t)c * h + cy.i0) * w;
+    const float* r1 = in + ((size_t)c * h + cy.i1) * w;
+    auto value = [&](int X) {
+        const UpCoef cx = td_up_coef(X, sx, w);
+        return (1.f - cy.l) * ((1.f - cx.l) * r0[cx.i0] + cx.l * r0[cx.i1]) + cy.l * ((1.f - cx.l) * r1[cx.i0] + cx.l * r1[cx.i1]);
+    };
+    if (q > 0 && xb - xa == 4) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = value(xa + e);
+        td_st4(orow + xa, o);
+    } else {
+        for (int X = xa; X < xb; ++X) orow[X] = value(X);
+    }
 }
 // same arithmetic, 4 consecutive output columns per lane and one 16-byte store (W % 4 == 0): the 159 MB logits write
 // of a 1024x2048 frame is the largest single HBM stream of the path

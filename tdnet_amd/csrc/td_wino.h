@@ -40,7 +40,7 @@ struct WinoArgs {
     // Chunked transforms (k_wino4_in_c / k_wino4_out_c): a launch covers the Tc tiles whose phase row is py = ny * i + cy and whose
     // phase column is px = nx * j + cx (i < dil / ny, j < dil / nx); V / Mb then hold ONLY those tiles ([36][TP][C], TP >= Tc).  With
     // an even dilation and ny = 2 the two chunks are the even and the odd image rows: a dilated conv maps a row parity onto itself,
-    // so through a run of even-dilation convs the two chunks are independent chains (td_model.hip run_parity_chains).
+    // so through a run of even-dilation convs the two chunks are independent chains (td_frame.h run_parity_chains).
     int Tc, ny, cy, nx, cx;
 };
 // Buffer descriptors of a transform: every access is an UNCONDITIONAL range-checked buffer access (a tap outside the image, an output

@@ -110,6 +110,24 @@ def test_layernorm_ppm_upsample(lib):
         opcheck.ppm(lib, MEM, h, w, pid)
     for c, h, w, H, W in [(19, 5, 9, 33, 65), (3, 9, 17, 65, 129), (2, 1, 1, 4, 5)]:
         opcheck.upsample(lib, MEM, c, h, w, H, W)
+    # k_upsample_row (round 5; any W -- 769x1537 is the reference's native size): rows of every alignment, a destination that itself starts
+    # at every 4-byte offset of a 16-byte line (sample i > 0 of a batch), widths shorter than a quad, nothing written outside the map;
+    # against the 4-column kernel's answer where W % 4 == 0 allows one
+    import torch
+    import torch.nn.functional as F
+    for c, h, w, H, W in [(3, 5, 9, 33, 65), (2, 4, 7, 29, 53), (2, 3, 2, 9, 3), (1, 2, 2, 5, 1), (2, 5, 9, 33, 66), (2, 5, 9, 33, 64)]:
+        x = np.random.default_rng(W).standard_normal((c, h, w)).astype(np.float32)
+        ref = F.interpolate(torch.from_numpy(x)[None], (H, W), mode="bilinear", align_corners=True)[0].numpy()
+        outs = []
+        for off in range(4):
+            buf = np.full(c * H * W + 16, 7e7, np.float32)
+            base = (-buf.ctypes.data // 4) % 4                                   # element index of a 16-byte boundary
+            view = buf[base + off: base + off + c * H * W]
+            lib.check(lib.tdnet_op_upsample(MEM.ptr(MEM.put(x)), c, h, w, H, W, view.ctypes.data, None))
+            assert np.abs(view.reshape(c, H, W) - ref).max() <= 1e-5, (c, h, w, H, W, off)
+            assert (buf[:base + off] == 7e7).all() and (buf[base + off + c * H * W:] == 7e7).all(), (W, off)
+            outs.append(view.copy())
+        assert all(np.array_equal(outs[0], o) for o in outs[1:]), (W, "the value of an element must not depend on which store wrote it")
 
 
 CASES = [("td4", "resnet18", 33, 65), ("td2", "resnet18", 33, 65), ("td2", "resnet50", 33, 65), ("td2", "resnet34", 33, 65), ("td2", "resnet18", 49, 81),

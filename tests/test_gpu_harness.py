@@ -142,7 +142,7 @@ def test_idle_handles_do_not_slow_a_busy_one():
     """tools/idle_handle_probe.py: the C2 workload beside 0 / 1 / 2 / 3 idle td4 handles.  HIP reuses hardware queues once its pool is full;
     with an odd number of idle handles alive the busy handle's second row-parity chain used to land on the CALLER's queue and the frame ran
     at 0.63x (335 / 212 / 335 / 212 frames/s).  The first frame now checks the pair with two spin kernels and replaces the internal stream
-    (td_model.hip place_chain_stream).  Run under HIP's default pool size (4), where the collision occurs; TDNET_NO_QUEUE_CHECK=1 shows the
+    (td_frame.h place_chain_stream).  Run under HIP's default pool size (4), where the collision occurs; TDNET_NO_QUEUE_CHECK=1 shows the
     old behaviour (printed, not asserted)."""
     import re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
