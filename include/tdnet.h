@@ -93,19 +93,23 @@ typedef struct tdnet_opts {
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent
                                     chains -- on two HIP streams.  fp32 (winograd >= 3): the HBM-bound transforms of one chain run under the
                                     MFMA-bound GEMMs of the other.  (precision 1: ignored.  Round 5 ran the fp16 mode's direct convs as row
-                                    classes as well -- bit-identical, 1121 -> 1050 frames/s at 720x960: removed, profiles/r05a_*),
+                                    classes as well -- bit-identical, 1121 -> 1050 frames/s at 720x960: removed, profiles/r05a_*.)
+                                    By default only on maps of >= 24000 feature pixels (h w): td4-psp18 measured -2 % with the chains at 8192 ..
+                                    18721 pixels (512x1024 .. 769x1537), +0.8 % at 25088, +1.8 % at 32768 (profiles/r05g_*),
+                                2 = the low-register transform kernels for every F(4x4) conv, chained or not,
+                                4 = the chains of bit 1 at ANY map size (tests, A/B),
                                 8 = the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h: no staging registers, 82 VGPRs),
                                 bits 4-5 = channels per lane of the chunked transform kernels: 0 -> 1, 1 -> 2, 2 -> 4,
                                 64 = PROBE HOOK, tdnet_op_conv2d / tdnet_bench_conv only (the frame ignores it): with bit 1, a conv whose dilation is
                                      a multiple of 4 as FOUR row classes mod 4 instead of two.  Round 5's Infinity-Cache residency experiment: a
                                      class's V + M is 76 MB at 1024x2048 instead of 151 MB; transforms -5 %, GEMMs +10 %, frame -1.2 % -- not adopted
                                      (tools/wino_l3_probe.py, profiles/r05a_l3_*).
-                                (rounds 3-4 used 4 for a staggered start of the second chain and 64 for transforms riding inside the other chain's GEMM launches,
+                                (rounds 3-4 used bit 4 for a staggered start of the second chain and 64 for transforms riding inside the other chain's GEMM launches,
                                  128 = the next frame's cache-only chain launched at the end of this one: measured neutral to negative in
                                  rounds 3-4, removed in round 5 and ignored; DESIGN_experiments.md 4.1d, 8.)                                  */
     int32_t reserved[8];     /* must be 0 (round 4: cu_reserve / cu_mode, the CU-mask-partitioned pipeline, -2.5x, removed)        */
 } tdnet_opts;
-#define TDNET_OVERLAP_MASK 0x7b    /* the bits of tdnet_opts.overlap that exist: 1 | 2 | 8 | 16 | 32 | 64 */
+#define TDNET_OVERLAP_MASK 0x7f    /* the bits of tdnet_opts.overlap that exist: 1 | 2 | 4 | 8 | 16 | 32 | 64 */
 void tdnet_opts_default(tdnet_opts* o);
 
 /* ---- lifecycle: replaces the nn.Module constructor + load_state_dict (td4_psp18.py:32-120, :232-240) ---------- */

@@ -201,6 +201,7 @@ static Folded fold(tdnet* n, const std::string& wkey, const std::string& bkey, c
 // EVEN dilation reads, for an output row y, only the input rows y + k * dil: rows of y's parity.  So from the first such conv to the end
 // of the backbone (ResNet-18/34: layer3.0.conv2 .. layer4.1.conv2, dilations 2,2,2,4,4,8,4 -- resnet.py:181-198) the even and the odd
 // rows are two INDEPENDENT chains of convs (residual adds and the 1x1 downsample are pixel-wise), each with half the Winograd tiles.
+constexpr int TD_CHAIN_MIN_PIXELS = 24000;                            // feature pixels (h w) from which the row-parity chains are on by default
 static bool conv_chainable(int cin, int cout, int stride, int dil) {
     return stride == 1 && dil % 2 == 0 && cin >= 128 && cout >= 128 && gemm_supports(cin) && cout % 4 == 0;
 }
@@ -209,6 +210,11 @@ static void plan_chains(tdnet* n) {
     n->seg_block = -1; n->seg_conv = 0;
     const tdnet_opts& o = n->opts;
     if (!(o.overlap & 1) || o.winograd < 3 || o.precision || !o.gemm_persistent || n->deep) return;
+    // The chains pay on LARGE maps only: td4-psp18, frames/s with / without them (profiles/r05g_*): 512x1024 (8192 feature pixels) 805 / 822,
+    // 640x1280 (12800) 565 / 575, 769x1537 (18721) 384.5 / 391.9, 896x1792 (25088) 324.1 / 321.7, 1024x2048 (32768) 273.8 / 269.1 -- two
+    // half-size GEMMs fill the chip less well than one, and below ~23 k pixels that costs more than the hidden transforms return.
+    // overlap bit 4 forces them at any size (tests, A/B).
+    if (n->Lq < TD_CHAIN_MIN_PIXELS && !(o.overlap & 4)) return;
     int sb = -1, sc = 0;
     for (int b = (int)n->bspec.size() - 1; b >= 0; --b) {
         const BlockSpec& S = n->bspec[b];

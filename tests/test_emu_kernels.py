@@ -374,8 +374,9 @@ def test_winograd_chunked_low_register_transforms(lib):
         opcheck.conv(lib, MEM, 13, 21, 96, 128, 3, 1, 2, 1, True, tol=2e-4, opts={"winograd": 4, "overlap": 9 | 16, "gemm_persistent": cap})
 
 
-@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 41}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 16}),
-                                          ("td2", "resnet18", {"overlap": 3 | 32}), ("td2", "resnet18", {"overlap": 1 | 8, "gemm_persistent": 5})])
+@pytest.mark.parametrize("name,bb,opts", [("td4", "resnet18", {"overlap": 41 | 4}), ("td4", "resnet18", {"overlap": 0}), ("td4", "resnet34", {"overlap": 1 | 4 | 16}),
+                                          ("td2", "resnet18", {"overlap": 3 | 4 | 32}), ("td2", "resnet18", {"overlap": 1 | 4 | 8, "gemm_persistent": 5}),
+                                          ("td2", "resnet18", {"overlap": 41})])
 def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     """tdnet_opts.overlap: layers 3-4 as an even-row and an odd-row chain of Winograd convs (+ the 1x1 downsample on image rows), 1 / 2 /
     4 channels per lane in the transforms, the LDS-DMA-fed GEMM (bit 8; 41 = the library default, also with several tiles per workgroup)
@@ -388,6 +389,8 @@ def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
     e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=opts)
     assert e.opts()["overlap"] == opts["overlap"]
     e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    # bit 4 forces the chains on this 5 x 9 map (by default they start at 24000 feature pixels: the last case runs unchained); a chained frame
+    # issues every conv of the run as two launches
     for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 1, seed=1)):
         out = np.full((1, 19, H, W), 7e7, np.float32)
         e.forward(x, t % spec.path_num, out)
@@ -395,7 +398,15 @@ def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
             assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 1e-4 * np.abs(g["f%d_c4" % t]).max()
         assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
         assert (out[0].argmax(0) == g["f%d_logits" % t][0].argmax(0)).all()
+    n_chained = e.last_launch_count()
     e.close()
+    if opts["overlap"] & 1:                                                      # the chains really ran (or, without bit 4 on a map this small, really did not)
+        e0 = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=dict(opts, overlap=opts["overlap"] & ~5))
+        e0.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+        for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 1, seed=1)):
+            e0.forward(x, t % spec.path_num, np.zeros((1, 19, H, W), np.float32))
+        assert (n_chained > e0.last_launch_count()) == bool(opts["overlap"] & 4), (n_chained, e0.last_launch_count())
+        e0.close()
 
 
 def test_activation_propagates_non_finite_values_like_the_reference(lib):

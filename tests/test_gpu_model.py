@@ -308,7 +308,7 @@ def test_every_schedule_option_reproduces_the_default_bit_for_bit():
     frames = [torch.from_numpy(x).cuda() for x in weights.synth_video(H, W, 8, seed=11)]
     pos = [0, 1, 2, 3, 0, 0, 1, 2]
     with torch.no_grad():
-        for base, variants in (({}, [{"overlap": 0}, {"overlap": 1}, {"overlap": 33}, {"overlap": 8}]),
+        for base, variants in (({}, [{"overlap": 0}, {"overlap": 1 | 4}, {"overlap": 33 | 4}, {"overlap": 41 | 4}, {"overlap": 8}]),   # bit 4: the chains on this small map too
                                ({"precision": 1}, [{"fusion": 6 | 2048}, {"fusion": 6 | 1024}, {"fusion": 38}, {"fusion": 38 | 8192}])):
             m = make_model("td4", "resnet18", seed=3, kernel_opts=dict(base))
             ref = [m(x, pos_id=p).clone() for x, p in zip(frames, pos)]
