@@ -183,7 +183,7 @@ def test_direct_conv_mode_meets_the_same_gate():
     _vs_oracle("td4", "resnet18", 1024, 2048, 5, kernel_opts={"winograd": 0})
 
 
-@pytest.mark.parametrize("wino", [0, 1, 3])
+@pytest.mark.parametrize("wino", [0, 3])
 def test_uncalibrated_reference_init(wino):
     """Stress with SURVEY 8d's ORIGINAL init (every conv ~ N(0, 2/(k k C_out)), no q/k gain, no depth normalisation): activations
     grow ~8x through the 512->64 projections, scores reach the hundreds, logits the tens -- the absolute 1e-3 gate stops being
@@ -193,10 +193,10 @@ def test_uncalibrated_reference_init(wino):
     and a label may differ from the truth's only inside the truth's top-2 tie band -- asserted exactly as written here (round 2
     asserted a looser 1e-3 max|truth| / 5x rms, which the direct kernel needed: its one sequential fp32 chain over K = 4608 was 6.8x /
     3.5x the CPU's error; the kernel now sums blocks of 512 products, td_conv.h FLUSH).  max|gpu - cpu| is printed as well: it is
-    what "within X of the CPU path" means for logits of this magnitude.  All three conv algorithms (direct, Winograd F(2x2), F(4x4))
-    must pass: Winograd's extra rounding error is a constant factor (measured on the CPU model of the kernels,
-    tests/numerics_winograd.py reference-init: rms 1.0x / 2.3x, max 1.8x / 3.0x the direct path's), not something the calibrated
-    weights were hiding."""
+    what "within X of the CPU path" means for logits of this magnitude.  Both conv algorithms (direct, Winograd F(4x4); F(2x2) left the
+    library in round 5) must pass: Winograd's extra rounding error is a constant factor (measured on the CPU model of the kernels,
+    tests/numerics_winograd.py reference-init: rms 1.0x / 2.3x, max 1.8x / 3.0x the direct path's for F(2x2) / F(4x4)), not something the
+    calibrated weights were hiding."""
     _reference_init_stress(129, 257, 5, wino)
 
 
