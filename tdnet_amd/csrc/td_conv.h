@@ -491,11 +491,12 @@ static inline int conv_cout_pad(int Cout, ConvTile t) {
     const int BN = conv_tile_dims(t).BN;
     return (Cout + BN - 1) / BN * BN;
 }
-static inline int conv_nsteps(int Cin, int KS, bool stem) { return stem ? (KS * KS + 7) / 8 : (Cin / 32) * KS * KS; }
+static inline int conv_nsteps(int Cin, int KS, int stem) { return stem == 2 ? KS : stem ? (KS * KS + 7) / 8 : (Cin / 32) * KS * KS; }
 
 // Pack BN-folded OIHW weights into the LDS image order of `tile`: [step][kq][slot][4], where packed column `slot`
 // holds output channel  tile_n*BN + wn*WN + j*NT + nt   for  slot = tile_n*BN + wn*WN + nt*32 + j.
-static inline void conv_pack_weights(const float* w, int Cout, int Cin, int KS, bool stem, ConvTile tile, float* dst) {
+// stem = 2: the 7x7 stem on the PACKED-ROW image (td_conv_ad.h STEM = 2): step = kernel row ky, k = 4 kq + e = 3 kx + c for k < 21.
+static inline void conv_pack_weights(const float* w, int Cout, int Cin, int KS, int stem, ConvTile tile, float* dst) {
     const ConvTileDims d = conv_tile_dims(tile);
     const int WN = d.BN / d.WGN, NT = WN / 32;
     const int CoutPad = conv_cout_pad(Cout, tile);
@@ -510,7 +511,10 @@ static inline void conv_pack_weights(const float* w, int Cout, int Cin, int KS, 
                 for (int e = 0; e < 4; ++e) {
                     float v = 0.f;
                     if (n < Cout) {
-                        if (stem) {
+                        if (stem == 2) {
+                            const int k = kq * 4 + e;                  // the row's 21 (kx, c) products, then three zero columns, then two zero k-groups
+                            if (k < 3 * KS) v = w[((size_t)n * 3 + k % 3) * ntaps + step * KS + k / 3];
+                        } else if (stem) {
                             const int t = step * 8 + kq;
                             if (t < ntaps && e < 3) v = w[((size_t)n * 3 + e) * ntaps + t];
                         } else {

@@ -12,10 +12,16 @@
 #pragma once
 #include "td_conv.h"
 
-template <int KS, bool STEM>
+// STEM: 0 = an NHWC map of Cin % 32 == 0 channels; 1 = the stems on the NHWC4 image (one 4-channel pixel = one tap per k-group, 8 taps per K
+// step); 2 (round 5) = the 7x7 stem on the PACKED-ROW image: [H + 7][W + 8][3] floats with a zero border of 3 pixels, so the 7 taps x 3
+// channels of a kernel row are 21 CONTIGUOUS floats -- a K step is one kernel row: six 16-byte k-groups (21 products, three columns and
+// two groups of zero weights), 24 MFMAs instead of 32; 7 steps, K = 168 instead of 224 for the same 147 products.  The loads are 4-byte
+// aligned 16-byte buffer loads; nothing is masked (the border is in the image, a row past M reads out of range = zeros).
+template <int KS, int STEM>
 TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_conv_adirect(ConvArgs p) {
     constexpr int BM = 128, BN = 64, NT = 2;
     constexpr int NTAPS = STEM ? 1 : KS * KS;
+    constexpr int NG = STEM == 2 ? 3 : 4;                            // k-group pairs per K step
     constexpr int B_STRIDE = BN * 4, BUF_FLOATS = 8 * B_STRIDE;     // weights only: [kq][64 slots][4 floats]
     TD_DYN_LDS(smem);
     float* lds = reinterpret_cast<float*>(smem);
@@ -46,7 +52,12 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_conv_adirect(ConvArgs p) {
     int la_step = 0, la_chunk = 0, la_tap = 0;
     auto load_a = [&](f32x4 (&ra)[4]) {
         const bool live = la_step < p.nsteps;                       // wave-uniform: past the last step nothing is consumed -> read zeros
-        if (STEM) {
+        if (STEM == 2) {
+            const bool ok = live && m < p.M;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)                             // kernel row la_step: floats 4 (2 g + half) .. + 3 of its 24
+                ra[g] = td_buf_ld4(in_buf, ok ? a_off + (unsigned)(la_step * p.W * 3 + (2 * g + half) * 4) * 4u : TD_BUF_OOB, 0u);
+        } else if (STEM) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int t = la_step * 8 + 2 * g + half;           // one 4-channel pixel per k-group: 8 taps per step
@@ -92,8 +103,8 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_conv_adirect(ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf[0][j] = td_ld4(Bs + half * B_STRIDE + j * 128);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) {
+        for (int g = 0; g < NG; ++g) {
+            if (g < NG - 1) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) bf[(g + 1) & 1][j] = td_ld4(Bs + (2 * g + 2 + half) * B_STRIDE + j * 128);
             }
@@ -132,12 +143,17 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_conv_adirect(ConvArgs p) {
 // supported: the 128 x 64 tiles (weights packed for CT_128x64 / CT_128x64_DEEP: same packing), no batching
 static inline bool conv_adirect_supports(ConvTile tile, int nbatch) { return (tile == CT_128x64 || tile == CT_128x64_DEEP) && nbatch <= 1; }
 
-static inline void conv_launch_adirect(ConvArgs a, int KS, bool stem, hipStream_t s) {
+// stem: 0 no, 1 the NHWC4 image, 2 the packed-row image (7x7 only; the caller passes the padded image's H, W, Cin = 3, pad = 0)
+static inline void conv_launch_adirect(ConvArgs a, int KS, int stem, hipStream_t s) {
     a.tiles_n = a.CoutPad / 64;
     const int grid = ((a.M + 127) / 128) * a.tiles_n;
     const int lds = 2 * 8 * 64 * 4 * 4;
-    if (stem && KS == 7) TD_LAUNCH((k_conv_adirect<7, true>), dim3(grid), dim3(256), lds, s, a);
-    else if (stem) TD_LAUNCH((k_conv_adirect<3, true>), dim3(grid), dim3(256), lds, s, a);
-    else if (KS == 3) TD_LAUNCH((k_conv_adirect<3, false>), dim3(grid), dim3(256), lds, s, a);
-    else TD_LAUNCH((k_conv_adirect<1, false>), dim3(grid), dim3(256), lds, s, a);
+    if (stem == 2 && KS == 7) TD_LAUNCH((k_conv_adirect<7, 2>), dim3(grid), dim3(256), lds, s, a);
+    else if (stem && KS == 7) TD_LAUNCH((k_conv_adirect<7, 1>), dim3(grid), dim3(256), lds, s, a);
+    else if (stem) TD_LAUNCH((k_conv_adirect<3, 1>), dim3(grid), dim3(256), lds, s, a);
+    else if (KS == 3) TD_LAUNCH((k_conv_adirect<3, 0>), dim3(grid), dim3(256), lds, s, a);
+    else TD_LAUNCH((k_conv_adirect<1, 0>), dim3(grid), dim3(256), lds, s, a);
 }
+// the packed-row image of an H x W frame: [H + 7][W + 8][3] floats (3 border pixels on every side + what the last 24-float row read reaches)
+static inline int stem_rows_hp(int H) { return H + 7; }
+static inline int stem_rows_wp(int W) { return W + 8; }

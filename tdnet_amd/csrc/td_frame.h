@@ -114,7 +114,7 @@ static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t 
 static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s) {
     const int DV = n->DV;
     // backbone (resnet.py:204-215)
-    run_stem_pre(n, img, n->H, n->W, n->img4, s, n->opts.fusion);
+    run_stem_pre(n, img, n->H, n->W, n->img4, s, n->opts.fusion, L.stem.stem_rows);
     if (n->deep) {                                                     // resnet.py:122-131
         TD_TRY(run_conv(n, L.stem, n->img4, n->H, n->W, nullptr, n->s1b, s));
         TD_TRY(run_conv(n, L.stem2, n->s1b, n->H1, n->W1, nullptr, n->s1, s));

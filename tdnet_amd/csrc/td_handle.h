@@ -118,6 +118,7 @@ static int out_size(int n, int KS, int stride, int dil, int pad) { return (n + 2
 struct ConvLayer {
     int Cin = 0, Cout = 0, KS = 1, stride = 1, dil = 1, pad = 0, act = 0;
     bool stem = false;
+    bool stem_rows = false;                                            // the 7x7 fp32 stem on the packed-row image (td_conv_ad.h STEM = 2; tdnet_opts.fusion bit 65536)
     bool h16 = false;                                                  // fp16-MFMA operands (td_conv_h.h)
     int wino_pad = 0;                                                  // padding rows per Winograd plane (fusion bit 64)
     bool adirect = false;                                              // Cout <= 64: A operand straight from global (td_conv_ad.h, fusion bit 32)

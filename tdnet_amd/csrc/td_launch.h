@@ -161,7 +161,11 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
         ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = a.M;
         gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
-    } else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem, s);
+    } else if (L.adirect && L.stem_rows) {                              // the image is padded already: its own geometry, 3 channels, no padding taps
+        ConvArgs r = a;
+        r.H = stem_rows_hp(H); r.W = stem_rows_wp(W); r.Cin = 3; r.pad = 0;
+        conv_launch_adirect(r, L.KS, 2, s);
+    } else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem ? 1 : 0, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;
@@ -219,9 +223,12 @@ static void run_ppm(tdnet* n, const float* c4, int h, int w, int C, int XS, int 
     prof_end(n, s);
 }
 
-static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, hipStream_t s, int fusion) {
+// rows: the packed-row image of the 7x7 stem (ConvLayer.stem_rows; img4 then holds [H + 7][W + 8][3] with a zero border) instead of NHWC4
+static void run_stem_pre(tdnet* n, const float* img, int H, int W, float* img4, hipStream_t s, int fusion, bool rows = false) {
     prof_begin(n, 2, false, 0, s);
-    if ((fusion & (16 | 256)) && (H * W) % 4 == 0 && ((size_t)img & 15) == 0)
+    if (rows)
+        TD_LAUNCH(k_nchw3_to_rgbpad, dim3(td_grid_for((long)H * ((W + 3) / 4))), dim3(256), 0, s, img, img4, H, W, stem_rows_wp(W));
+    else if ((fusion & (16 | 256)) && (H * W) % 4 == 0 && ((size_t)img & 15) == 0)
         TD_LAUNCH(k_nchw3_to_nhwc4_x4, dim3(td_grid_for((long)H * W / 4)), dim3(256), 0, s, img, img4, H * W);
     else
     TD_LAUNCH(k_nchw3_to_nhwc4, dim3(td_grid_for((long)H * W)), dim3(256), 0, s, img, img4, H * W);

@@ -31,6 +31,25 @@ TD_KERNEL void k_nchw3_to_nhwc4_x4(const float* __restrict__ img, float* __restr
     }
 }
 
+// ---- image NCHW [3][H][W] -> the packed-row image of the 7x7 stem: out[(y + 3) Wp + x + 3][3] (td_conv_ad.h STEM = 2).  The border (zeros)
+// is written once, when the workspace is allocated; a thread moves 4 consecutive pixels of a row: three loads, twelve floats out.
+TD_KERNEL void k_nchw3_to_rgbpad(const float* __restrict__ img, float* __restrict__ out, int H, int W, int Wp) {
+    const int W4 = (W + 3) >> 2;
+    const long total = (long)H * W4;
+    const long HW = (long)H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W4), x0 = (int)(i % W4) * 4;
+        float* o = out + ((size_t)(y + 3) * Wp + x0 + 3) * 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (x0 + e < W) {
+                const long p = (long)y * W + x0 + e;
+                o[3 * e] = img[p]; o[3 * e + 1] = img[HW + p]; o[3 * e + 2] = img[2 * HW + p];
+            }
+        }
+    }
+}
+
 // ---- MaxPool2d(3, stride 2, pad 1), padding = -inf, floor mode (resnet.py:137) -----------------------------------
 TD_KERNEL void k_maxpool3s2(const float* __restrict__ in, float* __restrict__ out, int H, int W, int C, int Ho, int Wo) {
     const int CV = C >> 2;

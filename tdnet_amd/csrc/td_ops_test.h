@@ -90,8 +90,10 @@ extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host
     if (bias_host) b.assign(bias_host, bias_host + 64);
     if (make_conv_layer(L, w, b, 64, 3, 7, 2, 1, 1, true, (long)H1 * W1, o)) return -1;
     float *img4 = nullptr, *s1 = nullptr;
-    if (dev_alloc(&img4, (size_t)H * W * 4) || dev_alloc(&s1, (size_t)H1 * W1 * 64)) return -1;
-    run_stem_pre(nullptr, img, H, W, img4, s, o.fusion);
+    const size_t img_floats = std::max((size_t)H * W * 4, (size_t)stem_rows_hp(H) * stem_rows_wp(W) * 3 + 4);
+    if (dev_alloc(&img4, img_floats) || dev_alloc(&s1, (size_t)H1 * W1 * 64)) return -1;
+    if (L.stem_rows) TD_HIP(hipMemsetAsync(img4, 0, img_floats * sizeof(float), s));   // the packed-row image's zero border
+    run_stem_pre(nullptr, img, H, W, img4, s, o.fusion, L.stem_rows);
     run_conv(nullptr, L, img4, H, W, nullptr, s1, s);
     run_maxpool(nullptr, s1, H1, W1, 64, out, s, o.fusion);
     TD_HIP(hipStreamSynchronize(s));

@@ -29,12 +29,12 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
                : pers ? gemm_pick_tile(wino_tiles_estimate(M, dil, L.wino) / chunks, nb, Cout, deep)
                       : conv_pick_tile((int)std::min<long>(nb * M / (L.wino * L.wino), 1 << 30), Cout, deep);
         L.CoutPad = conv_cout_pad(Cout, L.tile);
-        L.nsteps = conv_nsteps(Cin, 1, false);
+        L.nsteps = conv_nsteps(Cin, 1, 0);
         std::vector<std::vector<float>> U;
         wino_transform_weights(w.data(), Cout, Cin, L.wino, U);
         const size_t per = (size_t)L.nsteps * 8 * L.CoutPad * 4;
         std::vector<float> packed(nb * per);
-        for (int bi = 0; bi < nb; ++bi) conv_pack_weights(U[bi].data(), Cout, Cin, 1, false, L.tile, packed.data() + bi * per);
+        for (int bi = 0; bi < nb; ++bi) conv_pack_weights(U[bi].data(), Cout, Cin, 1, 0, L.tile, packed.data() + bi * per);
         TD_TRY(dev_alloc(&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         std::vector<float> bb(Cout, 0.f), zz(Cout, 0.f);
@@ -68,9 +68,12 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         TD_TRY(dev_alloc((_Float16**)&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     } else {
-        L.nsteps = conv_nsteps(Cin, KS, stem);
+        // the 7x7 stem with its A operand straight from global memory can read a packed-row image instead of NHWC4 taps: K = 168 instead of 224
+        L.stem_rows = stem && KS == 7 && stride == 2 && (o.fusion & 65536) && (o.fusion & 32) && conv_adirect_supports(L.tile, 1);
+        const int stem_kind = L.stem_rows ? 2 : stem ? 1 : 0;
+        L.nsteps = conv_nsteps(Cin, KS, stem_kind);
         std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
-        conv_pack_weights(w.data(), Cout, Cin, KS, stem, L.tile, packed.data());
+        conv_pack_weights(w.data(), Cout, Cin, KS, stem_kind, L.tile, packed.data());
         TD_TRY(dev_alloc(&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -244,7 +247,12 @@ static int alloc_workspace(tdnet* n) {
             ch = oh; cw = ow;
         }
     }
-    if (dev_alloc(&n->img4, (size_t)n->H * n->W * 4)) return -1;
+    {   // the stem's input image: NHWC4, or the packed-row image with its zero border (written once, here)
+        const bool rows = !n->paths.empty() && n->paths[0].stem.stem_rows;
+        const size_t img_floats = std::max((size_t)n->H * n->W * 4, rows ? (size_t)stem_rows_hp(n->H) * stem_rows_wp(n->W) * 3 + 4 : (size_t)0);
+        if (dev_alloc(&n->img4, img_floats)) return -1;
+        if (rows) TD_HIP(hipMemset(n->img4, 0, img_floats * sizeof(float)));
+    }
     if (dev_alloc(&n->s1, (size_t)n->H1 * n->W1 * 64)) return -1;
     if (n->deep && dev_alloc(&n->s1b, (size_t)n->H1 * n->W1 * 64)) return -1;
     if (n->deep) bmax = std::max(bmax, (size_t)n->H1 * n->W1 * 128);   // br also holds the deep stem output

@@ -63,6 +63,10 @@ def test_stem(lib):
     opcheck.stem(lib, MEM, 40, 52)
     for (H, W) in ((40, 52), (33, 65), (34, 66), (8, 10)):                # fusion bit 16: 4-pixel layout kernel (H*W % 4 == 0) and 2-output max-pool, odd and even widths
         opcheck.stem(lib, MEM, H, W, opts={"fusion": 16})
+    # round 5: the 7x7 stem on the PACKED-ROW image (fusion bit 65536 with bit 32; [H + 7][W + 8][3] with a zero border, a K step = one kernel
+    # row of 21 contiguous floats, K = 168): odd and even sizes, images narrower than one 24-float row read, a single output row
+    for (H, W) in ((33, 65), (40, 52), (34, 66), (8, 10), (9, 9), (129, 17), (7, 31)):
+        opcheck.stem(lib, MEM, H, W, opts={"fusion": 32 | 65536})
 
 
 def test_attention(lib):
