@@ -88,7 +88,7 @@ typedef struct tdnet_opts {
                                      (64 -> 64 channels) to the narrow kernel: 11.9 -> 9.8 us isolated, 1090 -> 1121 frames/s at 720x960.
                                      (Round 5 also tried the narrow tiles on the 512-channel convs and 64- / 96-row narrow tiles: 1 - 7 % slower
                                      in the frame, removed; profiles/r05c_*.)
-                                65536 = fp32, with bit 32 (round 5): the 7x7 stem reads a PACKED-ROW image -- [H + 7][W + 8][3] floats with a zero
+                                65536 = fp32, with bit 32 (round 5): the 7x7 stem reads a PACKED-ROW image -- [H + 7][~W + 9][3] floats with a zero
                                      border, written by the layout kernel -- so that the 21 (kx, channel) products of a kernel row are contiguous:
                                      a K step is one kernel row, K = 168 instead of 224 for the same 147 products (td_conv_ad.h STEM = 2).      */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:

@@ -13,7 +13,7 @@
 #include "td_conv.h"
 
 // STEM: 0 = an NHWC map of Cin % 32 == 0 channels; 1 = the stems on the NHWC4 image (one 4-channel pixel = one tap per k-group, 8 taps per K
-// step); 2 (round 5) = the 7x7 stem on the PACKED-ROW image: [H + 7][W + 8][3] floats with a zero border of 3 pixels, so the 7 taps x 3
+// step); 2 (round 5) = the 7x7 stem on the PACKED-ROW image: [H + 7][Wp][3] floats with a zero border (stem_rows_wp below), so the 7 taps x 3
 // channels of a kernel row are 21 CONTIGUOUS floats -- a K step is one kernel row: six 16-byte k-groups (21 products, three columns and
 // two groups of zero weights), 24 MFMAs instead of 32; 7 steps, K = 168 instead of 224 for the same 147 products.  The loads are 4-byte
 // aligned 16-byte buffer loads; nothing is masked (the border is in the image, a row past M reads out of range = zeros).
@@ -36,7 +36,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 3) k_conv_adirect(ConvArgs p) {
     const int m = m0 + wave * 32 + l31;
     const int oy = m / p.Wo, ox = m - oy * p.Wo;
     const int a_by = (m < p.M) ? oy * p.stride - p.pad : -(1 << 28);
-    const int a_bx = ox * p.stride - p.pad;
+    const int a_bx = ox * p.stride - p.pad + (STEM == 2 ? 1 : 0);   // packed-row image: 4 border pixels on the left (16-byte aligned rows), 3 needed
     const unsigned a_off = (((unsigned)a_by * (unsigned)p.W + (unsigned)a_bx) * (unsigned)p.Cin + (STEM ? 0u : (unsigned)half * 4u)) * 4u;
     const TdBuf in_buf = td_make_buf(p.in, (unsigned)p.H * (unsigned)p.W * (unsigned)p.Cin * 4u);
     const TdBuf w_buf = td_make_buf(p.wp, (unsigned)p.nsteps * 8u * (unsigned)p.CoutPad * 16u);
@@ -154,6 +154,8 @@ static inline void conv_launch_adirect(ConvArgs a, int KS, int stem, hipStream_t
     else if (KS == 3) TD_LAUNCH((k_conv_adirect<3, 0>), dim3(grid), dim3(256), lds, s, a);
     else TD_LAUNCH((k_conv_adirect<1, 0>), dim3(grid), dim3(256), lds, s, a);
 }
-// the packed-row image of an H x W frame: [H + 7][W + 8][3] floats (3 border pixels on every side + what the last 24-float row read reaches)
+// the packed-row image of an H x W frame: [H + 7][Wp][3] floats -- 3 border rows on top, FOUR border pixels on the left (pixel x sits at
+// column x + 4, so that 4 consecutive pixels = 12 floats start on a 16-byte boundary and the layout kernel writes whole 16-byte vectors),
+// and on the right / bottom what the last 24-float row read reaches; Wp a multiple of 4 (every row starts on a 16-byte boundary)
 static inline int stem_rows_hp(int H) { return H + 7; }
-static inline int stem_rows_wp(int W) { return W + 8; }
+static inline int stem_rows_wp(int W) { return (W + 9 + 3) / 4 * 4; }

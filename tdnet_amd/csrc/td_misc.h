@@ -31,21 +31,26 @@ TD_KERNEL void k_nchw3_to_nhwc4_x4(const float* __restrict__ img, float* __restr
     }
 }
 
-// ---- image NCHW [3][H][W] -> the packed-row image of the 7x7 stem: out[(y + 3) Wp + x + 3][3] (td_conv_ad.h STEM = 2).  The border (zeros)
-// is written once, when the workspace is allocated; a thread moves 4 consecutive pixels of a row: three loads, twelve floats out.
+// ---- image NCHW [3][H][W] -> the packed-row image of the 7x7 stem: out[(y + 3) Wp + x + 4][3] (td_conv_ad.h STEM = 2; Wp % 4 == 0).  The
+// border (zeros) is written once, when the workspace is allocated.  A thread moves 4 consecutive pixels of a row: three 16-byte loads
+// (one per colour plane, where the plane rows are 16-byte aligned) and three 16-byte stores of 12 contiguous, aligned floats.
 TD_KERNEL void k_nchw3_to_rgbpad(const float* __restrict__ img, float* __restrict__ out, int H, int W, int Wp) {
     const int W4 = (W + 3) >> 2;
     const long total = (long)H * W4;
     const long HW = (long)H * W;
+    const bool vec = (W & 3) == 0 && (((size_t)img) & 15) == 0;       // uniform
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int y = (int)(i / W4), x0 = (int)(i % W4) * 4;
-        float* o = out + ((size_t)(y + 3) * Wp + x0 + 3) * 3;
+        const long p = (long)y * W + x0;
+        float* o = out + ((size_t)(y + 3) * Wp + x0 + 4) * 3;         // 16-byte aligned: Wp % 4 == 0, x0 % 4 == 0
+        if (vec) {
+            const f32x4 r = td_ld4(img + p), g = td_ld4(img + HW + p), b = td_ld4(img + 2 * HW + p);
+            const f32x4 v0 = {r[0], g[0], b[0], r[1]}, v1 = {g[1], b[1], r[2], g[2]}, v2 = {b[2], r[3], g[3], b[3]};
+            td_st4(o, v0); td_st4(o + 4, v1); td_st4(o + 8, v2);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (x0 + e < W) {
-                const long p = (long)y * W + x0 + e;
-                o[3 * e] = img[p]; o[3 * e + 1] = img[HW + p]; o[3 * e + 2] = img[2 * HW + p];
-            }
+            for (int e = 0; e < 4; ++e)
+                if (x0 + e < W) { o[3 * e] = img[p + e]; o[3 * e + 1] = img[HW + p + e]; o[3 * e + 2] = img[2 * HW + p + e]; }
         }
     }
 }

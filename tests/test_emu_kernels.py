@@ -402,13 +402,13 @@ def test_pipeline_row_parity_chains(lib, golden_dir, name, bb, opts):
             assert np.abs(e.stage("c4", (1, 512, h, w)) - g["f%d_c4" % t]).max() <= 1e-4 * np.abs(g["f%d_c4" % t]).max()
         assert np.abs(out - g["f%d_logits" % t]).max() <= 1e-3
         assert (out[0].argmax(0) == g["f%d_logits" % t][0].argmax(0)).all()
-    n_chained = e.last_launch_count()
+        if t == 0:
+            n_chained = e.last_launch_count()
     e.close()
     if opts["overlap"] & 1:                                                      # the chains really ran (or, without bit 4 on a map this small, really did not)
         e0 = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=dict(opts, overlap=opts["overlap"] & ~5))
         e0.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
-        for t, x in enumerate(weights.synth_video(H, W, spec.path_num + 1, seed=1)):
-            e0.forward(x, t % spec.path_num, np.zeros((1, 19, H, W), np.float32))
+        e0.forward(weights.synth_video(H, W, 1, seed=1)[0], 0, np.zeros((1, 19, H, W), np.float32))      # frame 0 of the same clip
         assert (n_chained > e0.last_launch_count()) == bool(opts["overlap"] & 4), (n_chained, e0.last_launch_count())
         e0.close()
 
