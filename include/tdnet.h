@@ -46,9 +46,10 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 40998   /* 2 | 4 | 32 | 8192 | 32768; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+#define TDNET_FUSION_DEFAULT 106534  /* 2 | 4 | 32 | 8192 | 32768 | 65536; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
                                        bits 8192 and 32768 (precision 1 only) since round 4: 1042 -> 1053 -> (see DESIGN) frames/s at 720x960 fp16, bit-identical
-                                       (profiles/r04j_*, r04x_*) */
+                                       (profiles/r04j_*, r04x_*); bit 65536 (fp32 only) since round 5: the 7x7 stem 168 -> 125 us at 1024x2048, frames/s +0.2 % (td4
+                                       1024x2048, where the stem runs beside the cache-only attention chain) ... +1.5 % (td2 1024x2048) (profiles/r05j_*) */
 #define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 3 (default) = Winograd F(4x4,3x3) for the stride-1 3x3
