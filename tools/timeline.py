@@ -17,7 +17,7 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"].replace("void ", "").split("(")[0][:64]))
 rows.sort()
 # a frame starts with the layout kernel of the stem
-starts = [i for i, r in enumerate(rows) if r[3].startswith("k_nchw3_to_nhwc4")]
+starts = [i for i, r in enumerate(rows) if r[3].startswith("k_nchw3_to_")]   # the frame's first kernel: NHWC4 or packed-row image
 if len(starts) < back + 1:
     sys.exit("not enough frames in the trace")
 a, b = starts[-back - 1], starts[-back]
