@@ -391,7 +391,7 @@ def roofline_block(acc, fp16, peak, nframes):
                 "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nframes}
     fx_ms, fx_fl, fx_n = acc[4]
     fx = fx_fl / (fx_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "every 3x3 conv on an fp16 map (fixed layer set: k_conv_dma_h3n / _h3p / _h3 / _h<RH,3,..> / k_conv_igemm_h<..,3,true,..>), fp16 MFMA, fp32 accumulate",
+    return {"bound": "mfma", "kernel": "every 3x3 conv on an fp16 map (fixed layer set: k_conv_dma_h3n / _h3p / _h3 / _h<RH,3,..> / k_conv_igemm_h<..,3,true,..> / k_conv_igemm_h_group<..,3,1,true,..>), fp16 MFMA, fp32 accumulate",
             "achieved": round(fx, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(fx / peak, 4),
             "avg_launch_ms": round(fx_ms / fx_n, 4), "launches_per_frame": fx_n / nframes,
             "frac_round4_kernel_set": round(ach / peak, 4), "round4_kernel_set": "LDS-DMA + 128x128-tile 3x3 convs only (selected by kernel, %g launches per frame)" % (dom_n / nframes),
@@ -740,7 +740,7 @@ def main():
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
             if opts["precision"]:
                 kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> (dedicated loader waves) / k_conv_dma_h3n<RH,..> (narrow tiles) / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
-                                    "k_conv_igemm_h<..,3,true,..> where the register-staged kernel is kept"), r"k_conv_dma_h3[a-z]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<\d+, \d+, \d, \d, 3, true"
+                                    "k_conv_igemm_h<..,3,true,..> where the register-staged kernel is kept"), r"k_conv_dma_h3[a-z]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<\d+, \d+, \d, \d, 3, true|k_conv_igemm_h_group<\d+, \d+, \d, \d, 3, 1, true"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
                 if opts["gemm_persistent"]:

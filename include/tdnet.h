@@ -91,7 +91,10 @@ typedef struct tdnet_opts {
                                      in the frame, removed; profiles/r05c_*.)
                                 65536 = fp32, with bit 32 (round 5): the 7x7 stem reads a PACKED-ROW image -- [H + 7][~W + 9][3] floats with a zero
                                      border, written by the layout kernel -- so that the 21 (kx, channel) products of a kernel row are contiguous:
-                                     a K step is one kernel row, K = 168 instead of 224 for the same 147 products (td_conv_ad.h STEM = 2).      */
+                                     a K step is one kernel row, K = 168 instead of 224 for the same 147 products (td_conv_ad.h STEM = 2).
+                                131072 = precision 1 only (round 5): the Encoding's five 1x1 convs in TWO launches -- value / query / key first layers
+                                     side by side on z, then the query / key second layers (k_conv_igemm_h_group: blocks of up to three convs in one
+                                     grid); the value conv is packed for the 64-channel tile of the others.  Same products, same order: bit-identical. */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
                                 1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

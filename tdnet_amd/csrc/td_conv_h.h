@@ -131,8 +131,9 @@ TD_DEV void td_store_acc_h(const f32x16 (&acc)[MT][NT], void* outv, const float*
 // STEM (the 7x7 stride-2 conv on the 4-channel padded image, fp32 in HBM): a 16-byte LDS slot = 8 halfs = the 4 channels of TWO
 // horizontally adjacent taps, a K step = 8 slots x 2 = 16 taps = two kernel rows of 8 (7 + one zero-weight column), 4 steps = rows
 // 0..7 (row 7: zero weights).  K = 256 for 147 products -- 57 % useful, on a pipe 16x faster than the fp32 one.
+// The body takes its block index as an argument (bid of nblk): k_conv_igemm_h runs one conv per launch, k_conv_igemm_h_group up to three.
 template <int BM, int BN, int WGM, int WGN, int KS, bool IN16, bool OUT16, bool STEM = false>
-TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
+TD_DEV void conv_igemm_h_body(const ConvArgs& p, int bid, int nblk) {
     static_assert(!STEM || (!IN16 && KS == 7), "the stem reads the fp32 image");
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NT = WN / 32;
@@ -148,7 +149,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WGN, wn = wave % WGN;
-    const int lin = td_xcd_remap(blockIdx.x, gridDim.x);
+    const int lin = td_xcd_remap(bid, nblk);
     const int tile_m = lin / p.tiles_n, tile_n = lin - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -294,6 +295,35 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
 
     td_store_acc_h<MT, NT, OUT16, IN16>(acc, p.out, p.bias, p.resid, p.M, p.Cout, p.act, m0 + wm * WM, n0 + wn * WN, lane);
 }
+template <int BM, int BN, int WGM, int WGN, int KS, bool IN16, bool OUT16, bool STEM = false>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h(ConvArgs p) {
+    conv_igemm_h_body<BM, BN, WGM, WGN, KS, IN16, OUT16, STEM>(p, blockIdx.x, gridDim.x);
+}
+// Up to three INDEPENDENT convs of one kernel form in ONE launch (round 5): blocks [0, end[0]) run c[0], [end[0], end[1]) c[1], the rest c[2].
+// The Encoding's five 1x1 convs are two such groups (value / query / key first layers on z; query / key second layers): on a 10^4-pixel
+// map each of them is a launch of 6 .. 340 workgroups that lasts 4 - 9 us, most of it latency; side by side they fill the chip once.  The
+// arguments of the block's conv are selected with scalar moves (blockIdx is uniform), the body is compiled once.  Same products in the same
+// order as k_conv_igemm_h: bit-identical outputs.
+struct ConvGroupArgs {
+    ConvArgs c[3];
+    int end[3];
+};
+template <int BM, int BN, int WGM, int WGN, int KS0, int KS1, bool IN16, bool OUT16>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_conv_igemm_h_group(ConvGroupArgs q) {
+    const int b = blockIdx.x;
+    const int g = b < q.end[0] ? 0 : b < q.end[1] ? 1 : 2;
+    const int first = g == 0 ? 0 : g == 1 ? q.end[0] : q.end[1];
+    const int last = g == 0 ? q.end[0] : g == 1 ? q.end[1] : q.end[2];
+    if constexpr (KS0 == KS1) {
+        const ConvArgs p = g == 0 ? q.c[0] : g == 1 ? q.c[1] : q.c[2];
+        conv_igemm_h_body<BM, BN, WGM, WGN, KS0, IN16, OUT16, false>(p, b - first, last - first);
+    } else if (g == 0) {                                             // c[0] with another kernel size (a block's 3x3 conv1 beside its 1x1 downsample)
+        conv_igemm_h_body<BM, BN, WGM, WGN, KS0, IN16, OUT16, false>(q.c[0], b, q.end[0]);
+    } else {
+        const ConvArgs p = g == 1 ? q.c[1] : q.c[2];
+        conv_igemm_h_body<BM, BN, WGM, WGN, KS1, IN16, OUT16, false>(p, b - first, last - first);
+    }
+}
 
 static inline int conv_nsteps_h(int Cin, int KS) { return (Cin / 64) * KS * KS; }
 
@@ -359,6 +389,29 @@ static inline void conv_launch_h_io(const ConvArgs& a, const ConvTileDims& d, in
     if (d.BM == 128 && d.BN == 128) conv_launch_h_t<128, 128, 2, 2, IN16, OUT16>(a, KS, s);
     else if (d.BM == 64) conv_launch_h_t<64, 128, 2, 2, IN16, OUT16>(a, KS, s);
     else conv_launch_h_t<128, 64, 4, 1, IN16, OUT16>(a, KS, s);
+}
+// ng <= 3 convs of the same kernel form (tile, KS, in16, out16 -- the caller checks) in one launch
+template <int BM, int BN, int WGM, int WGN, bool IN16, bool OUT16>
+static inline void conv_launch_h_group_t(ConvGroupArgs& q, int KS0, hipStream_t s) {
+    const int lds = ConvLdsH<BM, BN>::BYTES;
+    if (KS0 == 3) TD_LAUNCH((k_conv_igemm_h_group<BM, BN, WGM, WGN, 3, 1, IN16, OUT16>), dim3(q.end[2]), dim3(256), lds, s, q);
+    else TD_LAUNCH((k_conv_igemm_h_group<BM, BN, WGM, WGN, 1, 1, IN16, OUT16>), dim3(q.end[2]), dim3(256), lds, s, q);
+}
+// ng <= 3 convs of one kernel form (tile and storage types equal; 1x1 convs, or a 3x3 conv first and 1x1 convs behind it -- the caller checks)
+static inline void conv_launch_h_group(const ConvArgs* a, int ng, ConvTile tile, int KS0, bool in16, bool out16, hipStream_t s) {
+    const ConvTileDims d = conv_tile_dims(tile);
+    ConvGroupArgs q;
+    int blocks = 0;
+    for (int g = 0; g < 3; ++g) {
+        q.c[g] = a[g < ng ? g : ng - 1];
+        q.c[g].tiles_n = q.c[g].CoutPad / d.BN;
+        if (g < ng) blocks += ((q.c[g].M + d.BM - 1) / d.BM) * q.c[g].tiles_n;
+        q.end[g] = blocks;
+    }
+    const bool io = in16 && out16;
+    if (d.BM == 128 && d.BN == 128) { if (io) conv_launch_h_group_t<128, 128, 2, 2, true, true>(q, KS0, s); else conv_launch_h_group_t<128, 128, 2, 2, false, false>(q, KS0, s); }
+    else if (d.BM == 64) { if (io) conv_launch_h_group_t<64, 128, 2, 2, true, true>(q, KS0, s); else conv_launch_h_group_t<64, 128, 2, 2, false, false>(q, KS0, s); }
+    else { if (io) conv_launch_h_group_t<128, 64, 4, 1, true, true>(q, KS0, s); else conv_launch_h_group_t<128, 64, 4, 1, false, false>(q, KS0, s); }
 }
 // in16 / out16: storage type of the input (+ residual) / output map (see the header comment)
 static inline void conv_launch_h(ConvArgs a, ConvTile tile, int KS, bool in16, bool out16, hipStream_t s) {

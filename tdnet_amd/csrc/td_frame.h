@@ -142,9 +142,12 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
             if (B.has_ds) { TD_TRY(run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s)); res = n->br; }
             TD_TRY(run_conv(n, B.c3, n->bu, oh, ow, res, last16 ? n->br : n->bx, s));         // 1x1 x4 + residual + ReLU (in place when res == bx)
         } else {
-            TD_TRY(run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow));
             const float* res = n->bx;
-            if (B.has_ds) { TD_TRY(run_conv(n, B.ds, n->bx, ch, cw, nullptr, n->br, s)); res = n->br; }
+            if (B.has_ds) {                                            // conv1 and the downsample read the same map: one grouped launch where they share a kernel form
+                const ConvCall both[2] = {{&B.c1, n->bx, ch, cw, n->bt}, {&B.ds, n->bx, ch, cw, n->br}};
+                TD_TRY(run_conv_group(n, both, 2, s, &oh, &ow));
+                res = n->br;
+            } else TD_TRY(run_conv(n, B.c1, n->bx, ch, cw, nullptr, n->bt, s, &oh, &ow));
             TD_TRY(run_conv(n, B.c2, n->bt, oh, ow, res, last16 ? n->br : n->bx, s));   // in-place on bx when res == bx (same element)
         }
         ch = oh; cw = ow;
@@ -170,11 +173,17 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
         TD_HIP(hipEventRecord(n->ev_fork2, s));
         TD_HIP(hipStreamWaitEvent(qs, n->ev_fork2, 0));
     }
-    if (!beside) TD_TRY(run_conv(n, L.enc_v, n->z, n->h, n->w, nullptr, n->v_cur, s));
-    TD_TRY(run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, qs));
-    TD_TRY(run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, qs));
-    TD_TRY(run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, qs));
-    TD_TRY(run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, qs));
+    if (!beside) {                                                    // one stream: the first layers side by side, then the second layers
+        const ConvCall first[3] = {{&L.enc_v, n->z, n->h, n->w, n->v_cur}, {&L.enc_q0, n->z, n->h, n->w, n->q1}, {&L.enc_k0, n->z, n->h, n->w, n->k1}};
+        const ConvCall second[2] = {{&L.enc_q1, n->q1, n->h, n->w, n->q_cur}, {&L.enc_k1, n->k1, n->hk, n->wk, cs.k}};
+        TD_TRY(run_conv_group(n, first, 3, s));
+        TD_TRY(run_conv_group(n, second, 2, s));
+    } else {
+        TD_TRY(run_conv(n, L.enc_q0, n->z, n->h, n->w, nullptr, n->q1, qs));
+        TD_TRY(run_conv(n, L.enc_q1, n->q1, n->h, n->w, nullptr, n->q_cur, qs));
+        TD_TRY(run_conv(n, L.enc_k0, n->z, n->h, n->w, nullptr, n->k1, qs));
+        TD_TRY(run_conv(n, L.enc_k1, n->k1, n->hk, n->wk, nullptr, cs.k, qs));
+    }
     if (!beside) {                                                    // one stream: both cache entries (q_, v_) in one launch
         prof_begin(n, 2, false, 0, s);
         TD_LAUNCH(k_subsample2, dim3(td_grid_for((long)n->Lk * (16 + DV / 4))), dim3(256), 0, s, (const float*)n->q_cur, cs.q, 64, (const float*)n->v_cur, cs.v, DV,

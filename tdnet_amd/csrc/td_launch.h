@@ -173,6 +173,41 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     return 0;
 }
 
+struct ConvCall { const ConvLayer* L; const float* in; int H, W; float* out; };
+// Up to three independent convs in one launch when they share a kernel form (fp16 mode: the register-staged k_conv_igemm_h on the same tile,
+// kernel size and storage types; `fusion` bit 131072); otherwise one launch each, in order.
+static int run_conv_group(tdnet* n, const ConvCall* c, int ng, hipStream_t s, int* Ho_out = nullptr, int* Wo_out = nullptr) {   // Ho / Wo: of c[0]
+    bool same = n && (n->opts.fusion & 131072) && ng >= 2 && ng <= 3;
+    for (int g = 0; same && g < ng; ++g) {
+        const ConvLayer& L = *c[g].L;
+        const ConvLayer& L0 = *c[0].L;
+        same = L.h16 && !L.stem && !L.rh && !L.wino && L.in16 == L.out16 && L.in16 == L0.in16 && (g == 0 ? (L.KS == 1 || L.KS == 3) : L.KS == 1) &&
+               conv_tile_dims(L.tile).BM == conv_tile_dims(L0.tile).BM && conv_tile_dims(L.tile).BN == conv_tile_dims(L0.tile).BN;
+    }
+    if (!same) {
+        for (int g = 0; g < ng; ++g) TD_TRY(run_conv(n, *c[g].L, c[g].in, c[g].H, c[g].W, nullptr, c[g].out, s, g == 0 ? Ho_out : nullptr, g == 0 ? Wo_out : nullptr));
+        return 0;
+    }
+    ConvArgs a[3];
+    double flops = 0.0;
+    for (int g = 0; g < ng; ++g) {
+        const ConvLayer& L = *c[g].L;
+        const int Ho = out_size(c[g].H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(c[g].W, L.KS, L.stride, L.dil, L.pad);
+        a[g].in = c[g].in; a[g].wp = L.d_wp; a[g].bias = L.d_bias; a[g].resid = nullptr; a[g].out = c[g].out;
+        a[g].H = c[g].H; a[g].W = c[g].W; a[g].Cin = L.Cin; a[g].Wo = Wo; a[g].Cout = L.Cout; a[g].CoutPad = L.CoutPad;
+        a[g].stride = L.stride; a[g].dil = L.dil; a[g].pad = L.pad; a[g].M = Ho * Wo; a[g].nsteps = L.nsteps; a[g].act = L.act; a[g].tiles_n = 0; a[g].nbatch = 1;
+        flops += L.flops_per_pixel() * a[g].M;
+        if (g == 0 && Ho_out) *Ho_out = Ho;
+        if (g == 0 && Wo_out) *Wo_out = Wo;
+    }
+    // a 3x3 conv on an fp16 map stays in the fp16 roofline's fixed layer set: the record carries ITS FLOP only (the launch's time includes the 1x1 beside it)
+    const bool dom = c[0].L->in16 && c[0].L->KS == 3;
+    prof_begin(n, 0, dom ? 4 : 0, dom ? c[0].L->flops_per_pixel() * a[0].M : flops, s);
+    conv_launch_h_group(a, ng, c[0].L->tile, c[0].L->KS, c[0].L->in16, c[0].L->out16, s);
+    prof_end(n, s);
+    return 0;
+}
+
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
                          int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,

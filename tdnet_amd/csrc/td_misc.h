@@ -251,7 +251,7 @@ TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* _
         const int cnt = (yhi - ylo) * (td_bin_hi(bx, w, o) - td_bin_lo(bx, w, o));
         for (int cv = threadIdx.x; cv < (C >> 2); cv += blockDim.x) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
+#pragma unroll 32                                               // the level-0 bin adds every row of the map: 32 loads in flight per trip, same order
             for (int y = ylo; y < yhi; ++y) s = s + td_ld4(rowbins + ((size_t)y * 12 + xoff + bx) * C + cv * 4);
             td_st4(pv + cv * 4, s * (1.0f / (float)cnt));
         }
@@ -261,7 +261,7 @@ TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* _
     const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
     const float* pp = pv + sl * cq;
     float s = 0.f;
-#pragma unroll 8
+#pragma unroll 32                                                       // one dependent fma chain, its loads 32 at a time (8: 16 round trips at C = 512)
     for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pp[c], s);
     red[sl * 64 + fl] = s;
     __syncthreads();
@@ -370,15 +370,19 @@ TD_KERNEL void k_ln_finalize(const float* __restrict__ part, int nstrips, int pe
         return t;
     };
     float s = 0.f;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int k = sl; k < nstrips; k += 64) s += count(k) * part[(size_t)k * C + c];
+    }
     const float m = combine(s) / (float)HW;
     s = 0.f;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int k = sl; k < nstrips; k += 64) {
             const float d = part[(size_t)k * C + c] - m;
             s += part[((size_t)nstrips + k) * C + c] + count(k) * d * d;
         }
+    }
     const float t = combine(s);
     (void)mu;
     if (sl == 0 && c < C) {

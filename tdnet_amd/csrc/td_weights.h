@@ -412,7 +412,9 @@ static int finalize_block(tdnet* n) {
         const std::string ep = b;
         {
             Folded fv = fold(n, ep + ".w_vs.0.conv.weight", ep + ".w_vs.0.conv.bias", "", DV);
-            if (make_conv_layer(L.enc_v, fv.w, fv.b, DV, C, 1, 1, 1, 0, false, n->Lq, n->opts)) return -1;
+            // fp16 mode with grouped launches: the value conv on the 64-channel tile of the query / key convs it shares a launch with
+            const int vtile = (n->opts.precision && (n->opts.fusion & 131072)) ? (int)conv_pick_tile((int)n->Lq, 64, n->opts.pipeline != 0) : -1;
+            if (make_conv_layer(L.enc_v, fv.w, fv.b, DV, C, 1, 1, 1, 0, false, n->Lq, n->opts, vtile)) return -1;
             Folded q0 = fold(n, ep + ".w_qs.0.conv.weight", ep + ".w_qs.0.conv.bias", ep + ".w_qs.0.bn", 64);
             if (make_conv_layer(L.enc_q0, q0.w, q0.b, 64, C, 1, 1, 1, 2, false, n->Lq, n->opts)) return -1;
             Folded q1 = fold(n, ep + ".w_qs.1.conv.weight", ep + ".w_qs.1.conv.bias", "", 64);

@@ -311,8 +311,8 @@ def test_fp16_conv_with_dedicated_loader_waves(lib):
     H, W = 33, 65
     spec = arch.model_spec("td2", 19, "resnet34")
     sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
-    outs = []
-    for fusion in (38, 38 | 8192, 38 | 8192 | 32768):
+    outs, launches = [], []
+    for fusion in (38, 38 | 8192, 38 | 8192 | 32768, 38 | 131072):     # 131072: the Encoding's five 1x1 convs as two grouped launches (round 5)
         e = Engine(2, 34, 19, H, W, 0, lib=lib, opts={"precision": 1, "fusion": fusion})
         e.load_state_dict(sd)
         o = []
@@ -321,8 +321,12 @@ def test_fp16_conv_with_dedicated_loader_waves(lib):
             e.forward(x, t % 2, out)
             o.append(out)
         outs.append(o)
+        launches.append(e.last_launch_count())
         e.close()
-    assert all(np.array_equal(a, b) and np.array_equal(a, c) for a, b, c in zip(*outs))
+    assert all(np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d) for a, b, c, d in zip(*outs))
+    # the Encoding: 5 launches -> 2; conv1 + downsample of layers 2.0 / 3.0 / 4.0 in one launch each (on this tiny map layers 3-4 stay on the
+    # register-staged kernel too; at 720x960 their conv1 is an LDS-DMA conv and only layer2.0 pairs up)
+    assert launches[3] == launches[0] - 3 - 3, launches
 
 
 def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
