@@ -434,27 +434,38 @@ TD_KERNEL void k_classifier(const float* __restrict__ x, const float* __restrict
     TD_DYN_LDS(smem);
     float* ws = reinterpret_cast<float*>(smem);                // [NC][C]
     float* red = ws + NC * C;                                  // [4][NC][64]
-    for (int i = threadIdx.x; i < NC * C; i += blockDim.x) ws[i] = wgt[i];
-    __syncthreads();
     const int lp = threadIdx.x & 63, q = threadIdx.x >> 6, CQ = C >> 2;
     const int p = blockIdx.x * 64 + lp;
+    const float* xp = x + (size_t)(p < HW ? p : 0) * C + q * CQ;
+    // the lane's channels in runs of 16 (a ragged last run is clamped / skipped): the first run is requested BEFORE the weights are staged, so that the two memory
+    // round trips overlap (round 5: one launch of 169 workgroups at 720x960 is nothing but these latencies); same fma order as before
+    f32x4 xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = td_ld4(xp + (4 * e < CQ ? 4 * e : CQ - 4));
+    for (int i = threadIdx.x; i < NC * C; i += blockDim.x) ws[i] = wgt[i];
+    __syncthreads();
     float acc[NC_MAX];
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k) acc[k] = 0.f;
-    if (p < HW) {
-        const float* xp = x + (size_t)p * C + q * CQ;
-#pragma unroll 4
-        for (int c = 0; c < CQ; c += 4) {
-            const f32x4 v = td_ld4(xp + c);
+    for (int c = 0; c < CQ; c += 16) {
+        f32x4 nx[4];
+        const bool more = c + 16 < CQ;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int cn = (more ? c + 16 : c) + 4 * e; nx[e] = td_ld4(xp + (cn < CQ ? cn : CQ - 4)); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + 4 * e >= CQ) continue;                         // uniform
 #pragma unroll
             for (int k = 0; k < NC_MAX; ++k) {
                 if (k < NC) {
-                    const float* wr = ws + k * C + q * CQ + c;
-                    acc[k] = fmaf(v[0], wr[0], acc[k]); acc[k] = fmaf(v[1], wr[1], acc[k]);
-                    acc[k] = fmaf(v[2], wr[2], acc[k]); acc[k] = fmaf(v[3], wr[3], acc[k]);
+                    const float* wr = ws + k * C + q * CQ + c + 4 * e;
+                    acc[k] = fmaf(xv[e][0], wr[0], acc[k]); acc[k] = fmaf(xv[e][1], wr[1], acc[k]);
+                    acc[k] = fmaf(xv[e][2], wr[2], acc[k]); acc[k] = fmaf(xv[e][3], wr[3], acc[k]);
                 }
             }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = nx[e];
     }
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k)
