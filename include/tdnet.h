@@ -46,10 +46,12 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 106534  /* 2 | 4 | 32 | 8192 | 32768 | 65536; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+#define TDNET_FUSION_DEFAULT 237606  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
                                        bits 8192 and 32768 (precision 1 only) since round 4: 1042 -> 1053 -> (see DESIGN) frames/s at 720x960 fp16, bit-identical
                                        (profiles/r04j_*, r04x_*); bit 65536 (fp32 only) since round 5: the 7x7 stem 168 -> 125 us at 1024x2048, frames/s +0.2 % (td4
-                                       1024x2048, where the stem runs beside the cache-only attention chain) ... +1.5 % (td2 1024x2048) (profiles/r05j_*) */
+                                       1024x2048, where the stem runs beside the cache-only attention chain) ... +1.5 % (td2 1024x2048) (profiles/r05j_*);
+                                       bit 131072 (precision 1 only) since round 5: 54 -> 50 launches and 1131 -> 1162 frames/s at 720x960 fp16, 722 -> 729 at 1024x2048 fp16,
+                                       bit-identical (profiles/r05l_*) */
 #define TDNET_OVERLAP_DEFAULT 41   /* row-parity chains with 4 channels per lane (+2 %) on the LDS-DMA-fed GEMM (+0.9 %): profiles/r03a_*, r03m_* */
 typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 3 (default) = Winograd F(4x4,3x3) for the stride-1 3x3
@@ -92,7 +94,8 @@ typedef struct tdnet_opts {
                                 65536 = fp32, with bit 32 (round 5): the 7x7 stem reads a PACKED-ROW image -- [H + 7][~W + 9][3] floats with a zero
                                      border, written by the layout kernel -- so that the 21 (kx, channel) products of a kernel row are contiguous:
                                      a K step is one kernel row, K = 168 instead of 224 for the same 147 products (td_conv_ad.h STEM = 2).
-                                131072 = precision 1 only (round 5): the Encoding's five 1x1 convs in TWO launches -- value / query / key first layers
+                                131072 = precision 1 only (default, round 5): a BasicBlock's conv1 and 1x1 downsample in ONE launch where both run on the
+                                     register-staged kernel (ResNet layer2.0 at 720x960), and the Encoding's five 1x1 convs in TWO launches -- value / query / key first layers
                                      side by side on z, then the query / key second layers (k_conv_igemm_h_group: blocks of up to three convs in one
                                      grid); the value conv is packed for the 64-channel tile of the others.  Same products, same order: bit-identical. */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:

@@ -243,6 +243,15 @@ TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* _
     const int groups = FS >> 6, bin = blockIdx.x / groups, fl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int f = (blockIdx.x % groups) * 64 + fl;
     const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
+    const int cq = C >> 2;
+    const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
+    // The thread's first 128 weights are requested BEFORE the pooling phase (they do not depend on it): the launch is 50 workgroups of pure
+    // latency -- the level-0 bin's 3 round trips over the rows and the conv's 4 over the weights, which come from beyond the L2 -- and the two
+    // now overlap (C = 512: all of the weights).  Same fma chain, same order.
+    constexpr int WPRE = 128;
+    float wv[WPRE];
+#pragma unroll
+    for (int c = 0; c < WPRE; ++c) wv[c] = wr[(size_t)(c < cq ? c : cq - 1) * FS];
     {
         const int o = lvl == 0 ? 1 : lvl == 1 ? 2 : lvl == 2 ? 3 : 6, xoff = lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 3 : 6;
         const int lb = bin - (lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 5 : 14);
@@ -257,12 +266,12 @@ TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* _
         }
     }
     __syncthreads();
-    const int cq = C >> 2;
-    const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
     const float* pp = pv + sl * cq;
     float s = 0.f;
-#pragma unroll 32                                                       // one dependent fma chain, its loads 32 at a time (8: 16 round trips at C = 512)
-    for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pp[c], s);
+#pragma unroll
+    for (int c = 0; c < WPRE; ++c) if (c < cq) s = fmaf(wv[c], pp[c], s);
+#pragma unroll 32                                                       // (C > 512) one dependent fma chain, its loads 32 at a time
+    for (int c = WPRE; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pp[c], s);
     red[sl * 64 + fl] = s;
     __syncthreads();
     if (sl == 0) {
@@ -434,38 +443,27 @@ TD_KERNEL void k_classifier(const float* __restrict__ x, const float* __restrict
     TD_DYN_LDS(smem);
     float* ws = reinterpret_cast<float*>(smem);                // [NC][C]
     float* red = ws + NC * C;                                  // [4][NC][64]
-    const int lp = threadIdx.x & 63, q = threadIdx.x >> 6, CQ = C >> 2;
-    const int p = blockIdx.x * 64 + lp;
-    const float* xp = x + (size_t)(p < HW ? p : 0) * C + q * CQ;
-    // the lane's channels in runs of 16 (a ragged last run is clamped / skipped): the first run is requested BEFORE the weights are staged, so that the two memory
-    // round trips overlap (round 5: one launch of 169 workgroups at 720x960 is nothing but these latencies); same fma order as before
-    f32x4 xv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) xv[e] = td_ld4(xp + (4 * e < CQ ? 4 * e : CQ - 4));
     for (int i = threadIdx.x; i < NC * C; i += blockDim.x) ws[i] = wgt[i];
     __syncthreads();
+    const int lp = threadIdx.x & 63, q = threadIdx.x >> 6, CQ = C >> 2;
+    const int p = blockIdx.x * 64 + lp;
     float acc[NC_MAX];
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k) acc[k] = 0.f;
-    for (int c = 0; c < CQ; c += 16) {
-        f32x4 nx[4];
-        const bool more = c + 16 < CQ;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const int cn = (more ? c + 16 : c) + 4 * e; nx[e] = td_ld4(xp + (cn < CQ ? cn : CQ - 4)); }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (c + 4 * e >= CQ) continue;                         // uniform
+    if (p < HW) {
+        const float* xp = x + (size_t)p * C + q * CQ;
+#pragma unroll 4
+        for (int c = 0; c < CQ; c += 4) {
+            const f32x4 v = td_ld4(xp + c);
 #pragma unroll
             for (int k = 0; k < NC_MAX; ++k) {
                 if (k < NC) {
-                    const float* wr = ws + k * C + q * CQ + c + 4 * e;
-                    acc[k] = fmaf(xv[e][0], wr[0], acc[k]); acc[k] = fmaf(xv[e][1], wr[1], acc[k]);
-                    acc[k] = fmaf(xv[e][2], wr[2], acc[k]); acc[k] = fmaf(xv[e][3], wr[3], acc[k]);
+                    const float* wr = ws + k * C + q * CQ + c;
+                    acc[k] = fmaf(v[0], wr[0], acc[k]); acc[k] = fmaf(v[1], wr[1], acc[k]);
+                    acc[k] = fmaf(v[2], wr[2], acc[k]); acc[k] = fmaf(v[3], wr[3], acc[k]);
                 }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] = nx[e];
     }
 #pragma unroll
     for (int k = 0; k < NC_MAX; ++k)

@@ -318,7 +318,8 @@ def test_every_schedule_option_reproduces_the_default_bit_for_bit():
     """tdnet_opts.overlap / fusion choose WHEN and on which kernel variant the same products are summed in the same order: no chains
     (round 2's schedule), chains with 1 / 4 channels per lane, the persistent or the LDS-DMA-fed Winograd GEMM; in the fp16 mode the
     tap-by-tap or the row-image conv kernel, the conv without / with dedicated loader waves (the default since round 4), wide instead of narrow
-    tiles (layer1 on the register-staged kernel instead of the narrow LDS-DMA tiles: round 5).  On the real streams and DMA engines (the
+    tiles (layer1 on the register-staged kernel instead of the narrow LDS-DMA tiles: round 5), one launch per register-staged conv instead of
+    the grouped launches (fusion bit 131072, default since round 5: every fp16 variant below lacks it).  On the real streams and DMA engines (the
     emulator runs them in issue order) every variant must give the default's logits bit for bit, frame by frame, through warm-up and steady
     state, including a repeated pos_id.  (The schedules that lost in rounds 3-4 were removed in round 5 and left this matrix.)"""
     H, W = 257, 513
