@@ -243,15 +243,6 @@ TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* _
     const int groups = FS >> 6, bin = blockIdx.x / groups, fl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int f = (blockIdx.x % groups) * 64 + fl;
     const int lvl = bin >= 14 ? 3 : bin >= 5 ? 2 : bin >= 1 ? 1 : 0;
-    const int cq = C >> 2;
-    const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
-    // The thread's first 128 weights are requested BEFORE the pooling phase (they do not depend on it): the launch is 50 workgroups of pure
-    // latency -- the level-0 bin's 3 round trips over the rows and the conv's 4 over the weights, which come from beyond the L2 -- and the two
-    // now overlap (C = 512: all of the weights).  Same fma chain, same order.
-    constexpr int WPRE = 128;
-    float wv[WPRE];
-#pragma unroll
-    for (int c = 0; c < WPRE; ++c) wv[c] = wr[(size_t)(c < cq ? c : cq - 1) * FS];
     {
         const int o = lvl == 0 ? 1 : lvl == 1 ? 2 : lvl == 2 ? 3 : 6, xoff = lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 3 : 6;
         const int lb = bin - (lvl == 0 ? 0 : lvl == 1 ? 1 : lvl == 2 ? 5 : 14);
@@ -266,12 +257,15 @@ TD_KERNEL void k_ppm_pool_conv(const float* __restrict__ rowbins, const float* _
         }
     }
     __syncthreads();
+    const int cq = C >> 2;
+    const float* wr = wgt + ((size_t)lvl * C + (size_t)sl * cq) * FS + f;   // weights stored [lvl][c][f]: lanes read consecutive f
     const float* pp = pv + sl * cq;
     float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < WPRE; ++c) if (c < cq) s = fmaf(wv[c], pp[c], s);
-#pragma unroll 32                                                       // (C > 512) one dependent fma chain, its loads 32 at a time
-    for (int c = WPRE; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pp[c], s);
+    // one dependent fma chain, its loads 32 at a time (8 or 32 at a time: 13.3 us per launch at 720x960 either way).  Requesting all 128
+    // weights of the thread BEFORE the pooling phase was measured too: 28.6 us -- with 128 registers held the compiler serialises the pooling
+    // loop's loads (and under the default 1024-thread bound it spilled: 45 us), profiles/r05m_*.
+#pragma unroll 32
+    for (int c = 0; c < cq; ++c) s = fmaf(wr[(size_t)c * FS], pp[c], s);
     red[sl * 64 + fl] = s;
     __syncthreads();
     if (sl == 0) {
