@@ -329,6 +329,35 @@ def test_fp16_conv_with_dedicated_loader_waves(lib):
     assert launches[3] == launches[0] - 3 - 3, launches
 
 
+@pytest.mark.parametrize("name,P,layers,bb", [("td4", 4, 18, "resnet18"), ("td2", 2, 50, "resnet50")])
+def test_fp16_grouped_launches_equal_single_launches(lib, name, P, layers, bb):
+    """tdnet_opts.fusion bit 131072 (fp16 default since round 5, td_conv_h.h k_conv_igemm_h_group): up to three independent convs of one
+    kernel form in ONE grid -- the Encoding's value / query / key first layers, then the query / key second layers; a BasicBlock's conv1
+    beside its 1x1 downsample.  Same body, same products, same order: logits bit for bit through warm-up and steady state, with the
+    launch count down by 3 (Encoding) + 2 (a BasicBlock backbone's downsample pairs whose conv1 runs on the register-staged kernel: on this
+    small map layer2.0 and layer4.0 -- layer3.0's conv1 is a 256-channel "same" conv on the narrow LDS-DMA tiles, fusion bit 32768; a
+    Bottleneck backbone has no pair: its conv1 is not the downsample's sibling)."""
+    H, W = 33, 65
+    spec = arch.model_spec(name, 19, bb)
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
+    default = lib.opts(precision=1).fusion
+    assert default & 131072
+    outs, launches = [], []
+    for fusion in (default, default & ~131072):
+        e = Engine(P, layers, 19, H, W, 0, lib=lib, opts={"precision": 1, "fusion": fusion})
+        e.load_state_dict(sd)
+        o = []
+        for t, x in enumerate(weights.synth_video(H, W, P + 2, seed=4)):
+            out = np.zeros((1, 19, H, W), np.float32)
+            e.forward(x, t % P, out)
+            o.append(out)
+        outs.append(o)
+        launches.append(e.last_launch_count())
+        e.close()
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
+    assert launches[1] - launches[0] == (5 if layers < 50 else 3), launches
+
+
 def test_winograd_f4_conv_and_pipeline(lib, golden_dir):
     """Winograd F(4x4,3x3) (td_wino.h k_wino4_in / k_wino4_out, 36 batched GEMMs): every dilation, ragged sizes (tiles hanging
     over the image, images smaller than a tile), residual/activation variants, then the td4 pipeline with layers 3-4 and the
