@@ -16,7 +16,8 @@
  *     remove: a handle whose frame uses a second internal stream (row-parity chains) checks ONCE per caller stream that this stream
  *     sits on another hardware queue than the caller's (two 40-us spin kernels, a host synchronisation of both streams).
  *     tdnet_warmup(h, stream) does that check explicitly; a frame call on a stream tdnet_warmup has not seen does it lazily
- *     (skipped while the stream is being captured into a hipGraph).  tdnet_finalize_weights, tdnet_create_shared, tdnet_get_stage
+ *     (skipped while the stream is being captured into a hipGraph).  Every caller stream is checked ONCE per handle (the handle remembers
+ *     the streams it has seen; alternating between two streams does not repeat the check), for at most 8 distinct streams.  tdnet_finalize_weights, tdnet_create_shared, tdnet_get_stage
  *     and the tdnet_op_* / tdnet_bench_* entries synchronise.
  *   - all tensors are fp32.  Image in / logits out are NCHW like the reference; internal layout is NHWC.
  */
@@ -139,7 +140,9 @@ int  tdnet_finalize_weights(tdnet_t* h);
  * streams -- another video stream on this GPU, the samples 1..N-1 of a batch (the reference's batch shares one nn.Module's
  * parameters: td4_psp18.py:216-229), or the second lane of a frame-pipelined clip -- without a second copy of the packed weights
  * and without folding / packing / uploading them again.  `opts` must be NULL (inherit) or equal to the block's options: the
- * packing depends on them.  The block is reference-counted: handles may be destroyed in any order, the weights go with the last. */
+ * packing depends on them.  The block is reference-counted (atomically): handles may be destroyed in any order, the weights go with the
+ * last.  Threading: a HANDLE is single-threaded (one host thread at a time), but tdnet_create_shared / tdnet_destroy of DIFFERENT handles
+ * on one block may run concurrently on different host threads (a garbage collector's finaliser thread, say).                    */
 int  tdnet_create_shared(const tdnet_t* weights_of, const tdnet_opts* opts /* NULL = inherit */, tdnet_t** out);
 /* One-time placement of the handle's internal streams for frames that will arrive on `stream` (see "Conventions"): host-
  * synchronising, idempotent per stream.  Call it before capturing frames into a hipGraph or before a latency-critical first frame. */
@@ -196,8 +199,9 @@ double tdnet_last_ms(const tdnet_t* h, int which);
 /* same selection: summed algorithmic FLOP / number of launches of that family in the last forward.              */
 double tdnet_last_flops(const tdnet_t* h, int which);
 double tdnet_last_launches(const tdnet_t* h, int which);
-/* Kernel launches the last tdnet_forward* / tdnet_encode of this handle enqueued (all streams; device copies included: none in a
- * steady-state frame).  Counted in the launch macro itself, profiling on or off.                                      */
+/* Kernel launches the last tdnet_forward* / tdnet_encode / tdnet_propagate* of this handle enqueued (all streams, the final x8 upsample /
+ * upsample + argmax kernel included; device copies included: none in a steady-state frame).  Counted in the launch macro itself,
+ * profiling on or off.                                                                                              */
 int    tdnet_last_launch_count(const tdnet_t* h);
 
 /* Roofline / tuning probes: sustained fp32-MFMA TFLOP/s of a register-only MFMA loop, and the average device ms of

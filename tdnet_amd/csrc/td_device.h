@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define TD_KERNEL __global__
 #define TD_DEV __device__ __forceinline__
@@ -97,6 +98,19 @@ TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, u
 
 // fp16 inputs, fp32 accumulate: D(32x32) += A(32x16) * B(16x32); lane l supplies 8 consecutive k of row/column l&31 (k-group l>>5)
 TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// bf16 inputs, fp32 accumulate (v_mfma_f32_32x32x16_bf16, 16x the rate of td_mfma32): same operand / accumulator maps as td_mfma32_f16; an
+// operand is 8 bf16 packed two per dword (element 2 i in the low half of dword i).  td_gemm_b3.h feeds it the three bf16 parts of fp32 values.
+TD_DEV f32x16 td_mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    typedef __bf16 bf16x8_ __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_, a), __builtin_bit_cast(bf16x8_, b), c, 0, 0, 0);
+}
+// two fp32 -> two bf16, round to nearest even (v_cvt_pk_bf16_f32); a in the low half
+TD_DEV unsigned td_pk_bf16(float a, float b) {
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+}
 
 TD_DEV float td_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 // value of lane ^ 1 (DPP quad_perm [1,0,3,2]: VALU rate, no LDS crossbar)

@@ -73,7 +73,8 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
     ga.M = W; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = rows; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = ny * W;
     ga.wshare = 1;
     prof_begin(n, 0, 0, 2.0 * rows * W * (double)L.Cin * L.Cout, s);
-    gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
+    if (L.b3) gemm_b3_launch(ga, L.b3, L.pers > 1 ? L.pers : 0, s);
+    else gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     prof_end(n, s);
     return 0;
 }
@@ -301,20 +302,24 @@ static int streams_share_a_queue(hipStream_t a, hipStream_t x, hipEvent_t e0, hi
 // explicit_call: from tdnet_warmup (the documented place for the host synchronisation); otherwise the lazy check of the first frame on a
 // stream tdnet_warmup has not seen -- skipped, and left for later, while that stream is being captured into a hipGraph.
 static int place_chain_stream(tdnet* n, hipStream_t s, bool explicit_call = false) {
-    if (!n->chain2 || (n->placed && n->placed_for == (void*)s)) return 0;
+    if (!n->chain2 || std::find(n->placed_for.begin(), n->placed_for.end(), (void*)s) != n->placed_for.end()) return 0;
 #ifndef TD_EMU
     if (!explicit_call) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;
     }
 #endif
-    n->placed = true; n->placed_for = (void*)s;
+    n->placed_for.push_back((void*)s);
 #ifndef TD_EMU
     if (getenv("TDNET_NO_QUEUE_CHECK")) return 0;                      // A/B of this very mechanism (tools/ab_opts.py)
+    // A handle alternating between caller streams checks each of them once.  chain2 is replaced only while the handle's lifetime budget of
+    // replacements lasts (12 streams kept alive): a replacement that suits stream B may share a queue with stream A again, and a handle
+    // that kept swapping would grow retired_streams without bound and synchronise with the host on every switch.
+    if (n->placed_for.size() > 8 || n->retired_streams.size() >= 12) return 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     TD_HIP(hipEventCreate(&e0)); TD_HIP(hipEventCreate(&e1)); TD_HIP(hipEventCreate(&e2));
     int rc = 0;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    for (int attempt = 0; attempt < 6 && n->retired_streams.size() < 12; ++attempt) {
         bool shared = false;
         if ((rc = streams_share_a_queue(s, n->chain2, e0, e1, e2, &shared)) != 0 || !shared) break;
         hipStream_t fresh = nullptr;
@@ -334,13 +339,11 @@ static int place_chain_stream(tdnet* n, hipStream_t s, bool explicit_call = fals
 static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s, bool* started);
 static int forward_lowres(tdnet* n, const float* img, int pos_id, hipStream_t s) {
     bool started = false;
-    const long l0 = td_launch_count;
     const int rc = forward_lowres_impl(n, img, pos_id, s, &started);
     // A frame that failed after it started is dropped: it never reaches the FIFO, and whatever the internal streams were given is joined
     // back into the caller's.  A call rejected by the checks (bad pos_id, a frame waiting for tdnet_propagate) changes nothing: the
     // pending entry of a tdnet_encode stays valid.
     if (rc && started) { rejoin_streams(n, s); n->pending_slot = n->pending_pos = -1; }
-    if (n && n->finalized) n->launches = (int)(td_launch_count - l0);
     return rc;
 }
 static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream_t s, bool* started) {

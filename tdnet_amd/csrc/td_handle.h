@@ -18,6 +18,7 @@
 #include "td_wino.h"
 #include "td_gemm.h"
 #include "td_gemm_dma.h"
+#include "td_gemm_b3.h"
 #include "td_attn.h"
 #include "td_attn_h.h"
 #include "td_misc.h"
@@ -128,6 +129,7 @@ struct ConvLayer {
     bool rowimg_off = false;                                           // tdnet_opts.fusion bit 2048: keep the tap-by-tap LDS-DMA kernel
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
+    int b3 = 0;                                                        // != 0: d_wp holds the three bf16 parts of the weights (td_gemm_b3.h gemm_b3_pack; tdnet_opts.precision = 2), b3 = matrix waves per workgroup (2 / 4)
     bool gdma = false;                                                 // the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h; tdnet_opts.overlap bit 8)
     int vw = 0;                                                        // != 0: the low-register F(4x4) transform kernels with vw channels per lane (td_wino.h k_wino4_*_c)
     int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 4 = F(4x4,3x3)): d_wp = 36 packed 1x1 weight sets (td_wino.h)
@@ -146,7 +148,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     if (!o) return d;
     d = *o;
     d.winograd = d.winograd <= 0 ? 0 : (d.winograd == 2 || d.winograd >= 4) ? 4 : 3;   // 1 / 2 were F(2x2,3x3) (removed in round 5): the F(4x4) forms of the same scope
-    d.precision = d.precision ? 1 : 0;
+    d.precision = d.precision < 0 ? 0 : d.precision > 2 ? 1 : d.precision;   // 0 fp32 MFMA, 1 fp16 MFMA, 2 fp32-accurate GEMMs on the bf16 MFMA (td_gemm_b3.h)
     d.pipeline = d.pipeline ? 1 : 0;
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;
@@ -181,7 +183,7 @@ struct ProfRec { int family; int dominant; hipEvent_t e0, e1; double flops; };  
 // two lanes of a frame-pipelined clip, clips sharing a GPU) -- the reference's batch shares ONE nn.Module's parameters the same way
 // (td4_psp18.py:216-229).  Reference-counted; freed with the last handle, whatever the destroy order.
 struct TdWeights {
-    int refs = 1;
+    std::atomic<int> refs{1};                                          // handles on this block; tdnet_create_shared / tdnet_destroy may run on different host threads
     int device = 0;
     std::vector<BlockSpec> bspec;
     std::map<std::string, std::vector<float>> sd;                      // host state_dict until finalize
@@ -242,8 +244,7 @@ struct tdnet {
     std::vector<float*> seg_t, seg_r, seg_x;
     std::vector<hipStream_t> probe_streams;                            // TDNET_PROBE_EXTRA_STREAMS (-DTDNET_TIMING_PROBES builds only)
     std::vector<hipStream_t> retired_streams;                          // chain2 candidates that shared the caller's hardware queue (place_chain_stream)
-    bool placed = false;
-    void* placed_for = nullptr;                                        // the caller stream chain2 was checked against
+    std::vector<void*> placed_for;                                     // the caller streams chain2 has been checked against (place_chain_stream): once per stream
     int chain_replaced = 0;
     float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
     _Float16* vt16 = nullptr;                                         // fp16 attention: V' transposed [DV][LkPad]

@@ -88,7 +88,7 @@ extern "C" int tdnet_create_shared(const tdnet_t* weights_of, const tdnet_opts* 
     }
     TD_ON_DEVICE(weights_of, -1);
     tdnet* n = new tdnet(weights_of->wt);
-    n->wt->refs++;
+    n->wt->refs.fetch_add(1, std::memory_order_relaxed);
     set_geometry(n, &weights_of->cfg);
     n->opts = weights_of->opts;
     if (init_handle(n)) { tdnet_destroy(n); return -1; }
@@ -120,7 +120,7 @@ extern "C" void tdnet_destroy(tdnet_t* n) {
     if (n->ev_join2) hipEventDestroy(n->ev_join2);
     TdWeights* wt = n->wt;
     delete n;
-    if (--wt->refs == 0) {                                             // the last handle of the block, whichever it is (the owner may go first)
+    if (wt->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {                                             // the last handle of the block, whichever it is (the owner may go first)
         for (auto& p : wt->paths) free_path(p);
         delete wt;
     }
@@ -156,13 +156,20 @@ extern "C" int tdnet_memory_bytes(const tdnet_t* n, size_t* weights, size_t* han
     if (!n) return td_fail("tdnet_memory_bytes: null handle");
     if (weights) *weights = n->wt->device_bytes;
     if (handle) *handle = n->ws_bytes;
-    return n->wt->refs;
+    return n->wt->refs.load(std::memory_order_relaxed);
 }
 extern "C" int tdnet_last_launch_count(const tdnet_t* n) { return n ? n->launches : -1; }
 
+// tdnet_last_launch_count: everything a frame entry enqueued, the final upsample / argmax kernel included (counted in TD_LAUNCH itself)
+struct LaunchCount {
+    tdnet* n; long l0;
+    explicit LaunchCount(tdnet* n_) : n(n_), l0(td_launch_count) {}
+    ~LaunchCount() { n->launches = (int)(td_launch_count - l0); }
+};
 extern "C" int tdnet_forward(tdnet_t* n, const float* img, int pos_id, float* logits, void* stream) {
     if (!n || !img || !logits) return td_fail("tdnet_forward: null argument");
     TD_ON_DEVICE(n, -1);
+    LaunchCount count_(n);
     hipStream_t s = (hipStream_t)stream;
     if (forward_lowres(n, img, pos_id, s)) return -1;
     prof_begin(n, 2, false, 0, s);
@@ -181,6 +188,7 @@ extern "C" int tdnet_argmax(tdnet_t* n, const float* logits, int32_t* labels, vo
 extern "C" int tdnet_forward_labels(tdnet_t* n, const float* img, int pos_id, int32_t* labels, void* stream) {
     if (!n || !img || !labels) return td_fail("tdnet_forward_labels: null argument");
     TD_ON_DEVICE(n, -1);
+    LaunchCount count_(n);
     hipStream_t s = (hipStream_t)stream;
     if (forward_lowres(n, img, pos_id, s)) return -1;
     prof_begin(n, 2, false, 0, s);
@@ -203,13 +211,12 @@ extern "C" int tdnet_encode(tdnet_t* n, const float* img, int pos_id, void* stre
     n->nrec = 0;
     n->failed = false;
     TD_TRY(place_chain_stream(n, (hipStream_t)stream));
-    const long l0 = td_launch_count;
+    LaunchCount count_(n);
     if (encode_frame(n, n->paths[pos_id], img, (hipStream_t)stream)) {  // a failed frame is dropped (as in tdnet_forward): no entry stays pending
         rejoin_streams(n, (hipStream_t)stream);
         n->pending_slot = n->pending_pos = -1;
         return -1;
     }
-    n->launches = (int)(td_launch_count - l0);
     n->pending_pos = pos_id;
     TD_HIP(hipGetLastError());
     return 0;
@@ -224,6 +231,7 @@ static int propagate_lowres(tdnet* n, hipStream_t s) {
 extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
     if (!n || !logits) return td_fail("tdnet_propagate: null argument");
     TD_ON_DEVICE(n, -1);
+    LaunchCount count_(n);
     hipStream_t s = (hipStream_t)stream;
     if (propagate_lowres(n, s)) return -1;
     launch_upsample(n->lowres, n->cfg.nclass, n->h, n->w, n->H, n->W, logits, s);
@@ -233,6 +241,7 @@ extern "C" int tdnet_propagate(tdnet_t* n, float* logits, void* stream) {
 extern "C" int tdnet_propagate_labels(tdnet_t* n, int32_t* labels, void* stream) {
     if (!n || !labels) return td_fail("tdnet_propagate_labels: null argument");
     TD_ON_DEVICE(n, -1);
+    LaunchCount count_(n);
     hipStream_t s = (hipStream_t)stream;
     if (propagate_lowres(n, s)) return -1;
     TD_LAUNCH(k_upsample_argmax, dim3(td_grid_for((long)n->H * n->W)), dim3(256), 0, s, (const float*)n->lowres, labels, n->cfg.nclass,

@@ -13,7 +13,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     L.pers = o.gemm_persistent;
     const bool deep = o.pipeline != 0;
     if (!stem && Cin % 32 != 0) return td_fail("conv: Cin=%d is not a multiple of 32", Cin);
-    const bool wino_ok = o.winograd && !o.precision && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
+    const bool wino_ok = o.winograd && o.precision != 1 && !stem && KS == 3 && stride == 1 && Cin % 32 == 0 && Cout % 4 == 0 &&
                          (o.winograd == 4 || (Cin >= 128 && Cout >= 128));
     L.wino = wino_ok ? 4 : 0;
     L.wino_pad = (L.wino && (o.fusion & 64) && o.gemm_persistent && gemm_supports(Cin)) ? 24 : 0;   // 24 rows: 12..48 KB between plane phases
@@ -32,11 +32,22 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         L.nsteps = conv_nsteps(Cin, 1, 0);
         std::vector<std::vector<float>> U;
         wino_transform_weights(w.data(), Cout, Cin, L.wino, U);
+        if (o.precision == 2 && pers && gemm_b3_supports(Cin, Cout)) {
+            // the 36 GEMMs on the bf16 MFMA, fp32-accurate (td_gemm_b3.h): the Winograd-domain weights as three bf16 parts, split here once
+            L.b3 = forced_tile >= 0 ? (conv_tile_dims((ConvTile)forced_tile).BM == 64 ? 2 : 4) : gemm_b3_pick_wr(wino_tiles_estimate(M, dil, L.wino) / chunks, nb, Cout);
+            L.CoutPad = gemm_b3_npad(Cout);
+            const size_t per = gemm_b3_packed_bytes(Cin, Cout) / 2;
+            std::vector<unsigned short> packed(nb * per);
+            for (int bi = 0; bi < nb; ++bi) gemm_b3_pack(U[bi].data(), Cout, Cin, packed.data() + bi * per);
+            TD_TRY(dev_alloc((unsigned short**)&L.d_wp, packed.size()));
+            TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        } else {
         const size_t per = (size_t)L.nsteps * 8 * L.CoutPad * 4;
         std::vector<float> packed(nb * per);
         for (int bi = 0; bi < nb; ++bi) conv_pack_weights(U[bi].data(), Cout, Cin, 1, 0, L.tile, packed.data() + bi * per);
         TD_TRY(dev_alloc(&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         std::vector<float> bb(Cout, 0.f), zz(Cout, 0.f);
         if (!b.empty()) bb = b;
         TD_TRY(dev_alloc(&L.d_bias, (size_t)Cout));
@@ -45,8 +56,8 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         TD_HIP(hipMemcpy(L.d_zero, zz.data(), Cout * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     }
-    L.h16 = o.precision && !stem && Cin % 64 == 0;
-    const bool stem16 = o.precision && stem && KS == 7 && stride == 2 && Cout <= 64;    // fp16-MFMA stem (td_conv_h.h)
+    L.h16 = o.precision == 1 && !stem && Cin % 64 == 0;
+    const bool stem16 = o.precision == 1 && stem && KS == 7 && stride == 2 && Cout <= 64;    // fp16-MFMA stem (td_conv_h.h)
     const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && o.gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
     L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout, deep) : conv_pick_tile((int)M, Cout, deep);
     // fp16 mode, ResNet layer1 (64 -> 64, 3x3 stride 1): packed for the 128-wide two-wave-column tile, of which the narrow LDS-DMA kernel
@@ -67,6 +78,15 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         conv_pack_weights_h(w.data(), Cout, Cin, KS, L.tile, packed.data());
         TD_TRY(dev_alloc((_Float16**)&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    } else if (o.precision == 2 && gemm1x1 && gemm_b3_supports(Cin, Cout)) {
+        // precision 2: a stride-1 1x1 conv is one GEMM on the bf16 MFMA with its weights as three bf16 parts (td_gemm_b3.h)
+        L.b3 = forced_tile >= 0 ? (conv_tile_dims((ConvTile)forced_tile).BM == 64 ? 2 : 4) : gemm_b3_pick_wr(M, 1, Cout);
+        L.CoutPad = gemm_b3_npad(Cout);
+        L.nsteps = Cin / 16;
+        std::vector<unsigned short> packed(gemm_b3_packed_bytes(Cin, Cout) / 2);
+        gemm_b3_pack(w.data(), Cout, Cin, packed.data());
+        TD_TRY(dev_alloc((unsigned short**)&L.d_wp, packed.size()));
+        TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     } else {
         // the 7x7 stem with its A operand straight from global memory can read a packed-row image instead of NHWC4 taps: K = 168 instead of 224
         L.stem_rows = stem && KS == 7 && stride == 2 && (o.fusion & 65536) && (o.fusion & 32) && conv_adirect_supports(L.tile, 1);
@@ -212,7 +232,7 @@ static bool conv_chainable(int cin, int cout, int stride, int dil) {
 static void plan_chains(tdnet* n) {
     n->seg_block = -1; n->seg_conv = 0;
     const tdnet_opts& o = n->opts;
-    if (!(o.overlap & 1) || o.winograd < 3 || o.precision || !o.gemm_persistent || n->deep) return;
+    if (!(o.overlap & 1) || o.winograd < 3 || o.precision == 1 || !o.gemm_persistent || n->deep) return;
     // The chains pay on LARGE maps only: td4-psp18, frames/s with / without them (profiles/r05g_*): 512x1024 (8192 feature pixels) 805 / 822,
     // 640x1280 (12800) 565 / 575, 769x1537 (18721) 384.5 / 391.9, 896x1792 (25088) 324.1 / 321.7, 1024x2048 (32768) 273.8 / 269.1 -- two
     // half-size GEMMs fill the chip less well than one, and below ~23 k pixels that costs more than the hidden transforms return.
@@ -300,7 +320,7 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
     if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
-    if (n->opts.precision && dev_alloc(&n->vt16, (size_t)n->DV * attn_lkpad((int)lk))) return -1;
+    if (n->opts.precision == 1 && dev_alloc(&n->vt16, (size_t)n->DV * attn_lkpad((int)lk))) return -1;
     n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;
@@ -413,7 +433,7 @@ static int finalize_block(tdnet* n) {
         {
             Folded fv = fold(n, ep + ".w_vs.0.conv.weight", ep + ".w_vs.0.conv.bias", "", DV);
             // fp16 mode with grouped launches: the value conv on the 64-channel tile of the query / key convs it shares a launch with
-            const int vtile = (n->opts.precision && (n->opts.fusion & 131072)) ? (int)conv_pick_tile((int)n->Lq, 64, n->opts.pipeline != 0) : -1;
+            const int vtile = (n->opts.precision == 1 && (n->opts.fusion & 131072)) ? (int)conv_pick_tile((int)n->Lq, 64, n->opts.pipeline != 0) : -1;
             if (make_conv_layer(L.enc_v, fv.w, fv.b, DV, C, 1, 1, 1, 0, false, n->Lq, n->opts, vtile)) return -1;
             Folded q0 = fold(n, ep + ".w_qs.0.conv.weight", ep + ".w_qs.0.conv.bias", ep + ".w_qs.0.bn", 64);
             if (make_conv_layer(L.enc_q0, q0.w, q0.b, 64, C, 1, 1, 1, 2, false, n->Lq, n->opts)) return -1;
@@ -449,7 +469,7 @@ static int finalize_block(tdnet* n) {
     // The rim: the 7x7 stem runs on the fp16 MFMA from the fp32 image and writes an fp16 map (the 3x3 deep stem's first conv stays an
     // fp32 kernel with an fp32 map), and c4 -- the LAST conv of the backbone -- writes fp32 for the pyramid, Encoding and head
     // kernels, which keep fp32 storage.
-    n->act16 = n->opts.precision != 0;
+    n->act16 = n->opts.precision == 1;
     if (n->act16)
         for (auto& L : n->paths) {
             bool all16 = true;

@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct dim3 {
     unsigned x, y, z;
@@ -81,6 +82,7 @@ extern thread_local char* g_lds;
 void syncthreads();
 f32x16 mfma32(float a, float b, f32x16 c);
 f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c);
+f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c);
 float shfl_xor(float v, int mask);
 void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t lds_bytes);
 }  // namespace tdemu
@@ -163,6 +165,15 @@ TD_DEV void td_buf_ld16_lds(TdBuf b, char* lds_wave_base, unsigned voff_bytes, u
 
 TD_DEV f32x16 td_mfma32(float a, float b, f32x16 c) { return tdemu::mfma32(a, b, c); }
 TD_DEV f32x16 td_mfma32_f16(f16x8 a, f16x8 b, f32x16 c) { return tdemu::mfma32_f16(a, b, c); }
+TD_DEV f32x16 td_mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) { return tdemu::mfma32_bf16(a, b, c); }
+// fp32 -> bf16 bits, round to nearest even (NaN stays NaN): what v_cvt_pk_bf16_f32 does per element
+TD_DEV unsigned tdemu_bf16_rne(float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+TD_DEV unsigned td_pk_bf16(float a, float b) { return tdemu_bf16_rne(a) | (tdemu_bf16_rne(b) << 16); }
 TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
 TD_DEV float td_swap1(float v) { return tdemu::shfl_xor(v, 1); }
 TD_DEV bool td_any(bool pred) {

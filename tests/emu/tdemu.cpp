@@ -171,6 +171,30 @@ f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c) {
     }
     return c;
 }
+// v_mfma_f32_32x32x16_bf16: same maps as the fp16 form; an operand is 8 bf16 packed two per dword.  Products of two bf16 are exact in
+// fp32; the 16 products of an output are summed in double here and rounded once with the accumulator (the hardware's internal order is
+// not documented -- the tests that use this compare against fp64 with a tolerance, never bit for bit).
+f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    Fiber* f = cur;
+    WaveCtx& w = W->waves[f->tidx.x >> 6];
+    const int lane = f->tidx.x & 63, slot = f->seq & 1;
+    f->seq++;
+    auto widen = [](unsigned bits16) { const unsigned u = bits16 << 16; float x; memcpy(&x, &u, 4); return x; };
+    for (int e = 0; e < 8; ++e) {
+        w.a8[slot][lane][e] = widen((a[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        w.b8[slot][lane][e] = widen((b[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+    }
+    wave_barrier(w);
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double s = 0.0;
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) s += (double)w.a8[slot][row + 32 * h][e] * (double)w.b8[slot][col + 32 * h][e];
+        c[r] = (float)((double)c[r] + s);
+    }
+    return c;
+}
 float shfl_xor(float v, int mask) {
     Fiber* f = cur;
     WaveCtx& w = W->waves[f->tidx.x >> 6];

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     ConvArgs a;
     a.in = (const float*)dx; a.wp = (const float*)dw; a.bias = db; a.resid = nullptr; a.out = (float*)dout;
     a.H = H; a.W = W; a.Cin = Cin; a.Wo = W; a.Cout = Cout; a.CoutPad = CoutPad; a.stride = 1; a.dil = dil; a.pad = dil; a.M = H * W;
-    a.nsteps = nsteps; a.act = 1; a.tiles_n = 0; a.stagger = 0; a.nbatch = 1;
+    a.nsteps = nsteps; a.act = 1; a.tiles_n = 0; a.nbatch = 1;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) conv_launch_dma(a, code, KS, true, 0);
     hipEventRecord(e0, 0);

@@ -20,7 +20,7 @@ __global__ void k_fill(float* p, size_t n, unsigned seed) {
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 131072, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 128;
     const int nbatch = argc > 4 ? atoi(argv[4]) : 1;
-    const int tile = argc > 5 ? atoi(argv[5]) : 0, stagger = argc > 6 ? atoi(argv[6]) : 0, dynamic = argc > 7 ? atoi(argv[7]) : 0;   // tile 0: 128x128, 1: 64x128
+    const int tile = argc > 5 ? atoi(argv[5]) : 0, dynamic = argc > 7 ? atoi(argv[7]) : 0;   // tile 0: 128x128, 1: 64x128 (argv[6] was `stagger`, removed with the field in round 5; the position is kept)
     float *a, *w, *bias, *out; unsigned long long* tr;
     const size_t na = (size_t)nbatch * M * K, nw = (size_t)nbatch * K * N, no = (size_t)nbatch * M * N;
     hipMalloc(&a, na * 4); hipMalloc(&w, nw * 4); hipMalloc(&bias, N * 4); hipMalloc(&out, no * 4);
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     k_fill<<<1024, 256>>>(a, na, 1); k_fill<<<1024, 256>>>(w, nw, 2); k_fill<<<1, 256>>>(bias, N, 3);
     GemmArgs g{};
     g.a = a; g.wp = w; g.bias = bias; g.resid = nullptr; g.out = out; g.M = M; g.N = N; g.NPad = N; g.K = K; g.nbatch = nbatch; g.act = 1;
-    g.MP = M; g.stagger = stagger; g.trace = tr;
+    g.MP = M; g.trace = tr;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {                                  // the last launch is the one dumped
         hipEventRecord(e0, 0);
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     const int tiles = (M / BM) * (N / 128) * nbatch, per_wg = (tiles + grid - 1) / grid;
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < grid; ++b) t0 = std::min(t0, h[b * 64 + 2]);
-    printf("# dynamic %d tile %d stagger %d M %d N %d K %d nbatch %d: %.4f ms, %d tiles, %d per workgroup; times in us from the first workgroup's start\n", dynamic, tile, stagger, M, N, K, nbatch, ms, tiles, per_wg);
+    printf("# dynamic %d tile %d M %d N %d K %d nbatch %d: %.4f ms, %d tiles, %d per workgroup; times in us from the first workgroup's start\n", dynamic, tile, M, N, K, nbatch, ms, tiles, per_wg);
     printf("# wg xcc se sh cu simd wave | start | (kloop_end epi_end) per tile\n");
     for (int b = 0; b < grid; ++b) {
         const unsigned long long* r = &h[b * 64];
