@@ -49,6 +49,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")   # before the HIP runtime start
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_FP16_MFMA_TFLOPS = 2500.0
+PEAK_BF16X3_TFLOPS = 2500.0 / 6.0      # precision 2: six bf16-MFMA products per fp32 product (td_gemm_b3.h): the dense bf16 MFMA peak / 6 = 416.7
 
 
 def parse_args(argv=None):
@@ -76,9 +77,11 @@ def parse_args(argv=None):
     ap.add_argument("--fusion", type=int, default=None, help="bit mask of launch-level fusions (include/tdnet.h tdnet_opts.fusion)")
     ap.add_argument("--gemm-persistent", type=int, default=None, help="tuning: 1 persistent GEMM on a full wave of workgroups (default), 0 one tile per workgroup, n > 1 grid forced to n")
     ap.add_argument("--overlap", type=int, default=None, help="bit mask (include/tdnet.h tdnet_opts.overlap): 1 = layers 3-4 as two row-parity chains on two streams, 2 = low-register Winograd transforms everywhere, bits 4-5 = channels per lane")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "bf16x3"],
                     help="fp32 (default; the mode the parity gate is defined for) | fp16 = fp16 MFMA, fp32 accumulate (BASELINE "
-                         "config 5); parity vs the fp32 CPU path is gated at 3e-2 / 99.5 % of the labels / mIoU 0.99 (tests/test_gpu_fp16.py)")
+                         "config 5); parity vs the fp32 CPU path is gated at 3e-2 / 99.5 % of the labels / mIoU 0.99 (tests/test_gpu_fp16.py) | "
+                         "bf16x3 = tdnet_opts.precision 2: fp32 operands split three ways into bf16, six products on the bf16 MFMA, fp32 "
+                         "accumulate (fp32-accurate, opt-in; held to the fp32 gate)")
     ap.add_argument("--clips-per-gpu", type=int, default=1,
                     help="independent clips served concurrently by one GPU, each with its own handle/FIFO on its own HIP stream "
                          "(throughput mode; a step is then one frame of EVERY clip).  Default 1 = BASELINE's one clip per GPU")
@@ -446,7 +449,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     kopts = {"winograd": args.winograd, "pipeline": args.conv_pipeline, "attention": args.attention, "fusion": args.fusion, "overlap": args.overlap, "gemm_persistent": args.gemm_persistent,
-             "precision": 1 if args.precision == "fp16" else None}
+             "precision": 1 if args.precision == "fp16" else 2 if args.precision == "bf16x3" else None}
     kopts = {k: v for k, v in kopts.items() if v is not None}
     if args.backbone is None:
         args.backbone = "resnet101" if args.model == "psp" else "resnet18"
@@ -603,7 +606,8 @@ def main():
     res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
            "value": None if args.dry_run else round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": nwarm,
            "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.precision == "fp32" else "f16 (fp16 MFMA convs + attention, fp16 activation maps in the backbone, fp32 accumulate / softmax / LayerNorm)",
+           "dtype": "f32" if args.precision == "fp32" else "f32 via bf16x3 split, fp32 accumulate (GEMM operands as three bf16 parts, six products on the bf16 MFMA)" if args.precision == "bf16x3"
+                    else "f16 (fp16 MFMA convs + attention, fp16 activation maps in the backbone, fp32 accumulate / softmax / LayerNorm)",
            "data": "synthetic",
            "world_size_seen": world_seen, "backend": backend, "rccl_bcast_ms": round(bcast_ms, 3),
            "bcast_bytes": 4 * nparam if world > 1 else 0, "per_rank_fps": [round(v, 3) for v in per_rank],
@@ -689,7 +693,7 @@ def main():
                 tdnet_ref.tune_threads()
                 oracle = tdnet_ref.TDNetRef(spec, sd)
                 keep = []
-                par0, _, _ = parity_sample(model, oracle, clip, P, nchk, 0, args.precision == "fp32", torch, np, tdnet_ref, keep_labels=keep)
+                par0, _, _ = parity_sample(model, oracle, clip, P, nchk, 0, args.precision != "fp16", torch, np, tdnet_ref, keep_labels=keep)
                 model.reset()
                 res["parity"] = par0
                 if par0.get("FAILED"):
@@ -711,7 +715,7 @@ def main():
         eng = model.engine
         opts = eng.opts()
         gflop = eng.flops_per_frame() / 1e9
-        peak = PEAK_FP16_MFMA_TFLOPS if opts["precision"] else PEAK_FP32_MFMA_TFLOPS
+        peak = PEAK_FP16_MFMA_TFLOPS if opts["precision"] == 1 else PEAK_BF16X3_TFLOPS if opts["precision"] == 2 else PEAK_FP32_MFMA_TFLOPS
         res["config"]["kernel_opts"] = opts
         # ---- roofline of the dominant kernel: profiled replay (HIP events around every launch, same stream) ----------
         nprof = 2 * P
@@ -738,12 +742,15 @@ def main():
         dom_regex = None
         if dom_n > 0 and dom_ms > 0:
             achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-            if opts["precision"]:
+            if opts["precision"] == 1:
                 kname, dom_regex = ("k_conv_dma_h3<RH,..> / k_conv_dma_h3p<RH,..> (dedicated loader waves) / k_conv_dma_h3n<RH,..> (narrow tiles) / k_conv_dma_h<RH,3,..> (3x3 dilated convs on fp16 maps, fp16 MFMA fed by LDS-DMA, fp32 accumulate; td_conv_hd.h) + "
                                     "k_conv_igemm_h<..,3,true,..> where the register-staged kernel is kept"), r"k_conv_dma_h3[a-z]?<|k_conv_dma_h<\d, 3|k_conv_igemm_h<\d+, \d+, \d, \d, 3, true|k_conv_igemm_h_group<\d+, \d+, \d, \d, 3, 1, true"
             elif opts["winograd"]:
                 f4 = opts["winograd"] >= 3
-                if opts["gemm_persistent"]:
+                if opts["precision"] == 2 and opts["gemm_persistent"]:
+                    gk, dom_regex = ("k_gemm_b3m<1> (fp32 operands as three bf16 parts, six bf16-MFMA products, fp32 accumulate; td_gemm_b3.h) [+ k_gemm_dma where a GEMM is too small for it]",
+                                     r"k_gemm_b3m?<|k_gemm_dma\(|k_gemm_persistent<\d+, \d+, \d+, \d+, 1>")
+                elif opts["gemm_persistent"]:
                     gk, dom_regex = ("k_gemm_dma (LDS-DMA-fed, tdnet_opts.overlap bit 8) / k_gemm_persistent<*,*,*,*,ROLE=1>",
                                      r"k_gemm_dma\(|k_gemm_persistent<\d+, \d+, \d+, \d+, 1>")
                 else:
@@ -757,13 +764,13 @@ def main():
                                "frac": round(achieved / peak, 4), "traffic": None,
                                "avg_launch_ms": round(dom_ms / dom_n, 4), "launches_per_frame": dom_n / nprof,
                                "gflop_per_launch": round(dom_fl / dom_n / 1e9, 2)}
-            if opts["precision"] and acc[4][2] > 0:                    # fp16 mode: the FIXED layer set is the headline fraction (roofline_block)
+            if opts["precision"] == 1 and acc[4][2] > 0:                    # fp16 mode: the FIXED layer set is the headline fraction (roofline_block)
                 res["roofline"].update(roofline_block(acc, True, peak, nprof))
                 res["roofline"]["traffic"] = None
         # With the row-parity chains (tdnet_opts.overlap) two launches of the dominant kernel are in flight at a time, each progressing at
         # about half speed: `frac` (per-launch durations, the figure rocprofv3's kernel stats reproduce) then understates the kernel.
         # The same replay on a handle WITHOUT the chains gives the kernel's own rate, reported beside it.
-        if "roofline" in res and opts.get("overlap", 0) & 1 and opts["winograd"] >= 3 and not opts["precision"] and world == 1 and pp is None and not args.no_direct_line:
+        if "roofline" in res and opts.get("overlap", 0) & 1 and opts["winograd"] >= 3 and opts["precision"] != 1 and world == 1 and pp is None and not args.no_direct_line:
             ms_ = make_model(dict(kopts, overlap=0))
             st2 = {"t": 0}
 
@@ -835,7 +842,7 @@ def main():
             cores = tdnet_ref.tune_threads()          # threads actually used (fastest of 8..128 on a probe conv)
             ref = (tdnet_ref.PSPNetRef if args.model == "psp" else tdnet_ref.TDNetRef)(spec, sd)
             nw, nsteady = P, max(1, args.cpu_frames)
-            par, cpu_t, _ = parity_sample(model, ref, clip, P, nw, nsteady, args.precision == "fp32", torch, np, tdnet_ref)
+            par, cpu_t, _ = parity_sample(model, ref, clip, P, nw, nsteady, args.precision != "fp16", torch, np, tdnet_ref)
             res["cpu_baseline"] = {"value": round(nsteady / cpu_t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d steady-state frames of the same clip (after %d warm-up frames), oracle/tdnet_ref.py "
                                              "= the reference's op graph on torch-CPU %s with %d threads (host has %d)"

@@ -226,21 +226,6 @@ class PathParallelStream:
             self._buf = torch.zeros(self.world, nq + nk + nv, dtype=torch.float32, device=self.device)
         return self._buf
 
-    @classmethod
-    def from_model(cls, model, path_num, device, frame_size, lanes=2):
-        """`lanes` lanes on ONE weight block: lane 0 is `model` itself, every further lane an instance of the same class whose handle is a
-        tdnet_create_shared handle of model's (own workspace, K/Q/V FIFO and streams; no second copy of the packed weights, no second
-        fold / pack / upload -- the reference's module is one set of parameters too).  model.share_weights_with documents the ownership."""
-        H, Wd = int(frame_size[0]), int(frame_size[1])
-        model.ensure_engine(H, Wd, device)
-        stages = [model]
-        for _ in range(lanes - 1):
-            kw = dict(nclass=model.nclass, model_path=None, backbone=model.backbone, kernel_opts=model.kernel_opts, synthetic_seed=model.synthetic_seed)
-            if getattr(model, "_model_id", None) != 1:
-                kw["path_num"] = model.path_num
-            stages.append(type(model)(**kw).eval().share_weights_with(model))
-        return cls(stages, path_num, device, frame_size)
-
     def _split(self, row):
         nq, nk, nv = self._sizes
         return row[:nq], row[nq:nq + nk], row[nq + nk:]

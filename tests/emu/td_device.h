@@ -173,6 +173,7 @@ TD_DEV unsigned tdemu_bf16_rne(float x) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+TD_DEV float td_sub1(float a, float b) { return a - b; }
 TD_DEV unsigned td_pk_bf16(float a, float b) { return tdemu_bf16_rne(a) | (tdemu_bf16_rne(b) << 16); }
 TD_DEV float td_shfl_xor(float v, int mask) { return tdemu::shfl_xor(v, mask); }
 TD_DEV float td_swap1(float v) { return tdemu::shfl_xor(v, 1); }

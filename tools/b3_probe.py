@@ -21,7 +21,7 @@ def accuracy(H, W, Cin, Cout, KS, dil, seed=0):
     ref = ref[0].permute(1, 2, 0).numpy()
     dx = torch.from_numpy(x).cuda()
     row = []
-    for name, kw in (("fp32", {}), ("b3", {"precision": 2}), ("b3 wr2", {"precision": 2, "_tile": 4})):
+    for name, kw in (("fp32", {}), ("b3", {"precision": 2}), ("b3 wr2", {"precision": 2, "_tile": 4}), ("b3 m", {"precision": 2, "_tile": 5})):
         tile = kw.pop("_tile", -1)
         out = torch.full((H, W, Cout), 7e7, device="cuda")
         o = lib.opts(**kw)
@@ -40,7 +40,7 @@ SHAPES = [("layer4 512->512 d4", 128, 256, 512, 512, 4), ("layer4 256->512 d4", 
           ("head 512->128", 128, 256, 512, 128, 1), ("layer2 128->128", 128, 256, 128, 128, 1),
           ("native l4 512->512 d4", 97, 193, 512, 512, 4), ("native l3 256->256 d2", 97, 193, 256, 256, 2)]
 VAR = [("fp32", {"overlap": 40}, -1), ("fp32 chunks", {"overlap": 45}, -1), ("b3 auto", {"precision": 2, "overlap": 40}, -1), ("b3 wr4", {"precision": 2, "overlap": 40}, 3),
-       ("b3 wr2", {"precision": 2, "overlap": 40}, 4), ("b3 chunks wr4", {"precision": 2, "overlap": 45}, 3), ("b3 chunks wr2", {"precision": 2, "overlap": 45}, 4)]
+       ("b3 wr2", {"precision": 2, "overlap": 40}, 4), ("b3 m", {"precision": 2, "overlap": 40}, 5), ("b3 chunks wr4", {"precision": 2, "overlap": 45}, 3), ("b3 chunks m", {"precision": 2, "overlap": 45}, 5)]
 for (nm, H, W, Cin, Cout, d) in SHAPES:
     row = []
     for (vn, kw, tile) in VAR:
@@ -52,8 +52,19 @@ for (nm, H, W, Cin, Cout, d) in SHAPES:
     print("%-24s " % nm + " | ".join(row), flush=True)
 for (nm, H, W, Cin, Cout) in (("enc_v 512->512 1x1", 128, 256, 512, 512), ("fc 512->512 on Lk", 32, 64, 512, 512), ("enc_q0 512->64 1x1", 128, 256, 512, 64)):
     row = []
-    for (vn, kw, tile) in (("fp32", {}, -1), ("b3 auto", {"precision": 2}, -1), ("b3 wr4", {"precision": 2}, 3), ("b3 wr2", {"precision": 2}, 4)):
+    for (vn, kw, tile) in (("fp32", {}, -1), ("b3 auto", {"precision": 2}, -1), ("b3 wr4", {"precision": 2}, 3), ("b3 wr2", {"precision": 2}, 4), ("b3 m", {"precision": 2}, 5)):
         o = lib.opts(**kw)
         ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 1, 1, 1, tile, 20, ctypes.byref(o), None) for _ in range(2))
         row.append("%s %.4f" % (vn, ms))
     print("%-24s " % nm + " | ".join(row), flush=True)
+
+# ---- schedule variants / skip probes of the 256-row Winograd GEMM (a -DTD_B3_PROBE build only: TDNET_EXTRA_CXXFLAGS=-DTD_B3_PROBE) ----
+if os.environ.get("TDNET_EXTRA_CXXFLAGS", "").find("TD_B3_PROBE") >= 0:
+    o = lib.opts(precision=2, overlap=40)
+    for (var, skip) in ((0, 0), (1, 0), (8, 0), (0, 64), (0, 66), (0, 67), (0, 125), (0, 3), (0, 61)):
+        os.environ["TD_B3_VAR"] = str(var); os.environ["TD_B3_SKIP"] = str(skip)
+        row = []
+        for (nm, H, W, Cin, Cout, d) in SHAPES[:3]:
+            ms = min(lib.tdnet_bench_conv(H, W, Cin, Cout, 3, 1, d, 3, 20, ctypes.byref(o), None) for _ in range(2))
+            row.append("%s %.3f" % (nm, ms))
+        print("var %d skip %2d: " % (var, skip) + " | ".join(row), flush=True)
