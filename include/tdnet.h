@@ -58,8 +58,15 @@ typedef struct tdnet_opts {
     int32_t winograd;        /* conv algorithm: 0 = direct implicit GEMM everywhere, 3 (default) = Winograd F(4x4,3x3) for the stride-1 3x3
                                 convs with Cin, Cout >= 128 (ResNet layers 2-4 + FCN head), 4 = F(4x4,3x3) for every stride-1 3x3 (test
                                 hook).  All fp32.  (1, 2 were F(2x2,3x3), removed in round 5; they are read as 3, 4.)                  */
-    int32_t precision;       /* 0 = fp32 MFMA (default; the only mode the 1e-3 logits gate applies to), 1 = fp16 MFMA with fp32
-                                accumulation (BASELINE config 5)                                                                 */
+    int32_t precision;       /* 0 = exact fp32 MFMA (default; the headline), 1 = fp16 MFMA with fp32 accumulation (BASELINE config 5),
+                                2 = OPT-IN, fp32-ACCURATE on the 16x faster bf16 MFMA: the large GEMMs of the frame (the 36 batched GEMMs of every
+                                    Winograd F(4x4) conv, the stride-1 1x1 convs of >= 256 tiles of 256 x 128) take their fp32 operands as the exact
+                                    sum of three bf16 values and multiply six bf16 products with fp32 accumulation (td_gemm_b3.h): every product
+                                    to 2^-26 relative, results not bit-identical to the fp32 MFMA's but held to the SAME gates (1e-3 + tie band on
+                                    the calibrated clips, 4x / 3x of the CPU's own error on un-calibrated init: tests/test_gpu_b3.py).  Everything
+                                    else (attention, direct convs, transforms, storage) is the fp32 path unchanged.  td4-psp18 1024x2048: 276 ->
+                                    303 frames/s, the dominant GEMM 306 -> 187 us (profiles/r06*),
+                                3 = TEST HOOK: 2 with the split kernel at ANY GEMM size (small maps in the tests)                        */
     int32_t pipeline;        /* conv software pipeline: 0 = one-stage prefetch, 1 (default) = two-stage                           */
     int32_t gemm_persistent; /* 1 (default) = stride-1 1x1 convs and the Winograd GEMMs on the persistent multi-tile GEMM kernel,
                                 0 = one tile per workgroup on the conv kernel, n > 1 = persistent with the grid forced to n (tests)  */

@@ -73,7 +73,7 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
     ga.M = W; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = rows; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = ny * W;
     ga.wshare = 1;
     prof_begin(n, 0, 0, 2.0 * rows * W * (double)L.Cin * L.Cout, s);
-    if (L.b3) gemm_b3_launch(ga, L.b3, L.pers > 1 ? L.pers : 0, s);
+    if (L.b3) gemm_b3_launch(ga, L.pers > 1 ? L.pers : 0, s);
     else gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     prof_end(n, s);
     return 0;

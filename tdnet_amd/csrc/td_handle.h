@@ -129,7 +129,7 @@ struct ConvLayer {
     bool rowimg_off = false;                                           // tdnet_opts.fusion bit 2048: keep the tap-by-tap LDS-DMA kernel
     int pers = 1;                                                      // tdnet_opts.gemm_persistent of the owning handle
     int chunks = 1;                                                    // > 1: run as that many row-parity chunks (tdnet_opts.overlap bit 1); the GEMM tile is picked for T / chunks rows
-    int b3 = 0;                                                        // != 0: d_wp holds the three bf16 parts of the weights (td_gemm_b3.h gemm_b3_pack; tdnet_opts.precision = 2), b3 = matrix waves per workgroup (2 / 4)
+    int b3 = 0;                                                        // != 0: d_wp holds the three bf16 parts of the weights (td_gemm_b3.h gemm_b3_pack; tdnet_opts.precision = 2) and the GEMM runs on k_gemm_b3
     bool gdma = false;                                                 // the Winograd GEMMs on the LDS-DMA-fed kernel (td_gemm_dma.h; tdnet_opts.overlap bit 8)
     int vw = 0;                                                        // != 0: the low-register F(4x4) transform kernels with vw channels per lane (td_wino.h k_wino4_*_c)
     int wino = 0;                                                      // Winograd output tile edge m (0 = direct, 4 = F(4x4,3x3)): d_wp = 36 packed 1x1 weight sets (td_wino.h)
@@ -148,7 +148,7 @@ static tdnet_opts opts_or_default(const tdnet_opts* o) {
     if (!o) return d;
     d = *o;
     d.winograd = d.winograd <= 0 ? 0 : (d.winograd == 2 || d.winograd >= 4) ? 4 : 3;   // 1 / 2 were F(2x2,3x3) (removed in round 5): the F(4x4) forms of the same scope
-    d.precision = d.precision < 0 ? 0 : d.precision > 2 ? 1 : d.precision;   // 0 fp32 MFMA, 1 fp16 MFMA, 2 fp32-accurate GEMMs on the bf16 MFMA (td_gemm_b3.h)
+    d.precision = d.precision < 0 ? 0 : d.precision > 3 ? 1 : d.precision;   // 0 fp32 MFMA, 1 fp16 MFMA, 2 fp32-accurate GEMMs on the bf16 MFMA (td_gemm_b3.h), 3 = 2 at any GEMM size (tests)
     d.pipeline = d.pipeline ? 1 : 0;
     d.gemm_persistent = d.gemm_persistent < 0 ? 0 : d.gemm_persistent;
     d.attention = d.attention < 0 ? 0 : d.attention > 2 ? 2 : d.attention;

@@ -96,7 +96,7 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         GemmArgs ga;
         ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
         ga.M = (int)Tc; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP;
-        if (L.b3) gemm_b3_launch(ga, L.b3, L.pers > 1 ? L.pers : 0, s);
+        if (L.b3) gemm_b3_launch(ga, L.pers > 1 ? L.pers : 0, s);
         else if (L.gdma && gemm_dma_supports(L.Cin, L.Cout, L.tile)) gemm_dma_launch(ga, L.pers > 1 ? L.pers : 0, s);
         else gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else {
@@ -161,7 +161,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
         ga.M = a.M; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = 1; ga.act = L.act; ga.tiles_m = ga.tiles_n = 0; ga.MP = a.M;
-        if (L.b3) gemm_b3_launch(ga, L.b3, L.pers > 1 ? L.pers : 0, s);
+        if (L.b3) gemm_b3_launch(ga, L.pers > 1 ? L.pers : 0, s);
         else gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else if (L.adirect && L.stem_rows) {                              // the image is padded already: its own geometry, 3 channels, no padding taps
         ConvArgs r = a;

@@ -32,8 +32,8 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         L.nsteps = conv_nsteps(Cin, 1, 0);
         std::vector<std::vector<float>> U;
         wino_transform_weights(w.data(), Cout, Cin, L.wino, U);
-        const int b3 = !(o.precision == 2 && pers && gemm_b3_supports(Cin, Cout)) ? 0
-                     : forced_tile >= 0 ? gemm_b3_wr_of_tile(forced_tile) : gemm_b3_pick_wr(wino_tiles_estimate(M, dil, L.wino) / chunks, nb, Cout);
+        const int b3 = !(o.precision >= 2 && pers && gemm_b3_supports(Cin, Cout)) ? 0
+                     : (forced_tile >= 0 || o.precision == 3) ? 1 : gemm_b3_pick(wino_tiles_estimate(M, dil, L.wino) / chunks, nb, Cout);   // a forced tile (tests, probes): always the split kernel
         if (b3) {
             // the 36 GEMMs on the bf16 MFMA, fp32-accurate (td_gemm_b3.h): the Winograd-domain weights as three bf16 parts, split here once
             L.b3 = b3;
@@ -80,9 +80,9 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         conv_pack_weights_h(w.data(), Cout, Cin, KS, L.tile, packed.data());
         TD_TRY(dev_alloc((_Float16**)&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    } else if (o.precision == 2 && gemm1x1 && gemm_b3_supports(Cin, Cout) && (forced_tile >= 0 ? gemm_b3_wr_of_tile(forced_tile) : gemm_b3_pick_wr(M, 1, Cout))) {
+    } else if (o.precision >= 2 && gemm1x1 && gemm_b3_supports(Cin, Cout) && (forced_tile >= 0 || o.precision == 3 || gemm_b3_pick(M, 1, Cout))) {
         // precision 2: a large stride-1 1x1 conv is one GEMM on the bf16 MFMA with its weights as three bf16 parts (td_gemm_b3.h)
-        L.b3 = forced_tile >= 0 ? gemm_b3_wr_of_tile(forced_tile) : gemm_b3_pick_wr(M, 1, Cout);
+        L.b3 = 1;
         L.CoutPad = gemm_b3_npad(Cout);
         L.nsteps = Cin / 16;
         std::vector<unsigned short> packed(gemm_b3_packed_bytes(Cin, Cout) / 2);

@@ -607,3 +607,65 @@ def test_split_frame_and_cache_transport_equal_the_single_handle_stream(lib, nam
     assert np.array_equal(out, ref[0])
     for e in ranks + [one]:
         e.close()
+
+
+def test_split_gemm_precision2_ops(lib):
+    """tdnet_opts.precision = 2 / 3 (td_gemm_b3.h): fp32 operands as three bf16 parts, six bf16-MFMA products, fp32 accumulate.  Operator
+    level on the emulator: the Winograd GEMMs (whole conv and row-parity chunks, dilations, ragged tile counts, N not a multiple of 128, N = 64
+    with half a tile of padding), the stride-1 1x1 conv with bias / residual / activations (all three epilogue roles), K = 32 .. 192 (2 .. 12
+    steps of 16: the two-buffer pipeline's prologue and both parities), several tiles per workgroup.  Tolerance of the fp32 kernels."""
+    o3 = {"precision": 3}
+    opcheck.conv(lib, MEM, 13, 21, 128, 128, 3, 1, 2, 1, True, opts=o3)                # dilated 3x3 + residual + ReLU (Winograd, 36 GEMMs)
+    opcheck.conv(lib, MEM, 9, 17, 128, 256, 3, 1, 1, 0, False, opts=o3)                # two N tiles
+    opcheck.conv(lib, MEM, 20, 30, 256, 132, 3, 1, 4, 1, True, opts=dict(o3, overlap=41 | 4))   # row-parity chunks, ragged N
+    opcheck.conv(lib, MEM, 11, 19, 64, 160, 1, 1, 1, 2, True, opts=o3)                 # 1x1: residual + LeakyReLU (ROLE 0)
+    opcheck.conv(lib, MEM, 40, 40, 128, 64, 1, 1, 1, 1, False, opts=o3)                # 1x1 to 64 channels (padded to one 128-column tile), ReLU (ROLE 2)
+    opcheck.conv(lib, MEM, 33, 9, 192, 128, 1, 1, 1, 0, False, opts=o3)                # K = 192: twelve steps; 297 rows: two M tiles, the second ragged
+    opcheck.conv(lib, MEM, 7, 9, 64, 128, 1, 1, 1, 0, True, opts=o3)                   # K = 64: four steps, one ragged tile
+    opcheck.conv(lib, MEM, 70, 70, 64, 256, 1, 1, 1, 0, False, opts=dict(o3, gemm_persistent=3))   # 40 tiles on three workgroups
+    opcheck.conv(lib, MEM, 24, 24, 128, 128, 3, 1, 1, 1, False, opts=dict(o3, gemm_persistent=5))  # 36 batches walked by five workgroups
+    # the size heuristic of precision 2: a GEMM of fewer than 256 tiles stays on the exact-fp32 kernels, bit for bit
+    import ctypes
+    g = np.random.default_rng(3)
+    x = g.standard_normal((13, 21, 128)).astype(np.float32)
+    w = (g.standard_normal((128, 128, 3, 3)) / 34.0).astype(np.float32)
+    outs = []
+    for prec in (0, 2, 3):
+        out = MEM.empty((13, 21, 128))
+        oo = lib.opts(precision=prec)
+        lib.check(lib.tdnet_op_conv2d(MEM.ptr(MEM.put(x)), 13, 21, 128, w.ctypes.data, None, 128, 3, 1, 1, None, 0, ctypes.byref(oo), -1, MEM.ptr(out), None))
+        outs.append(out.copy())
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
+    assert np.abs(outs[0] - outs[2]).max() < 1e-4
+
+
+@pytest.mark.parametrize("name,bb,H,W,opts", [("td2", "resnet18", 33, 65, {"precision": 3, "overlap": 41 | 4}), ("td2", "resnet50", 33, 65, {"precision": 3})])
+def test_pipeline_precision2_against_reference_goldens(lib, golden_dir, name, bb, H, W, opts):
+    """The whole frame with every eligible GEMM on the split kernel (precision 3 = precision 2 at any GEMM size): Winograd convs of layers 2-4 and
+    the head -- whole and as row-parity chains, whose downsample conv is the weight-shared batched form --, the Encoding's value conv, the
+    attention's fc on the cached value matrix, a Bottleneck backbone's 1x1 convs.  Same gate as the fp32 pipeline against the goldens captured
+    from the real reference: every stage within 1e-4 (relative to the stage's scale), logits within 1e-3, labels in the tie band.  (td2: the
+    warm-up frame and the first steady-state one -- the kernels are td4's, and a 256 x 128 tile is slow on the emulator whatever it holds.)"""
+    spec = arch.model_spec(name, 19, bb)
+    h, w = arch.feat_size(H), arch.feat_size(W)
+    g = np.load(os.path.join(golden_dir, "%s_%s_%dx%d.npz" % (name, bb, H, W)))
+    T = spec.path_num
+    e = Engine(spec.path_num, int(bb[6:]), 19, H, W, 0, lib=lib, opts=opts)
+    assert e.opts()["precision"] == 3
+    e.load_state_dict(weights.synth_state_dict(spec, h, w, 0))
+    shapes = {"c4": (1, spec.d_model, h, w), "z": (1, spec.d_model, h, w), "v_cur": (1, spec.d_v, h, w), "ln": (1, spec.d_v, h, w), "lowres": (1, 19, h, w)}
+    for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
+        out = np.full((1, 19, H, W), 7e7, np.float32)
+        e.forward(x, t % spec.path_num, out)
+        for st, shp in shapes.items():
+            if "f%d_%s" % (t, st) in g.files:
+                ref = g["f%d_%s" % (t, st)]
+                assert np.abs(e.stage(st, shp) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), (t, st)
+        ref = g["f%d_logits" % t]
+        err = float(np.abs(out - ref).max())
+        assert err <= 1e-3, (t, err)
+        bad = out[0].argmax(0) != ref[0].argmax(0)
+        if bad.any():
+            top2 = np.sort(ref[0], axis=0)[-2:]
+            assert ((top2[1] - top2[0])[bad] <= 2 * err).all(), (t, int(bad.sum()))
+    e.close()
