@@ -90,6 +90,11 @@ def parse_args(argv=None):
                          "stream served by all N ranks, one all-gather of cache entries per round of N frames (a step = one round) | "
                          "frame-pipelined: each rank's ONE clip with two frames in flight (two handles on two HIP streams of the rank, "
                          "parallel.FramePipelinedStream; a step = one round of two frames; throughput mode for maps that leave CUs idle)")
+    ap.add_argument("--graph", action="store_true",
+                    help="the timed loop replays ONE hipGraph per pos_id cycle (P frame calls captured on a stream in steady state: tdnet_amd/graph.py) "
+                         "instead of enqueueing every frame's launches; a step is then one cycle of P frames.  The default run reports the same comparison "
+                         "as the `hipgraph` object of the line without changing `value`")
+    ap.add_argument("--no-numerics-stress", action="store_true", help="skip the un-calibrated-init numerics leg (`numerics_stress`: fp64 oracle on 4 frames at 769x1537)")
     ap.add_argument("--dry-run", action="store_true",
                     help="plumbing check WITHOUT the model (CPU, gloo): rank launch, rendezvous, weight broadcast, barriers, timing "
                          "reduction and the JSON line; `value` is null.  Used by tests/test_bench_launch.py; never a measurement")
@@ -100,7 +105,7 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # this process runs under rocprofv3 for a counter pass
     a = ap.parse_args(argv)
     if a.quick:
-        a.no_cpu_baseline = a.no_pmc = a.no_direct_line = a.no_other_configs = True
+        a.no_cpu_baseline = a.no_pmc = a.no_direct_line = a.no_other_configs = a.no_numerics_stress = True
     return a
 
 
@@ -273,7 +278,61 @@ def latency_synced(step_one, sync, nframes=20, skip=6):
     return 1e3 * tot / max(cnt, 1)
 
 
-def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite, pipelined=False, published_ms=None):
+DTYPE_BF16X3 = "f32 via bf16x3 split, fp32 accumulate (GEMM operands as three bf16 parts, six products on the bf16 MFMA; tdnet_opts.precision = 2, opt-in)"
+
+
+def graph_compare(m, clip, P, NF, H, W, dev, sync, steps, torch):
+    """The clip's steady state as ONE hipGraph per pos_id cycle (tdnet_amd/graph.py GraphedClip: P frame calls captured on a stream, replayed)
+    against the eager loop on the same model: frames/s, host time per frame to enqueue (measured on an empty queue) and bit identity of the
+    replayed frames.  The model is left in step with `clip` at a multiple of P frames."""
+    from tdnet_amd.graph import GraphedClip
+    cycles = max(2, steps // P)
+    with torch.no_grad():
+        m.reset()
+        t = 0
+        for _ in range(2 * P):                                             # steady state, aligned to the cycle
+            m(clip[t % NF], pos_id=t % P); t += 1
+        eager = [m(clip[(t + j) % NF], pos_id=(t + j) % P).clone() for j in range(P)]
+        sync()
+        th = time.perf_counter()
+        for j in range(P):                                                 # host cost of one eager cycle on an empty queue
+            m(clip[(t + P + j) % NF], pos_id=(t + P + j) % P)
+        host_eager = (time.perf_counter() - th) / P * 1e6
+        sync()
+        t0 = time.perf_counter()
+        tt = t + 2 * P
+        for _ in range(cycles * P):
+            m(clip[tt % NF], pos_id=tt % P); tt += 1
+        sync()
+        eager_fps = cycles * P / (time.perf_counter() - t0)
+        # the same frames through the graph: rewind to the state before `eager` was computed
+        m.reset()
+        for u in range(t):
+            m(clip[u % NF], pos_id=u % P)
+        g = GraphedClip(m, H, W, dev)
+        outs = g.replay([clip[(t + j) % NF] for j in range(P)])
+        sync()
+        same = all(torch.equal(a, b) for a, b in zip(outs, eager))
+        sync()
+        th = time.perf_counter()
+        g.replay([clip[(t + P + j) % NF] for j in range(P)])
+        host_graph = (time.perf_counter() - th) / P * 1e6
+        sync()
+        staged = [[clip[(t + c * P + j) % NF] for j in range(P)] for c in range(2)]
+        t0 = time.perf_counter()
+        for c in range(cycles):
+            g.replay(staged[c & 1])
+        sync()
+        graph_fps = cycles * P / (time.perf_counter() - t0)
+        m.reset()
+    return {"what": "P = %d consecutive frame calls captured into one hipGraph on a caller stream (torch.cuda.CUDAGraph) in steady state and replayed per cycle; "
+                    "inputs copied into the graph's static frame buffers (included in the graph figures)" % P,
+            "eager_fps": round(eager_fps, 2), "graph_fps": round(graph_fps, 2), "graph_vs_eager": round(graph_fps / eager_fps, 4),
+            "host_launch_us_per_frame_eager": round(host_eager, 1), "host_launch_us_per_frame_graph": round(host_graph, 1),
+            "frames_timed": cycles * P, "bit_identical_to_eager": bool(same)}
+
+
+def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_frames, dev, sync, cite, pipelined=False, published_ms=None, graph=False):
     """One short leg for another BASELINE.json config on this GPU: frames/s over `steps` steady frames, the dominant kernel's roofline
     fraction (profiled replay) and parity against the CPU oracle on `cpu_frames` steady frames.  Own model, own clip, own oracle."""
     import numpy as np
@@ -286,7 +345,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
     P = spec.path_num
     sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
     cls = td4_psp18.td4_psp18 if model_name == "td4" else td2_psp50.td2_psp50
-    opts = {"precision": 1} if precision == "fp16" else {}
+    opts = {"precision": 1} if precision == "fp16" else {"precision": 2} if precision == "bf16x3" else {}
     if model_name == "psp":
         m = pspnet.pspnet(nclass=19, model_path=None, backbone=backbone, kernel_opts=opts).eval().to(dev)
     else:
@@ -310,7 +369,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         sync()
         dt = time.perf_counter() - t0
     eng = m.engine
-    peak = PEAK_FP16_MFMA_TFLOPS if precision == "fp16" else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_FP16_MFMA_TFLOPS if precision == "fp16" else PEAK_BF16X3_TFLOPS if precision == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
     with torch.no_grad():
         lat_ms = latency_synced(step, sync)
     nlaunch = eng.last_launch_count()
@@ -321,7 +380,7 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
     leg = {"config": tag, "workload": "%s, %dx%d, %s" % (mname, H, W, precision), "reference": cite,
            "value": round(steps / dt, 3), "unit": "frames/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 4),
            "latency_ms_synced": round(lat_ms, 4),
-           "dtype": "f32" if precision == "fp32" else "f16 (fp16 MFMA, fp32 accumulate)", "kernel_opts": eng.opts(),
+           "dtype": "f32" if precision == "fp32" else DTYPE_BF16X3 if precision == "bf16x3" else "f16 (fp16 MFMA, fp32 accumulate)", "kernel_opts": eng.opts(),
            "algorithmic_gflop": round(eng.flops_per_frame() / 1e9, 1), "launches_per_frame": nlaunch,
            "memory": {"weights_bytes": wbytes, "handle_bytes": hbytes}}
     if published_ms:
@@ -330,9 +389,17 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
                             "note": "other hardware, trained checkpoint vs synthetic weights of the same architecture: orientation, not vs_baseline"}
     if dom_n > 0 and dom_ms > 0:
         leg["roofline"] = roofline_block(acc, precision == "fp16", peak, 2 * P)
+        if precision == "bf16x3":
+            leg["roofline"]["kernel"] = ("k_gemm_b3<1> (the Winograd F(4x4) GEMMs with fp32 operands as three bf16 parts: six bf16-MFMA products per fp32 product, fp32 "
+                                         "accumulate; td_gemm_b3.h), executed GEMM FLOP")
+            leg["roofline"]["peak_note"] = "2500 TFLOP/s dense bf16 MFMA / 6 products"
+    if graph:
+        leg["hipgraph"] = graph_compare(m, clip, P, NF, H, W, dev, sync, steps, torch)
+        if not leg["hipgraph"]["bit_identical_to_eager"]:
+            leg.setdefault("parity", {})["FAILED"] = True
     if cpu_frames > 0:
         ref = (tdnet_ref.PSPNetRef if model_name == "psp" else tdnet_ref.TDNetRef)(spec, sd)
-        par, cpu_t, _ = parity_sample(m, ref, clip, P, P, cpu_frames, precision == "fp32", torch, np, tdnet_ref)
+        par, cpu_t, _ = parity_sample(m, ref, clip, P, P, cpu_frames, precision != "fp16", torch, np, tdnet_ref)
         leg["parity"] = par
         leg["cpu_baseline"] = {"value": round(cpu_frames / cpu_t, 4), "unit": "frames/s", "kind": "port", "sample": "%d steady-state frames" % cpu_frames}
     if pipelined:
@@ -379,6 +446,67 @@ def other_config_leg(tag, model_name, backbone, size, precision, steps, cpu_fram
         eng.close()
     del m
     return leg
+
+
+def numerics_stress(dev, torch, np, frames=4, H=769, W=1537):
+    """Numerics at REAL logit magnitudes on the line: td4-psp18 at the checkpoint's geometry (769x1537, [97,193] LayerNorm affine, td4_psp18.py:107-110)
+    with SURVEY 8d's UN-CALIBRATED init (every conv ~ N(0, 2 / (k k C_out)), resnet.py:162-165: logits in the tens), `frames` frames (the last one in
+    steady state), against an fp64 evaluation of the oracle graph ("truth") and the fp32 CPU oracle.  The gate of
+    tests/test_gpu_model.py::test_reference_init_at_the_checkpoints_geometry_769x1537: max|gpu - truth| <= 4x and rms <= 3x the fp32 CPU path's own,
+    max|gpu - cpu| <= 3x the CPU's own error, a label differs from the truth's only inside the truth's top-2 tie band.  One CPU evaluation, three GPU
+    configurations: the default kernels, all-direct convolutions (winograd 0) and precision 2 (bf16x3 split GEMMs)."""
+    from oracle import tdnet_ref                                          # checker only
+    from tdnet_amd import arch, weights
+    from tdnet_amd.model import td4_psp18
+    spec = arch.model_spec("td4", 19, "resnet18")
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0, init="reference")
+    ref32 = tdnet_ref.TDNetRef(spec, sd)
+    ref64 = tdnet_ref.TDNetRef(spec, {k: torch.from_numpy(np.asarray(v)).double() for k, v in sd.items()})
+    clip = weights.synth_video(H, W, frames, seed=1)
+    t0 = time.perf_counter()
+    truth, cpu = [], []
+    for t, x in enumerate(clip):
+        xt = torch.from_numpy(x)
+        truth.append(ref64.forward(xt.double(), t % 4).numpy())
+        cpu.append(ref32.forward(xt, t % 4).double().numpy())
+    cpu_s = time.perf_counter() - t0
+    edges = np.array([0.0, 1e-4, 1e-3, 1e-2, 1e-1, 1.0, np.inf])
+    e_cpu = max(float(np.abs(c - tr).max()) for c, tr in zip(cpu, truth))
+    n = sum(tr.size for tr in truth)
+    r_cpu = (sum(float(((c - tr) ** 2).sum()) for c, tr in zip(cpu, truth)) / n) ** 0.5
+    out = {"workload": "td4-psp18 %dx%d, un-calibrated (reference) init, %d frames; truth = the oracle graph in fp64" % (H, W, frames),
+           "max_abs_truth": round(max(float(np.abs(tr).max()) for tr in truth), 2), "cpu_fp32_max_err": float("%.3e" % e_cpu), "cpu_fp32_rms_err": float("%.3e" % r_cpu),
+           "oracle_seconds": round(cpu_s, 1),
+           "gate": "max err <= 4x and rms <= 3x the fp32 CPU path's own distance to the fp64 truth; max|gpu - cpu| <= 3x that distance; label flips only inside the truth's top-2 tie band",
+           "top2_gap_decades": "[0,1e-4) [1e-4,1e-3) [1e-3,1e-2) [1e-2,1e-1) [1e-1,1) [1,inf)", "configs": {}}
+    for tag, opts in (("default", {}), ("winograd 0 (all-direct convs)", {"winograd": 0}), ("precision 2 (bf16x3 split GEMMs)", {"precision": 2})):
+        m = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None, kernel_opts=opts).eval().to(dev)
+        m.load_state_dict(sd)
+        e_gpu, s_gpu, e_gc, outside = 0.0, 0.0, 0.0, 0
+        gap_hist, flip_hist = np.zeros(6, np.int64), np.zeros(6, np.int64)
+        with torch.no_grad():
+            for t, x in enumerate(clip):
+                o = m(torch.from_numpy(x).to(dev), pos_id=t % 4).cpu().double().numpy()
+                dg = o - truth[t]
+                e_gpu = max(e_gpu, float(np.abs(dg).max())); s_gpu += float((dg ** 2).sum())
+                e_gc = max(e_gc, float(np.abs(o - cpu[t]).max()))
+                top2 = np.sort(truth[t][0], axis=0)[-2:]
+                gap = top2[1] - top2[0]
+                bad = o[0].argmax(0) != truth[t][0].argmax(0)
+                gap_hist += np.histogram(gap, edges)[0]
+                flip_hist += np.histogram(gap[bad], edges)[0]
+                outside += int((gap[bad] > 2 * float(np.abs(dg).max())).sum())
+        m.engine.close()
+        del m
+        r_gpu = (s_gpu / n) ** 0.5
+        c = {"max_err": float("%.3e" % e_gpu), "rms_err": float("%.3e" % r_gpu), "max_err_vs_cpu_own": round(e_gpu / e_cpu, 3), "rms_err_vs_cpu_own": round(r_gpu / r_cpu, 3),
+             "max_abs_gpu_minus_cpu": float("%.3e" % e_gc), "gpu_minus_cpu_vs_cpu_own": round(e_gc / e_cpu, 3),
+             "pixels_per_gap_decade": gap_hist.tolist(), "labels_differing_from_truth_per_gap_decade": flip_hist.tolist(), "flips_outside_tie_band": outside}
+        if e_gpu > 4.0 * e_cpu or r_gpu > 3.0 * r_cpu or e_gc > 3.0 * e_cpu or outside > 0:
+            c["FAILED"] = True
+            out["FAILED"] = True
+        out["configs"][tag] = c
+    return out
 
 
 def roofline_block(acc, fp16, peak, nframes):
@@ -524,7 +652,10 @@ def main():
             fpl_same = all(torch.equal(x, y) for x, y in zip(one, two))
             del one, two
             fpl.reset()
-    FR = C * (2 if fpl is not None else 1)                            # frames per step and rank
+    gclip = {"g": None}
+    if args.graph and (C != 1 or fpl is not None or pp is not None or args.dry_run):
+        raise SystemExit("bench.py --graph: one clip per GPU in the default mode only")
+    FR = C * (2 if fpl is not None else 1) * (P if args.graph else 1)   # frames per step and rank (--graph: a step = one cycle of P frames)
 
     def step(ms=None, n_clips=None):
         ms = models if ms is None else ms
@@ -532,6 +663,10 @@ def main():
         if fpl is not None and ms is models:                          # one round: frames t, t + 1 of the clip, no join between rounds
             out = fpl.process([clip[t % NF], clip[(t + 1) % NF]], first_frame=t, join=False)
             state["t"] = t + 2
+            return out[0]
+        if gclip["g"] is not None and ms is models:                   # --graph: one replay = P frames (t is a multiple of P here)
+            out = gclip["g"].replay([clip[(t + j) % NF] for j in range(P)])
+            state["t"] = t + P
             return out[0]
         if args.dry_run:
             clip[t % NF].add_(1.0)
@@ -558,9 +693,18 @@ def main():
         sync(); parallel.barrier()
         return time.perf_counter() - t0
 
-    nwarm = max(args.warmup, P + 2)
+    # EXACTLY --warmup untimed steps when that fills the FIFO (>= P frames: the first steady-state frame is frame P - 1 .. P); fewer are raised to P and
+    # the line says so (warmup = used, warmup_requested = asked)
+    nwarm = max(args.warmup, P)
     with torch.no_grad():
         for _ in range(nwarm):
+            step()
+        if args.graph:                                                # capture at the start of a cycle, FIFO full; then warm the replay path as well
+            from tdnet_amd.graph import GraphedClip
+            while state["t"] % P or state["t"] < P:
+                step()
+            sync()
+            gclip["g"] = GraphedClip(model, H, W, dev)
             step()
         sync()
         init_s = time.perf_counter() - t_proc0                        # process start -> first steady frame done (import, weights, handle, warm-up)
@@ -572,8 +716,21 @@ def main():
         th0 = time.perf_counter()
         for _ in range(nh):
             step()
-        host_us = (time.perf_counter() - th0) / max(nh, 1) * 1e6
+        host_us = (time.perf_counter() - th0) / max(nh * (P if args.graph else 1), 1) * 1e6
         sync()
+        # N > 1: the SAME process's 1-rank figure, in the same invocation -- rank 0 runs the K steps alone while the others wait at a barrier -- so
+        # that the line carries its own scaling efficiency (N-rank per-GPU frames/s / this) instead of leaning on another run of another box
+        solo_dt = None
+        if world > 1 and pp is None and not args.pmc_child:
+            parallel.barrier()
+            if rank == 0:
+                sync()
+                ts0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                sync()
+                solo_dt = time.perf_counter() - ts0
+            parallel.barrier()
         dt = timed(args.steps)
         # `value` stays the contract's EXACTLY K steps; a window under 0.5 s (K = 20 at 275 frames/s is 73 ms) is re-measured over as
         # many frames as fill 0.5 s -- the same number on every rank (derived from the all-reduced K-step time) -- and printed beside it
@@ -586,6 +743,8 @@ def main():
                 sustained = (n_long, parallel.allreduce_max(torch.tensor([dt_long], dtype=torch.float64, device=dev)).item())
     if args.pmc_child:                                                # counter pass under rocprofv3: the steps above are all it needs
         return 0
+    if args.graph:                                                    # everything below (rank check, profiled replay, parity) runs the eager frame calls again:
+        gclip["g"] = None                                             # the ring is where the eager loop would have left it (t is a multiple of P)
     tmax = parallel.allreduce_max(torch.tensor([dt], dtype=torch.float64, device=dev)).item()
     per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
     per_rank[rank] = FR * args.steps / dt
@@ -601,16 +760,18 @@ def main():
         aff_rank = parallel.gather_strings("node %s cpus %s (%d), %d threads%s" % (aff.get("numa_node"), aff.get("cpus"), aff.get("n_cpus", 0), aff.get("omp_num_threads", 0),
                                                                                "" if aff.get("pinned") else " NOT PINNED: " + str(aff.get("why", ""))), world, dev)
     fps = world * FR * args.steps / tmax
+    hwq_rank = parallel.gather_strings(__import__("tdnet_amd").hw_queue_note(), world, dev) if world > 1 else None
 
     mname = ("psp%s" if args.model == "psp" else args.model + "-psp%s") % args.backbone[6:]
     res = {"metric": "frames/sec (%s, %dx%d, full-resolution logits)" % (mname, H, W),
-           "value": None if args.dry_run else round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": nwarm,
+           "value": None if args.dry_run else round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": nwarm, "warmup_requested": args.warmup,
            "ms_per_step": round(1e3 * tmax / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32" if args.precision == "fp32" else "f32 via bf16x3 split, fp32 accumulate (GEMM operands as three bf16 parts, six products on the bf16 MFMA)" if args.precision == "bf16x3"
                     else "f16 (fp16 MFMA convs + attention, fp16 activation maps in the backbone, fp32 accumulate / softmax / LayerNorm)",
            "data": "synthetic",
            "world_size_seen": world_seen, "backend": backend, "rccl_bcast_ms": round(bcast_ms, 3),
            "bcast_bytes": 4 * nparam if world > 1 else 0, "per_rank_fps": [round(v, 3) for v in per_rank],
+           "per_rank_fps_min_max_spread": [round(min(per_rank), 3), round(max(per_rank), 3), round((max(per_rank) - min(per_rank)) / max(max(per_rank), 1e-9), 4)],
            "init_s_per_rank": [round(v, 2) for v in init_rank],
            "host_launch_us_per_frame": [round(v, 1) for v in host_rank],
            "cpu_affinity": aff_rank if aff_rank is not None else "not pinned (N = 1: the whole host, %d CPUs allowed)" % (len(allowed0) if allowed0 else os.cpu_count() or 1),
@@ -624,6 +785,26 @@ def main():
                                      ("clip-parallel x%d, RCCL weight broadcast only" % world) if pp is None else
                                      ("path-parallel x%d: one stream, one all-gather of %d cache entries per round" % (world, world)),
                       "target_fps_per_gpu": 30}}
+    if args.graph:
+        res["config"]["step"] = "--graph: a step = ONE hipGraph replay = one pos_id cycle of %d frames (frame calls captured on a stream, tdnet_amd/graph.py); value counts frames" % P
+    if world > 1:
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            ver = None
+        res["collective"] = {"backend": backend, "rccl_version": ver, "bcast_ms": round(bcast_ms, 3), "bcast_bytes": 4 * nparam,
+                             "bcast_GBps": round(4 * nparam / max(bcast_ms, 1e-6) / 1e6, 2),
+                             "what": "ONE broadcast of the flat weight blob at start (timed between two barriers, so it includes the slowest rank's readiness); "
+                                     "end-of-run all-reduces of timing / digests / confusion matrix; no per-frame collective",
+                             "hw_queues_per_rank": hwq_rank}
+        if solo_dt is not None or rank != 0:
+            solo_fps = None if solo_dt is None else FR * args.steps / solo_dt
+            res["scaling_check"] = {"solo_fps_rank0": None if (solo_fps is None or args.dry_run) else round(solo_fps, 3),
+                                    "per_gpu_fps": None if args.dry_run else round(fps / world, 3),
+                                    "scaling_efficiency": None if (solo_fps is None or args.dry_run) else round(fps / world / solo_fps, 4),
+                                    "what": "rank 0 alone ran the same K steps in this invocation (the other ranks waiting at a barrier) right before the N-rank timed "
+                                            "loop: efficiency = N-rank frames/s per GPU / that.  No curve has been measured by the builder (no multi-GPU box)"}
     if sustained is not None:
         res["sustained"] = {"steps_timed": sustained[0], "seconds": round(sustained[1], 4),
                             "value": round(world * FR * sustained[0] / sustained[1], 3),
@@ -836,6 +1017,13 @@ def main():
         elif "roofline" in res:
             res["roofline"]["traffic_source"] = "not measured (--no-pmc or N > 1)"
 
+        # ---- the steady state as one hipGraph per cycle, beside the eager loop (N = 1, one clip) ---------------------------------
+        if world == 1 and pp is None and fpl is None and C == 1 and not args.quick:
+            res["hipgraph"] = graph_compare(model, clip, P, NF, H, W, dev, sync, args.steps, torch)
+            if not res["hipgraph"]["bit_identical_to_eager"]:
+                res["hipgraph"]["FAILED"] = True
+                exit_code = 5
+
         # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) ------------------------------------------
         if world == 1 and not args.no_cpu_baseline:
             from oracle import tdnet_ref                                          # checker / baseline only
@@ -843,7 +1031,7 @@ def main():
             ref = (tdnet_ref.PSPNetRef if args.model == "psp" else tdnet_ref.TDNetRef)(spec, sd)
             nw, nsteady = P, max(1, args.cpu_frames)
             par, cpu_t, _ = parity_sample(model, ref, clip, P, nw, nsteady, args.precision != "fp16", torch, np, tdnet_ref)
-            res["cpu_baseline"] = {"value": round(nsteady / cpu_t, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            res["cpu_baseline"] = {"value": round(nsteady / cpu_t, 4), "unit": "frames/s", "cores": cores, "host_threads": os.cpu_count() or 1, "kind": "port",
                                    "sample": "%d steady-state frames of the same clip (after %d warm-up frames), oracle/tdnet_ref.py "
                                              "= the reference's op graph on torch-CPU %s with %d threads (host has %d)"
                                              % (nsteady, nw, torch.__version__, cores, os.cpu_count() or 1)}
@@ -862,11 +1050,15 @@ def main():
                 if m_.engine is not None:
                     m_.engine.close()
             res["other_configs"] = [
+                # OPT-IN arithmetic (the headline stays exact fp32): the same workload with the large GEMMs as six bf16-MFMA products per fp32 product
+                other_config_leg("configs[2] with tdnet_opts.precision = 2 (opt-in)", "td4", "resnet18", (1024, 2048), "bf16x3", 40, min(ncpu, 3), dev, sync,
+                                 "the headline workload; resnet.py:25-59 / transformer.py:126-139 are fp32 throughout: this mode keeps fp32 storage, fp32 accumulation and "
+                                 "fp32-accurate products (2^-26), and is held to the fp32 parity gate", graph=True),
                 other_config_leg("configs[1]", "td2", "resnet18", (1024, 2048), "fp32", 40, ncpu, dev, sync,
                                  "td2_psp50(backbone='resnet18', path_num=2), Testing/model/pspnet/td2_psp50.py:52-58"),
                 other_config_leg("configs[4]", "td2", "resnet34", (720, 960), "fp16", 40, ncpu, dev, sync,
                                  "td2-bise34 does not exist in the reference (SURVEY 0): td2_psp50(backbone='resnet34') is its stand-in; "
-                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path", pipelined=True),
+                                 "fp16 MFMA with fp32 accumulation, parity reported against the fp32 CPU path", pipelined=True, graph=True),
                 # the configurations the reference SHIPS and publishes numbers for, at its native 769x1537 (Testing/test.py:22-38, TEST_README.md:31-33)
                 other_config_leg("native td4-psp18", "td4", "resnet18", (769, 1537), "fp32", 40, ncpu, dev, sync,
                                  "test.py:24-26 `--model td4-psp18` at 769x1537; TEST_README.md:33 publishes 85 ms/frame (Titan Xp)", published_ms=85.0),
@@ -877,6 +1069,10 @@ def main():
                                  "(the stateless ResNet-101 frame is the most expensive on the host)", published_ms=360.0)]
             if any(l.get("parity", {}).get("FAILED") for l in res["other_configs"]):
                 exit_code = 3
+            if not args.no_numerics_stress and not args.no_cpu_baseline:
+                res["numerics_stress"] = numerics_stress(dev, torch, np)
+                if res["numerics_stress"].get("FAILED"):
+                    exit_code = 3
     if rank == 0:
         print(json.dumps(res), flush=True)
     parallel.barrier()

@@ -1,13 +1,15 @@
-"""ctypes binding of include/tdnet.h (libtdnet_hip.so).
+"""ctypes binding of include/tdnet.h (libtdnet_hip.so) and, for tests / tools only, of include/tdnet_test.h (libtdnet_hip_test.so).
 
 The HIP library is the product: importing a model fails loudly when it is missing -- there is no CPU or
-torch fallback anywhere in this package.
+torch fallback anywhere in this package.  The product library exports the C ABI of include/tdnet.h and nothing else; the single-operator entry
+points and probes the tests use live in a second library built from the same sources (tdnet_amd/build.py), loaded by `test_lib()`.
 """
 import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libtdnet_hip.so")
+TEST_LIB = os.path.join(_HERE, "lib", "libtdnet_hip_test.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_void_p = ctypes.c_void_p
@@ -48,6 +50,7 @@ SYMBOLS = {
     "tdnet_warmup": (ctypes.c_int, [c_void_p, c_void_p]),
     "tdnet_memory_bytes": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "tdnet_last_launch_count": (ctypes.c_int, [c_void_p]),
+    "tdnet_streams_share_queue": (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "tdnet_forward": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
     "tdnet_argmax": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_forward_labels": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
@@ -65,10 +68,15 @@ SYMBOLS = {
     "tdnet_last_ms": (ctypes.c_double, [c_void_p, ctypes.c_int]),
     "tdnet_last_flops": (ctypes.c_double, [c_void_p, ctypes.c_int]),
     "tdnet_last_launches": (ctypes.c_double, [c_void_p, ctypes.c_int]),
-    "tdnet_bench_mfma_peak": (ctypes.c_double, [ctypes.c_int, ctypes.c_int, c_void_p]),
-    "tdnet_bench_conv": (ctypes.c_double, [ctypes.c_int] * 9 + [c_opts_p, c_void_p]),
     "tdnet_last_error": (ctypes.c_char_p, []),
     "tdnet_version": (ctypes.c_char_p, []),
+}
+
+
+# include/tdnet_test.h: libtdnet_hip_test.so (and the emulator library) only
+TEST_SYMBOLS = {
+    "tdnet_bench_mfma_peak": (ctypes.c_double, [ctypes.c_int, ctypes.c_int, c_void_p]),
+    "tdnet_bench_conv": (ctypes.c_double, [ctypes.c_int] * 9 + [c_opts_p, c_void_p]),
     "tdnet_op_conv2d": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, c_void_p, ctypes.c_int, c_opts_p, ctypes.c_int,
                                        c_void_p, c_void_p]),
@@ -81,27 +89,27 @@ SYMBOLS = {
     "tdnet_op_layernorm_hw": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tdnet_op_ppm": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, ctypes.c_int, ctypes.c_int,
                                     c_void_p, c_void_p]),
-    "tdnet_op_streams_share_queue": (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "tdnet_op_upsample": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          c_void_p, c_void_p]),
 }
 
 
 class Lib:
-    """A loaded libtdnet shared object with typed entry points; `check()` turns return codes into TdnetError."""
+    """A loaded libtdnet shared object with typed entry points; `check()` turns return codes into TdnetError.  test_symbols: also bind the
+    entry points of include/tdnet_test.h (the tests' library and the emulator build carry them, the product library does not)."""
 
-    def __init__(self, path=DEFAULT_LIB):
+    def __init__(self, path=DEFAULT_LIB, test_symbols=False):
         if not os.path.exists(path):
             raise TdnetError("HIP library not found: %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
-        if path == DEFAULT_LIB:
+        if path in (DEFAULT_LIB, TEST_LIB):
             # PyTorch-ROCm bundles its own HIP runtime under the same SONAME; it must be the one already loaded when this
             # library's libamdhip64 dependency is resolved, or the process ends up with two runtimes and hipSetDevice reports
             # "no ROCm-capable device" (seen on the GPU box when the library was loaded before `import torch`).
             import torch  # noqa: F401
         self.dll = ctypes.CDLL(path)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + (list(TEST_SYMBOLS.items()) if test_symbols else []):
             fn = getattr(self.dll, name)              # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
@@ -125,6 +133,7 @@ class Lib:
 
 
 _default = None
+_test = None
 
 
 def lib():
@@ -133,3 +142,11 @@ def lib():
     if _default is None:
         _default = Lib(DEFAULT_LIB)
     return _default
+
+
+def test_lib():
+    """tests / tools only: the superset library with the single-operator entry points and probes of include/tdnet_test.h."""
+    global _test
+    if _test is None:
+        _test = Lib(TEST_LIB, test_symbols=True)
+    return _test

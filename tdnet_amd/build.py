@@ -14,8 +14,10 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "lib", "libtdnet_hip.so")
+OUT = os.path.join(HERE, "lib", "libtdnet_hip.so")                   # the PRODUCT library: the C ABI of include/tdnet.h, nothing else (csrc/td_model.hip)
+OUT_TEST = os.path.join(HERE, "lib", "libtdnet_hip_test.so")         # + the tests' single-operator entry points and probes (csrc/td_model_test.hip, include/tdnet_test.h)
 HEADER = os.path.join(os.path.dirname(HERE), "include", "tdnet.h")
+HEADER_TEST = os.path.join(os.path.dirname(HERE), "include", "tdnet_test.h")
 STAMP_MARK = b"tdnet-src-hash:"
 
 
@@ -31,7 +33,7 @@ def extra_flags():
 def sources():
     """The regular *.h / *.hip files of csrc/ + the C-ABI header: an editor backup, a stray directory or a build product next to them
     neither changes the stamp nor breaks the hash."""
-    return sorted(p for p in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(p) and p.endswith((".h", ".hip"))) + [HEADER]
+    return sorted(p for p in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(p) and p.endswith((".h", ".hip"))) + [HEADER, HEADER_TEST]
 
 
 def toolchain_id():
@@ -65,18 +67,32 @@ def built_hash(path=OUT):
     return m.group(1).decode() if m else None
 
 
-def build(force=False, verbose=False):
-    want = source_hash()
-    if not force and built_hash() == want:
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+def _compile(src, out, want, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + extra_flags() + ['-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, "td_model.hip"), "-o", OUT]
+    cmd = [hipcc] + FLAGS + extra_flags() + ['-DTDNET_SRC_HASH="%s"' % want, os.path.join(CSRC, src), "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    if built_hash() != want:
-        raise RuntimeError("libtdnet_hip.so was built but does not carry the source hash %s" % want)
+    if built_hash(out) != want:
+        raise RuntimeError("%s was built but does not carry the source hash %s" % (os.path.basename(out), want))
+
+
+def build(force=False, verbose=False, test_lib=True):
+    """Both libraries carry the same stamp (one hash over all sources): the product library from td_model.hip, the tests' superset from
+    td_model_test.hip.  Stale ones are rebuilt, side by side (two hipcc processes)."""
+    want = source_hash()
+    todo = [(src, out) for src, out in (("td_model.hip", OUT), ("td_model_test.hip", OUT_TEST))
+            if (out == OUT or test_lib) and (force or built_hash(out) != want)]
+    if not todo:
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if len(todo) == 1:
+        _compile(todo[0][0], todo[0][1], want, verbose)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(2) as ex:
+            for f in [ex.submit(_compile, src, out, want, verbose) for src, out in todo]:
+                f.result()
     return OUT
 
 

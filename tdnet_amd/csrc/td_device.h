@@ -131,6 +131,38 @@ TD_DEV void td_wave_sync() {
 // a compare, a select, an add and a multiply per call -- which the softmax does not need (such terms are 1e-38 of a sum >= 1) and
 // which sits in the MFMA stream of the attention kernels 16 times per key tile.
 TD_DEV float td_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// ---- two runtime facts the host code asks the platform (tests/emu/td_device.h answers them for the emulator) ---------------------------------
+// Do two HIP streams share ONE hardware queue?  Two 40-us spin kernels started together: ~45 us for the pair = two queues, 80+ us = one.  The better
+// of two tries (a context switch on the host must not look like a shared queue).  Synchronises both streams with the host; `a` stays ordered behind
+// everything this enqueued.  e0..e2: events of the caller (timing enabled).
+__global__ void k_queue_probe_spin(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+}
+static inline hipError_t td_streams_share_a_queue(hipStream_t a, hipStream_t x, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, bool* shared, float* pair_us) {
+    float worst = 1e9f;
+    hipError_t e;
+    for (int rep = 0; rep < 2; ++rep) {
+        if ((e = hipEventRecord(e0, a)) != hipSuccess || (e = hipStreamWaitEvent(x, e0, 0)) != hipSuccess) return e;
+        TD_LAUNCH(k_queue_probe_spin, dim3(1), dim3(64), 0, a, 4000ull);
+        TD_LAUNCH(k_queue_probe_spin, dim3(1), dim3(64), 0, x, 4000ull);
+        if ((e = hipEventRecord(e1, a)) != hipSuccess || (e = hipEventRecord(e2, x)) != hipSuccess || (e = hipStreamWaitEvent(a, e2, 0)) != hipSuccess) return e;
+        if ((e = hipEventSynchronize(e1)) != hipSuccess || (e = hipEventSynchronize(e2)) != hipSuccess) return e;
+        float t1 = 0.f, t2 = 0.f;
+        if ((e = hipEventElapsedTime(&t1, e0, e1)) != hipSuccess || (e = hipEventElapsedTime(&t2, e0, e2)) != hipSuccess) return e;
+        const float m = t1 > t2 ? t1 : t2;
+        worst = m < worst ? m : worst;
+    }
+    *shared = worst > 0.064f;                                          // 40 us each: 40-45 us side by side, 80+ us one after the other
+    if (pair_us) *pair_us = worst * 1e3f;
+    return hipSuccess;
+}
+// is this stream being captured into a hipGraph right now?
+static inline bool td_stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+}
+
 TD_DEV int td_lane() { return threadIdx.x & 63; }
 TD_DEV int td_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 #endif  // TD_DEVICE_H

@@ -272,45 +272,18 @@ static void rejoin_streams(tdnet* n, hipStream_t s) {
 // with the check; two extra streams in the process 193-275 -> 273.  NOT cured: three or more extra normal-priority streams created before
 // the handle's own (182 frames/s although the spin pair runs side by side) -- something below HIP's queue pool that a marker kernel beside an
 // oversubscribed grid could not tell apart from ordinary occupancy (tried, removed).
-#ifndef TD_EMU
-__global__ void k_queue_probe_spin(unsigned long long ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
-}
 static int streams_share_a_queue(hipStream_t a, hipStream_t x, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, bool* shared) {
-    float worst = 1e9f;
-    for (int rep = 0; rep < 2; ++rep) {                                // the better of two: a context switch on the host must not look like a shared queue
-        TD_HIP(hipEventRecord(e0, a));
-        TD_HIP(hipStreamWaitEvent(x, e0, 0));
-        TD_LAUNCH(k_queue_probe_spin, dim3(1), dim3(64), 0, a, 4000ull);
-        TD_LAUNCH(k_queue_probe_spin, dim3(1), dim3(64), 0, x, 4000ull);
-        TD_HIP(hipEventRecord(e1, a));
-        TD_HIP(hipEventRecord(e2, x));
-        TD_HIP(hipStreamWaitEvent(a, e2, 0));                          // the caller's stream stays ordered behind everything this enqueued
-        TD_HIP(hipEventSynchronize(e1));
-        TD_HIP(hipEventSynchronize(e2));
-        float t1 = 0.f, t2 = 0.f;
-        TD_HIP(hipEventElapsedTime(&t1, e0, e1));
-        TD_HIP(hipEventElapsedTime(&t2, e0, e2));
-        worst = std::min(worst, std::max(t1, t2));
-    }
-    *shared = worst > 0.064f;                                          // 40 us each: 40-45 us side by side, 80+ us one after the other
-    if (getenv("TDNET_QUEUE_CHECK_VERBOSE")) fprintf(stderr, "tdnet queue check: spin pair %.1f us\n", worst * 1e3f);
+    float pair_us = 0.f;
+    TD_HIP(td_streams_share_a_queue(a, x, e0, e1, e2, shared, &pair_us));          // td_device.h (the emulator's stand-in: never shared)
+    if (getenv("TDNET_QUEUE_CHECK_VERBOSE")) fprintf(stderr, "tdnet queue check: spin pair %.1f us\n", pair_us);
     return 0;
 }
-#endif
 // explicit_call: from tdnet_warmup (the documented place for the host synchronisation); otherwise the lazy check of the first frame on a
 // stream tdnet_warmup has not seen -- skipped, and left for later, while that stream is being captured into a hipGraph.
 static int place_chain_stream(tdnet* n, hipStream_t s, bool explicit_call = false) {
     if (!n->chain2 || std::find(n->placed_for.begin(), n->placed_for.end(), (void*)s) != n->placed_for.end()) return 0;
-#ifndef TD_EMU
-    if (!explicit_call) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;
-    }
-#endif
+    if (!explicit_call && td_stream_is_capturing(s)) return 0;
     n->placed_for.push_back((void*)s);
-#ifndef TD_EMU
     if (getenv("TDNET_NO_QUEUE_CHECK")) return 0;                      // A/B of this very mechanism (tools/ab_opts.py)
     // A handle alternating between caller streams checks each of them once.  chain2 is replaced only while the handle's lifetime budget of
     // replacements lasts (12 streams kept alive): a replacement that suits stream B may share a queue with stream A again, and a handle
@@ -330,9 +303,6 @@ static int place_chain_stream(tdnet* n, hipStream_t s, bool explicit_call = fals
     }
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
     return rc;
-#else
-    return 0;
-#endif
 }
 
 // started: set once the frame's own work has begun (past the argument checks) -- only then does a failure drop state

@@ -1,12 +1,13 @@
-// td_model.hip -- the translation unit of libtdnet_hip.so: the C ABI of include/tdnet.h.  The host code behind it lives in the headers this
-// file pulls in (td_ops_test.h -> td_frame.h -> td_launch.h -> td_weights.h -> td_handle.h -> the kernel headers).
+// td_model.hip -- the translation unit of libtdnet_hip.so: the C ABI of include/tdnet.h, and nothing else.  The host code behind it lives in the
+// headers this file pulls in (td_frame.h -> td_launch.h -> td_weights.h -> td_handle.h -> the kernel headers).  The single-operator entry points and
+// probes of the tests (include/tdnet_test.h, td_ops_test.h) are a SECOND library, libtdnet_hip_test.so = td_model_test.hip = this file + td_ops_test.h.
 //
 // Reference behaviour mirrored here (paths relative to /root/reference/Testing/model/pspnet):
 //   forward / path dispatch ........ td4_psp18.py:216-229, td2_psp50.py:146-155
 //   per-path graph ................. td4_psp18.py:137-212, td2_psp50.py:112-143      (td_frame.h)
 //   FIFO ........................... td4_psp18.py:123-134 (depth 3), td2_psp50.py:98-109 (depth 1)
 //   strict state_dict loading ...... td4_psp18.py:232-240                            (td_weights.h)
-#include "td_ops_test.h"
+#include "td_frame.h"
 
 extern "C" const char* tdnet_last_error(void) { return g_err; }
 // The build stamps the library with a hash of its sources (tdnet_amd/build.py: -DTDNET_SRC_HASH): tests and smoke() compare it with
@@ -159,6 +160,22 @@ extern "C" int tdnet_memory_bytes(const tdnet_t* n, size_t* weights, size_t* han
     return n->wt->refs.load(std::memory_order_relaxed);
 }
 extern "C" int tdnet_last_launch_count(const tdnet_t* n) { return n ? n->launches : -1; }
+extern "C" int tdnet_streams_share_queue(void* stream_a, void* stream_b, int* shared) {
+    if (!shared) return td_fail("tdnet_streams_share_queue: shared is NULL");
+    *shared = 0;
+    if (stream_a == stream_b) { *shared = 1; return 0; }
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        return td_fail("tdnet_streams_share_queue: hipEventCreate failed");
+    }
+    bool sh = false;
+    const int rc = streams_share_a_queue((hipStream_t)stream_a, (hipStream_t)stream_b, e0, e1, e2, &sh);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    *shared = sh ? 1 : 0;
+    return rc;
+}
 
 // tdnet_last_launch_count: everything a frame entry enqueued, the final upsample / argmax kernel included (counted in TD_LAUNCH itself)
 struct LaunchCount {

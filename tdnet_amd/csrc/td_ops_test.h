@@ -1,6 +1,6 @@
 // td_ops_test.h -- single-operator entry points (tests/ check each kernel family against torch fp32 through them) and the roofline /
-// tuning probes of include/tdnet.h.  NOT on the product path: nothing here is reached from tdnet_forward.  Part of the td_model.hip
-// translation unit.
+// tuning probes of include/tdnet_test.h.  NOT in the product library: libtdnet_hip.so (td_model.hip) is built without this file; the
+// tests' libtdnet_hip_test.so (td_model_test.hip = td_model.hip + this file) and the emulator library carry it.
 #pragma once
 #include "td_frame.h"
 
@@ -101,26 +101,6 @@ extern "C" int tdnet_op_stem(const float* img, int H, int W, const float* w_host
     hipFree(img4); hipFree(s1);
     free_conv_layer(L);
     return 0;
-}
-extern "C" int tdnet_op_streams_share_queue(void* stream_a, void* stream_b, int* shared) {
-    if (!shared) return td_fail("tdnet_op_streams_share_queue: shared is NULL");
-    *shared = 0;
-    if (stream_a == stream_b) { *shared = 1; return 0; }
-#ifndef TD_EMU
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
-        if (e0) hipEventDestroy(e0);
-        if (e1) hipEventDestroy(e1);
-        return td_fail("tdnet_op_streams_share_queue: hipEventCreate failed");
-    }
-    bool sh = false;
-    const int rc = streams_share_a_queue((hipStream_t)stream_a, (hipStream_t)stream_b, e0, e1, e2, &sh);
-    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-    *shared = sh ? 1 : 0;
-    return rc;
-#else
-    return 0;
-#endif
 }
 extern "C" int tdnet_op_attention(const float* q, const float* k, const float* vp, const float* bias, const float* resid, int Lq,
                                   int Lk, int DV, int online, const float* ln_g, const float* ln_b, float* ln_out, float* out,

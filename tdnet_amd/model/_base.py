@@ -243,14 +243,14 @@ class _TDNetBase(nn.Module):
         streams on one queue serialise (which pair collides depends on how many streams the process has created -- with three queues
         the second sample's first candidate lands on the caller's queue: 1066 instead of 1430 frames/s for two 720x960 clips,
         profiles/r04z_hw_queues_*).  Candidates from torch's pool are tried against every taken stream with the library's spin-pair test
-        (include/tdnet.h tdnet_op_streams_share_queue); with more samples than queues the last candidate is used as it is."""
+        (include/tdnet.h tdnet_streams_share_queue); with more samples than queues the last candidate is used as it is."""
         import ctypes
         s = None
         for _ in range(8):
             s = torch.cuda.Stream(device)
             shared = ctypes.c_int(0)
             for t in taken:
-                lib.check(lib.tdnet_op_streams_share_queue(t.cuda_stream, s.cuda_stream, ctypes.byref(shared)))
+                lib.check(lib.tdnet_streams_share_queue(t.cuda_stream, s.cuda_stream, ctypes.byref(shared)))
                 if shared.value:
                     break
             if not shared.value:

@@ -10,7 +10,7 @@ OUT = os.path.join(HERE, "_build", "libtdnet_emu.so")
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 import glob  # noqa: E402
 SRCS = glob.glob(os.path.join(ROOT, "tdnet_amd", "csrc", "*")) + \
-       [os.path.join(HERE, f) for f in ("td_device.h", "tdemu.cpp", "build_emu.py")] + [os.path.join(ROOT, "include", "tdnet.h")]
+       [os.path.join(HERE, f) for f in ("td_device.h", "tdemu.cpp", "build_emu.py")] + [os.path.join(ROOT, "include", "tdnet.h"), os.path.join(ROOT, "include", "tdnet_test.h")]
 
 
 def build(force=False):
@@ -26,7 +26,7 @@ def build(force=False):
     isa = [f for f, need in (("-mfma", "fma"), ("-mavx2", "avx2"), ("-mf16c", "f16c")) if need in flags]
     cmd = [CXX, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unused-value", "-ffp-contract=off", "-Wno-psabi"] + isa + [
            "-include", os.path.join(HERE, "td_device.h"),
-           "-x", "c++", os.path.join(ROOT, "tdnet_amd", "csrc", "td_model.hip"), os.path.join(HERE, "tdemu.cpp"), "-o", OUT]
+           "-x", "c++", os.path.join(ROOT, "tdnet_amd", "csrc", "td_model_test.hip"), os.path.join(HERE, "tdemu.cpp"), "-o", OUT]
     subprocess.run(cmd, check=True)
     return OUT
 

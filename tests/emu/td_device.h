@@ -67,6 +67,14 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 
+// the emulator has one "queue" and no graphs: streams never collide, nothing is ever being captured (csrc/td_device.h has the real answers)
+inline hipError_t td_streams_share_a_queue(hipStream_t, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t, bool* shared, float* pair_us) {
+    *shared = false;
+    if (pair_us) *pair_us = 0.f;
+    return hipSuccess;
+}
+inline bool td_stream_is_capturing(hipStream_t) { return false; }
+
 // ---- execution model ------------------------------------------------------------------------------------------------
 namespace tdemu {
 struct Idx { unsigned x, y, z; };

@@ -14,5 +14,5 @@ def emu_lib():
     if _lib is None:
         import build_emu
         from tdnet_amd import _capi
-        _lib = _capi.Lib(build_emu.build())
+        _lib = _capi.Lib(build_emu.build(), test_symbols=True)
     return _lib

@@ -106,3 +106,26 @@ def test_eight_ranks_the_size_of_the_scaling_run():
     out = r.stdout.decode(errors="replace")
     assert r.returncode != 0, out[-2000:]
     assert _last_json(out)["rank_check"]["ranks_agree"] is False
+
+
+def test_eight_rank_dry_run_line_schema():
+    """The WHOLE `bench.py --gpus 8` self-spawn path (launcher, rendezvous, pinning plan, weight broadcast, the solo reference run of rank 0, the
+    8-rank timed loop, reductions, rank check) over gloo on the CPU, and the schema of the line the driver's scaling run will read: the
+    collective block (backend, bytes, GB/s, hardware queues per rank), per-rank frames/s with min / max / spread, and the scaling check."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"], env=_env(), cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    line = _last_json(out)
+    assert line["n_gpus"] == 8 and line["world_size_seen"] == 8 and line["dry_run"] is True and line["value"] is None
+    assert len(line["per_rank_fps"]) == 8 and len(line["init_s_per_rank"]) == 8 and len(line["host_launch_us_per_frame"]) == 8
+    lo, hi, spread = line["per_rank_fps_min_max_spread"]
+    assert lo == min(line["per_rank_fps"]) and hi == max(line["per_rank_fps"]) and 0.0 <= spread < 1.0
+    c = line["collective"]
+    assert c["backend"] == "gloo" and c["bcast_bytes"] == line["bcast_bytes"] > 1e6 and c["bcast_ms"] > 0 and c["bcast_GBps"] > 0
+    assert len(c["hw_queues_per_rank"]) == 8 and all("GPU_MAX_HW_QUEUES" in q for q in c["hw_queues_per_rank"])
+    sc = line["scaling_check"]
+    assert set(sc) >= {"solo_fps_rank0", "per_gpu_fps", "scaling_efficiency", "what"} and sc["scaling_efficiency"] is None   # dry run: never a number
+    assert line["rank_check"]["ranks_agree"] is True
+    assert line["warmup"] >= line["warmup_requested"] == 1
+    assert isinstance(line["cpu_affinity"], list) and len(line["cpu_affinity"]) == 8

@@ -15,6 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_hip_library_exports_every_declared_symbol():
+    """The PRODUCT library exports exactly what include/tdnet.h declares -- and none of the tests' single-operator entry points or probes
+    (include/tdnet_test.h: tdnet_op_*, tdnet_bench_*), which live in libtdnet_hip_test.so, a superset built from the same sources."""
+    import subprocess
     import __graft_entry__ as g
     g.build()
     lib = _capi.Lib(_capi.DEFAULT_LIB)
@@ -24,6 +27,16 @@ def test_hip_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib.dll, name), name
     assert b"gfx950" in lib.tdnet_version()
+    thdr = open(os.path.join(ROOT, "include", "tdnet_test.h")).read()
+    tdeclared = set(re.findall(r"\b(tdnet_[a-z0-9_]+)\s*\(", thdr))
+    assert tdeclared == set(_capi.TEST_SYMBOLS) and not (tdeclared & declared), tdeclared ^ set(_capi.TEST_SYMBOLS)
+    exported = set(re.findall(r" T (tdnet_[a-z0-9_]+)", subprocess.run(["nm", "-D", "--defined-only", _capi.DEFAULT_LIB], stdout=subprocess.PIPE, check=True).stdout.decode()))
+    assert exported == declared, exported ^ declared                     # nothing but the boundary: no tdnet_op_*, no tdnet_bench_*
+    tlib = _capi.Lib(_capi.TEST_LIB, test_symbols=True)
+    for name in declared | tdeclared:
+        assert hasattr(tlib.dll, name), name
+    from tdnet_amd import build as b
+    assert b.built_hash(_capi.TEST_LIB) == b.built_hash(_capi.DEFAULT_LIB) == b.source_hash()
 
 
 def test_library_is_stamped_with_the_hash_of_its_sources(tmp_path):
@@ -153,13 +166,13 @@ def test_model_classes_mirror_reference_api():
 
 
 def test_streams_share_queue_argument_checks():
-    """include/tdnet.h tdnet_op_streams_share_queue: the two paths that need no device -- a NULL result pointer is an error with a message,
+    """include/tdnet.h tdnet_streams_share_queue: the two paths that need no device -- a NULL result pointer is an error with a message,
     a stream compared with itself shares its queue by definition (the spin-pair test itself is exercised by the GPU batch tests)."""
     lib = _capi.lib()
-    assert lib.tdnet_op_streams_share_queue(None, None, None) != 0
+    assert lib.tdnet_streams_share_queue(None, None, None) != 0
     assert b"shared is NULL" in lib.tdnet_last_error()
     shared = ctypes.c_int(0)
-    assert lib.tdnet_op_streams_share_queue(ctypes.c_void_p(64), ctypes.c_void_p(64), ctypes.byref(shared)) == 0 and shared.value == 1
+    assert lib.tdnet_streams_share_queue(ctypes.c_void_p(64), ctypes.c_void_p(64), ctypes.byref(shared)) == 0 and shared.value == 1
 
 
 def test_the_package_caps_the_hardware_queues_before_the_runtime_starts():

@@ -48,7 +48,7 @@ def _conv_errors(lib, H, W, Cin, Cout, KS, dil, resid, act, variants, seed=0):
 
 
 def test_split_gemm_operators_are_as_accurate_as_the_fp32_kernels():
-    lib = _capi.lib()
+    lib = _capi.test_lib()
     V = [({}, -1), ({"precision": 3}, -1), ({"precision": 3, "overlap": 41 | 4}, -1), ({"precision": 3, "gemm_persistent": 7}, -1)]
     for (H, W, Cin, Cout, KS, dil, resid, act) in [(64, 128, 512, 512, 3, 4, True, 1),      # layer 4's conv: 36 GEMMs of K = 512, even dilation -> row-parity chunks
                                                    (64, 128, 256, 256, 3, 2, False, 0),     # layer 3

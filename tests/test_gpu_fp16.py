@@ -35,7 +35,7 @@ def _conv16(lib, mem, H, W, Cin, Cout, KS, stride, dil, tile, seed=0):
 
 
 def test_fp16_kernels():
-    lib, mem = _capi.lib(), opcheck.TorchMem()
+    lib, mem = _capi.test_lib(), opcheck.TorchMem()
     for tile in (3, 4, 5):
         _conv16(lib, mem, 13, 21, 128, 96, 3, 1, 1, tile)
         _conv16(lib, mem, 7, 9, 64, 64, 1, 1, 1, tile)              # single K step

@@ -142,31 +142,38 @@ def test_idle_handles_do_not_slow_a_busy_one():
     """tools/idle_handle_probe.py: the C2 workload beside 0 / 1 / 2 / 3 idle td4 handles.  HIP reuses hardware queues once its pool is full;
     with an odd number of idle handles alive the busy handle's second row-parity chain used to land on the CALLER's queue and the frame ran
     at 0.63x (335 / 212 / 335 / 212 frames/s).  The first frame now checks the pair with two spin kernels and replaces the internal stream
-    (td_frame.h place_chain_stream).  Run under HIP's default pool size (4), where the collision occurs; TDNET_NO_QUEUE_CHECK=1 shows the
-    old behaviour (printed, not asserted).
-    A throughput assertion on a box this test does not own: in one of ~10 suite runs of round 5 the first probe read 342 / 210 / 341 / 295
-    although the same library then gave 341-344 in all of 12 configurations of three verbose runs (every shared pair measured at 85 us
-    against 51 and replaced, profiles/r05n_*).  So a failing probe is repeated once, with the check's own measurements printed, and the
-    repeat is what is asserted; both results are printed."""
+    (td_frame.h place_chain_stream).  Run under HIP's default pool size (4), where the collision occurs.
+    What is ASSERTED is the check's own measurement, which is deterministic: every handle's final spin pair ran side by side (<= 64 us; two
+    40-us kernels take 40-51 us on two queues and 80-85 us on one: profiles/r04k_*, r05n_*).  The throughputs -- with the check and, for the
+    record, without it (TDNET_NO_QUEUE_CHECK=1) -- are printed, not asserted: a frames/s figure on a box this test does not own moved by
+    more than the effect in one of ~10 suite runs of round 5 (and this test then retried; it no longer does)."""
     import re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
 
-    def rates(**extra):
+    def run(**extra):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "idle_handle_probe.py")], env=dict(env, GPU_MAX_HW_QUEUES="4", TDNET_QUIET="1", **extra),
                            cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         out = r.stdout.decode(errors="replace")
         v = [float(x) for x in re.findall(r"alive: ([0-9.]+) frames/s", out)]
         assert r.returncode == 0 and len(v) == 4, out[-2000:]
-        if "TDNET_QUEUE_CHECK_VERBOSE" in extra:
-            print("\n".join(l for l in out.splitlines() if "queue check" in l or "alive" in l))
-        return v
-    got, old = rates(), rates(TDNET_NO_QUEUE_CHECK="1")
+        return v, out
+    got, out = run(TDNET_QUEUE_CHECK_VERBOSE="1")
+    old, _ = run(TDNET_NO_QUEUE_CHECK="1")
     print("busy handle beside 0..3 idle ones, frames/s: %s with the queue check, %s without" % (got, old))
-    if min(got) < 0.9 * got[0]:
-        first, got = got, rates(TDNET_QUEUE_CHECK_VERBOSE="1")
-        print("  repeated (verbose): %s after %s" % (got, first))
-    assert min(got) >= 0.9 * got[0], (got, old)
+    # the probe's output, in order: spin-pair lines of a handle's check(s) (one per attempt; a shared pair is followed by the replacement's), then
+    # that handle's "alive" line (the busy td2 handle) or nothing (an idle td4 handle's own first frame).  The LAST pair before each "alive" line
+    # is the busy handle's final placement.
+    finals, last = [], None
+    for l in out.splitlines():
+        m = re.search(r"queue check: spin pair ([0-9.]+) us", l)
+        if m:
+            last = float(m.group(1))
+        elif "alive:" in l:
+            finals.append(last)
+            last = None
+    print("final spin pair of the busy handle beside 0..3 idle ones: %s us" % finals)
+    assert len(finals) == 4 and all(f is not None and f <= 64.0 for f in finals), (finals, got)
 
 
 def test_bench_line_carries_measured_hbm_traffic_of_the_dominant_kernel():

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def lib():
     assert torch.cuda.is_available()
-    return _capi.lib()                      # the in-tree libtdnet_hip.so; raises if it is missing
+    return _capi.test_lib()                      # the in-tree libtdnet_hip.so; raises if it is missing
 
 
 @pytest.fixture(scope="module")

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_winograd_ops_and_model():
-    lib, mem = _capi.lib(), opcheck.TorchMem()
+    lib, mem = _capi.test_lib(), opcheck.TorchMem()
     if True:
         import test_gpu_model as tm
         # F(4x4,3x3) on every stride-1 3x3

@@ -2,7 +2,7 @@
 import sys; sys.path.insert(0, ".")
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); dev = torch.device("cuda:0")
+lib = _capi.test_lib(); dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(1)
 def run(Lq, Lk, DV, online=0, iters=20):
     q = (torch.randn(Lq, 64, generator=g) * 0.5).to(dev); k = (torch.randn(Lk, 64, generator=g) * 0.5).to(dev)

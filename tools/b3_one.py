@@ -5,7 +5,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.test_lib(); torch.zeros(1, device="cuda")
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 Cin = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 Cout = int(sys.argv[3]) if len(sys.argv) > 3 else 512

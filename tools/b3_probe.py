@@ -9,7 +9,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.test_lib(); torch.zeros(1, device="cuda")
 
 
 def accuracy(H, W, Cin, Cout, KS, dil, seed=0):

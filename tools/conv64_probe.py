@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.test_lib(); torch.zeros(1, device="cuda")
 for (nm, H, W, Cin, Cout, KS, st, d) in [("layer1 64->64 @256x512", 256, 512, 64, 64, 3, 1, 1), ("layer1 64->64 @193x385", 193, 385, 64, 64, 3, 1, 1),
                                         ("deep stem 64->64 @512x1024", 512, 1024, 64, 64, 3, 1, 1)]:
     gf = 2.0 * (H // st) * (W // st) * Cout * Cin * KS * KS / 1e9

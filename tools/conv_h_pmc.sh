@@ -8,7 +8,7 @@ cat > /tmp/ch.py <<'PY'
 import sys, ctypes, os; sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np, torch
 from tdnet_amd import _capi
-lib = _capi.lib()
+lib = _capi.test_lib()
 H, W, Cin, Cout, DIL = [int(v) for v in os.environ.get("CH_SHAPE", "128,256,512,512,4").split(",")]
 TILES = [int(v) for v in os.environ.get("CH_TILES", "19,18,3").split(",")]
 g = np.random.default_rng(0)

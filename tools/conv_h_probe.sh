@@ -9,7 +9,7 @@ cat > /tmp/rp.py <<'PY'
 import sys, os, json; sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np, torch
 from tdnet_amd import _capi
-lib = _capi.lib()
+lib = _capi.test_lib()
 g = np.random.default_rng(0)
 cases = eval(os.environ["RP_CASES"])
 order = []

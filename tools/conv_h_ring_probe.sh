@@ -8,7 +8,7 @@ cat > /tmp/rp.py <<'PY'
 import sys, os, json; sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import numpy as np, torch
 from tdnet_amd import _capi
-lib = _capi.lib()
+lib = _capi.test_lib()
 g = np.random.default_rng(0)
 cases = [("1024x2048 layer1 64ch d1", 256, 512, 64, 64, 1, (2, 30)),
          ("720x960 layer1 64ch d1", 180, 240, 64, 64, 1, (2, 30)),

@@ -5,7 +5,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.test_lib(); torch.zeros(1, device="cuda")
 for (nm, H, W, Cin, Cout, KS, st, d) in [("layer1 64->64 3x3 @256x512", 256, 512, 64, 64, 3, 1, 1), ("layer2.0 64->128 3x3 s2 @256x512", 256, 512, 64, 128, 3, 2, 1),
                                         ("layer2.0 ds 64->128 1x1 s2", 256, 512, 64, 128, 1, 2, 1), ("layer4 512->512 3x3 d4 @128x256 (direct)", 128, 256, 512, 512, 3, 1, 4),
                                         ("layer3 256->256 3x3 d2 (direct)", 128, 256, 256, 256, 3, 1, 2)]:

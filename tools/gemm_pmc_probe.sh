@@ -6,7 +6,7 @@ cat > /tmp/gp.py <<'PY'
 import sys, ctypes; sys.path.insert(0, "/root/repo")
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.test_lib(); torch.zeros(1, device="cuda")
 o = lib.opts(winograd=0)
 lib.tdnet_bench_conv(1024, 256, 128, 512, 1, 1, 1, 3, 6, ctypes.byref(o), None)     # M = 262144, K = 128: 16 tiles per workgroup x 4 steps
 lib.tdnet_bench_conv(64, 256, 2048, 512, 1, 1, 1, 3, 6, ctypes.byref(o), None)      # M = 16384, K = 2048: 1 tile per workgroup x 64 steps (same FLOP)

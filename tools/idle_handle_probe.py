@@ -33,7 +33,7 @@ for n_idle in range(4):
         for t in range(80):
             m(clip[t % 4], pos_id=t % 2)
         torch.cuda.synchronize()
-    print("  %d idle td4 handle(s) alive: %.1f frames/s" % (n_idle, 80 / (time.perf_counter() - t0)))
+    print("  %d idle td4 handle(s) alive: %.1f frames/s" % (n_idle, 80 / (time.perf_counter() - t0)), flush=True)
     m.engine.close()
     del m
     k = td4_psp18.td4_psp18(nclass=19, path_num=4, model_path=None).eval().to(dev)   # one more idle handle: built, run once, kept

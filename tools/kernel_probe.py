@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from tdnet_amd import _capi  # noqa: E402
 
-lib = _capi.lib()
+lib = _capi.test_lib()
 torch.zeros(1, device="cuda")
 out = {"mfma_peak_tflops": {}}
 for wps in (1, 2, 4):

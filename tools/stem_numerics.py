@@ -20,7 +20,7 @@ ROWS = 65536
 
 
 def stem_alone():
-    lib, mem = _capi.lib(), opcheck.TorchMem()
+    lib, mem = _capi.test_lib(), opcheck.TorchMem()
     for H, W in ((129, 257), (257, 513), (300, 422)):
         g = np.random.default_rng(1)
         img = g.standard_normal((3, H, W)).astype(np.float32)
@@ -40,7 +40,7 @@ def stem_alone():
 
 def stress():
     import test_gpu_model as tg
-    default = _capi.lib().opts().fusion
+    default = _capi.test_lib().opts().fusion
     for seed in (1, 2, 3):
         for wino in (0, 3):
             for fu in (default & ~ROWS, default | ROWS):

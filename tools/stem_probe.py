@@ -5,7 +5,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tdnet_amd import _capi
-lib = _capi.lib()
+lib = _capi.test_lib()
 prec = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 H, W = 1024, 2048
 img = torch.randn(3, H, W, device="cuda"); out = torch.empty(H // 4, W // 4, 64, device="cuda")

@@ -27,7 +27,7 @@ def main():
     a = ap.parse_args()
     import torch
     from tdnet_amd import _capi
-    lib = _capi.lib()
+    lib = _capi.test_lib()
     torch.zeros(1, device="cuda")
     forms = {"whole": 2 | 8 | 32, "half": 1 | 8 | 32, "quarter": 1 | 8 | 32 | 64}
     H, W, C = 128, 256, a.channels

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
 import torch
 from tdnet_amd import _capi
-lib = _capi.lib(); torch.zeros(1, device="cuda")
+lib = _capi.test_lib(); torch.zeros(1, device="cuda")
 SHAPES = [("layer4 512->512 d4", 128, 256, 512, 512, 4), ("layer4 512->512 d8", 128, 256, 512, 512, 8), ("layer4 256->512 d4", 128, 256, 256, 512, 4),
           ("layer3 256->256 d2", 128, 256, 256, 256, 2), ("layer3.0 128->256 d1", 128, 256, 128, 256, 1), ("head 512->128", 128, 256, 512, 128, 1),
           ("layer2 128->128", 128, 256, 128, 128, 1), ("layer1 64->64", 256, 512, 64, 64, 1), ("native l4 512->512 d4", 97, 193, 512, 512, 4)]

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import torch.nn.functional as F
 from tdnet_amd import _capi
-lib = _capi.Lib(sys.argv[1]) if len(sys.argv) > 1 else _capi.lib()
+lib = _capi.Lib(sys.argv[1]) if len(sys.argv) > 1 else _capi.test_lib()
 only = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
 print(lib.tdnet_version().decode())
 for (H, W, Cin, Cout, dil, resid) in ((13, 21, 64, 128, 2, True), (32, 64, 256, 256, 2, True), (32, 64, 256, 256, 2, False), (16, 32, 128, 128, 1, False)):
