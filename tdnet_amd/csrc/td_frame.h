@@ -52,7 +52,8 @@ static int launch_chain(tdnet* n, PathLayers& L, hipStream_t s, float* vp, int e
     // the side stream under the backbone, not in front of the final attention on the critical path (round 5: one 7-us kernel + a boundary)
     if (n->vt16) {
         prof_begin(n, 2, false, 0, c);
-        attn_prepare_vt_h(vp, n->Lk, DV, n->vt16, c);
+        if (n->opts.precision >= 2) attn_prepare_vt_b3(vp, n->Lk, DV, reinterpret_cast<unsigned short*>(n->vt16), c);   // precision 2: V' re-tiled as three bf16 parts
+        else attn_prepare_vt_h(vp, n->Lk, DV, n->vt16, c);
         prof_end(n, c);
     }
     TD_HIP(hipEventRecord(n->ev_join, c));
@@ -217,7 +218,7 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
         const AtnLayer& A = L.atn[n->P == 4 ? 2 : 0];                   // td4_psp18.py:147 / td2_psp50.py:120
         stats_nstr = (n->opts.fusion & 2) ? attn_strips(n->Lq, DV) : 0;                                         // LayerNorm strip statistics from the epilogue
         if (run_attention(n, n->q_cur, ck.k, n->vp, A.d_bias, n->v_cur, n->Lq, n->Lk, DV, n->feat, s, n->opts.attention,
-                          stats_nstr ? n->ln_part : nullptr, nullptr, false, /*vt_ready=*/n->vt16 != nullptr)) return -1;       // v4 + v_cur
+                          stats_nstr ? n->ln_part : nullptr, nullptr, false, /*vt_ready=*/n->vt16 != nullptr, /*b3=*/n->opts.precision >= 2)) return -1;       // v4 + v_cur
         feat = n->feat;
     }
     // (warm-up, td4_psp18.py:142-143: feat = v_cur -- read in place; rounds 1-4 copied it into n->feat, a device copy per warm-up frame)

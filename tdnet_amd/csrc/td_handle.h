@@ -21,6 +21,7 @@
 #include "td_gemm_b3.h"
 #include "td_attn.h"
 #include "td_attn_h.h"
+#include "td_attn_b3.h"
 #include "td_misc.h"
 
 #include <cmath>
@@ -247,7 +248,7 @@ struct tdnet {
     std::vector<void*> placed_for;                                     // the caller streams chain2 has been checked against (place_chain_stream): once per stream
     int chain_replaced = 0;
     float* c4 = nullptr;                                              // backbone output of the last frame (bx, or br in the fp16-activation mode)
-    _Float16* vt16 = nullptr;                                         // fp16 attention: V' transposed [DV][LkPad]
+    _Float16* vt16 = nullptr;                                         // fp16 attention: V' re-tiled [LkPad / 8][DV][8]; precision 2: its three bf16 parts (3x that, td_attn_b3.h)
     bool ln_pending = false;                                          // the `ln` map of the last frame was not materialised (fusion bit 4)
     int ln_path = 0;
     bool feat_is_vcur = false;                                        // warm-up frame (td4_psp18.py:142-143): the "feat" stage IS v_cur (no copy is made)

@@ -211,17 +211,20 @@ static int run_conv_group(tdnet* n, const ConvCall* c, int ng, hipStream_t s, in
 }
 
 // ln_part != nullptr: the kernel also writes the plane-LayerNorm strip statistics of `out` (one strip per 32-row query tile)
+// vt16 (or the handle's n->vt16): the operand buffer of the fp16-MFMA kernel (tdnet_opts.precision = 1) or, with b3, of the split kernel (precision 2:
+// td_attn_b3.h; the handle uses it for the FINAL attention of a frame only -- the cached-frame steps are hidden on the side stream either way)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
                          int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,
-                         _Float16* vt16 = nullptr, bool slices = false, bool vt_ready = false) {
-    if (n && n->vt16) vt16 = n->vt16;
+                         _Float16* vt16 = nullptr, bool slices = false, bool vt_ready = false, bool b3 = false) {
+    if (n && n->vt16 && (n->opts.precision == 1 || b3)) vt16 = n->vt16;
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
     a.scale_log2e = 1.4426950408889634f / 8.0f;                        // temperature = sqrt(d_k) = 8 (transformer.py:65)
     a.ln_part = ln_part; a.ln_nstr = 0;
     if (n && (probe_skip() & 4) && Lq > Lk) return 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = vt16 ? attn_launch_h(a, DV, vt16, s, vt_ready) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
+    const int rc = (vt16 && b3) ? attn_launch_b3(a, DV, reinterpret_cast<unsigned short*>(vt16), s, vt_ready)
+                 : vt16 ? attn_launch_h(a, DV, vt16, s, vt_ready) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);
     return 0;

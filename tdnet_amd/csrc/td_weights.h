@@ -322,7 +322,7 @@ static int alloc_workspace(tdnet* n) {
     if (dev_alloc(&n->feat, hw * n->DV) || dev_alloc(&n->ln, hw * n->DV)) return -1;
     const size_t ln_strips = std::max<size_t>(512, (size_t)attn_strips(n->Lq, n->DV));   // k_ln_stats: <= 512 strips; attention epilogue: one per query tile
     if (dev_alloc(&n->ln_part, 2 * ln_strips * n->DV) || dev_alloc(&n->ln_mean, n->DV) || dev_alloc(&n->ln_rstd, n->DV)) return -1;
-    if (n->opts.precision == 1 && dev_alloc(&n->vt16, (size_t)n->DV * attn_lkpad((int)lk))) return -1;
+    if (n->opts.precision >= 1 && dev_alloc(&n->vt16, (size_t)(n->opts.precision == 1 ? 1 : 3) * n->DV * attn_lkpad((int)lk))) return -1;
     n->slots.resize(n->FIFO + 2);                                      // FIFO + the pending entry + one being received
     for (auto& s : n->slots)
         if (dev_alloc(&s.q, lk * 64) || dev_alloc(&s.k, lk * 64) || dev_alloc(&s.v, lk * n->DV)) return -1;

@@ -624,6 +624,13 @@ def test_split_gemm_precision2_ops(lib):
     opcheck.conv(lib, MEM, 7, 9, 64, 128, 1, 1, 1, 0, True, opts=o3)                   # K = 64: four steps, one ragged tile
     opcheck.conv(lib, MEM, 70, 70, 64, 256, 1, 1, 1, 0, False, opts=dict(o3, gemm_persistent=3))   # 40 tiles on three workgroups
     opcheck.conv(lib, MEM, 24, 24, 128, 128, 3, 1, 1, 1, False, opts=dict(o3, gemm_persistent=5))  # 36 batches walked by five workgroups
+    # the attention kernel of precision 2 (td_attn_b3.h, online = 17): q, k, P and v' as three bf16 parts; Lk below one key tile, ragged super-tiles
+    # with a dominating key, the d_v = 128 variant, LayerNorm strip statistics from the epilogue, keys sorted by growing score
+    opcheck.attention(lib, MEM, 45, 6, 512, online=17)
+    opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=17)
+    opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0, online=17)
+    opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=17, ln=True)
+    opcheck.attention(lib, MEM, 70, 300, 512, online=17, ramp=True, ln=True)
     # the size heuristic of precision 2: a GEMM of fewer than 256 tiles stays on the exact-fp32 kernels, bit for bit
     import ctypes
     g = np.random.default_rng(3)

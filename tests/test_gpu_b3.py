@@ -68,6 +68,30 @@ def test_split_gemm_operators_are_as_accurate_as_the_fp32_kernels():
     opcheck.conv(lib, mem, 300, 40, 64, 256, 1, 1, 1, 0, False, opts={"precision": 3, "gemm_persistent": 11})
 
 
+def test_split_attention_is_as_accurate_as_the_fp32_kernel():
+    """td_attn_b3.h (tdnet_op_attention online = 17) against an fp64 evaluation at the frame's shapes and at ragged ones, next to the exact-fp32 kernel
+    (online = 2) on the same inputs: softmax(q k^T / 8) v' + bias + resid with |scores| up to ~30."""
+    lib = _capi.test_lib()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    s = torch.cuda.current_stream().cuda_stream
+    for (Lq, Lk, DV, scale) in ((32768, 2048, 512, 0.5), (18721, 1225, 512, 0.5), (32768, 2048, 128, 0.5), (4099, 777, 512, 2.0), (333, 45, 128, 1.0)):
+        q = (torch.randn(Lq, 64, generator=g) * scale).cuda(); k = (torch.randn(Lk, 64, generator=g) * scale).cuda()
+        vp = torch.zeros((Lk + 127) // 128 * 128, DV); vp[:Lk] = torch.randn(Lk, DV, generator=g); vp = vp.cuda()
+        b = torch.randn(DV, generator=g).cuda(); r = torch.randn(Lq, DV, generator=g).cuda()
+        ref = torch.softmax(q.double() @ k.double().t() / 8.0, dim=1) @ vp[:Lk].double() + b.double() + r.double()
+        errs = []
+        for online in (2 | 32, 17):
+            out = torch.full((Lq, DV), 7e7, device="cuda")
+            lib.check(lib.tdnet_op_attention(q.data_ptr(), k.data_ptr(), vp.data_ptr(), b.data_ptr(), r.data_ptr(), Lq, Lk, DV, online, None, None, None, out.data_ptr(), s))
+            e = (out.double() - ref).abs()
+            errs.append((e.max().item(), e.pow(2).mean().sqrt().item()))
+        print("attention Lq %d Lk %d DV %d: fp32 max %.2e rms %.2e | split max %.2e rms %.2e" % (Lq, Lk, DV, errs[0][0], errs[0][1], errs[1][0], errs[1][1]))
+        assert errs[1][0] <= 1.25 * errs[0][0] + 1e-7 and errs[1][1] <= 1.1 * errs[0][1] + 1e-9, (Lq, Lk, DV, errs)
+    mem = opcheck.TorchMem()
+    opcheck.attention(lib, mem, 300, 200, 512, spike=True, online=17, ln=True)       # + the plane LayerNorm from the epilogue's strip statistics
+    opcheck.attention(lib, mem, 130, 193, 128, True, True, online=17, ln=True)
+
+
 def test_precision2_meets_the_fp32_gate_1024x2048():
     _vs_oracle("td4", "resnet18", 1024, 2048, 5, kernel_opts={"precision": 2})         # configs[2]: four cold paths + the first steady-state frame
 
