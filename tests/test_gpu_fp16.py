@@ -2,7 +2,8 @@
 fp16-MFMA convs and attention, fp32 accumulation / softmax / LayerNorm.  Kernels against fp64 evaluations on fp16-rounded operands
 (tight: what is left is summation order and the output's own rounding), then the whole model against the fp32 CPU oracle with the
 gate this mode is held to at its BASELINE size (td2-psp34, 720x960 -- the stand-in for "td2-bise34", which does not exist in the
-reference): max|dlogit| <= 3e-2, >= 99.5 % of the labels equal, mIoU(pred, ref_pred) >= 0.99."""
+reference): max|dlogit| <= 3e-2, >= 99.5 % of the labels equal, mIoU(pred, ref_pred) >= 0.99, every class's IoU >= 0.97, and a label may differ
+only where the reference's top-2 gap is within twice that pixel's own logit error."""
 import ctypes
 
 import numpy as np
@@ -90,7 +91,7 @@ def _model_gate(name, bb, H, W, T):
     cls = td4_psp18.td4_psp18 if name == "td4" else td2_psp50.td2_psp50
     m = cls(nclass=19, path_num=spec.path_num, model_path=None, backbone=bb, synthetic_seed=0, kernel_opts={"precision": 1}).eval().to("cuda")
     tdnet_ref.tune_threads()
-    worst, agree = 0.0, []
+    worst, agree, outside = 0.0, [], 0
     hist = np.zeros((19, 19), np.int64)
     with torch.no_grad():
         for t, x in enumerate(weights.synth_video(H, W, T, seed=1)):
@@ -101,11 +102,21 @@ def _model_gate(name, bb, H, W, T):
             lo, lr = out[0].argmax(0), exp[0].argmax(0)
             agree.append(float((lo == lr).mean()))
             hist += tdnet_ref.confusion_miou(lo, lr, 19)[1]
+            # a label may differ only where the reference's top-2 gap is within twice THIS PIXEL's own logit error (round 5 measured the band
+            # against the clip's maximum error, 2 x 2.2e-2, which almost every near-tie satisfies)
+            bad = lo != lr
+            if bad.any():
+                top2 = np.sort(exp[0], axis=0)[-2:]
+                outside += int(((top2[1] - top2[0])[bad] > 2.0 * np.abs(out[0] - exp[0]).max(0)[bad]).sum())
     with np.errstate(divide="ignore", invalid="ignore"):
-        miou = float(np.nanmean(np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))))
+        iou = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+    present = hist.sum(1) > 0
+    miou, min_iou = float(np.nanmean(iou)), float(iou[present].min())
     assert m.engine.opts()["precision"] == 1
-    print("fp16 mode %s-%s %dx%d: max|dlogit| %.3e, label agreement %.4f, mIoU vs fp32 CPU %.4f" % (name, bb, H, W, worst, min(agree), miou))
+    print("fp16 mode %s-%s %dx%d: max|dlogit| %.3e, label agreement %.4f, mIoU vs fp32 CPU %.4f, lowest class IoU %.4f (class %d of %d present), flips outside the per-pixel band %d"
+          % (name, bb, H, W, worst, min(agree), miou, min_iou, int(np.nanargmin(np.where(present, iou, np.nan))), int(present.sum()), outside))
     assert worst <= 3e-2 and min(agree) >= 0.995 and miou >= 0.99, (worst, min(agree), miou)
+    assert min_iou >= 0.97 and outside == 0, (min_iou, outside)      # per-class floor: no class may absorb the flips; per-pixel tie band
 
 
 def test_fp16_model_gate_config5_720x960():
