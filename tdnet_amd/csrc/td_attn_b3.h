@@ -10,6 +10,10 @@
 //     the score tile); P: split by the lanes that own the scores and published through LDS as three [key group of 8][query][8 bf16] images;
 //   * v' is consumed re-tiled AND pre-split: vt3 [part 3][LkPad / 8][DV][8 bf16] (k_attn_vt_b3: one 6 MB pass at Lk = 2048, on the side stream
 //     where V' is produced), so a lane's B operand of a part is one 16-byte load and 32 lanes of a channel tile read 512 contiguous bytes.
+// (Round 6 also ran a second form -- the query parts kept in LDS instead of 48 registers, v' fragments by buffer loads with SGPR offsets, every k16-step's
+// fragments requested one step ahead and the first step's before the barrier that publishes P: 196 instead of 242 VGPRs, and 1.5-2.6 % SLOWER in the frame,
+// interleaved in one process (311.7 -> 307.0 frames/s at 1024x2048, 429.6 -> 418.7 at 769x1537; with a bare barrier 322.4 -> 315.1: profiles/r06n_*).  With two
+// workgroups per CU the compiler's just-in-time loads interleave better than the bulk prefetch.  Removed.)
 #pragma once
 #include "td_attn_h.h"
 #include "td_gemm_b3.h"
