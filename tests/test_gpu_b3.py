@@ -105,6 +105,22 @@ def test_precision2_split_kernel_forced_on_small_maps():
     _vs_oracle("td4", "resnet18", 257, 513, 8, kernel_opts={"precision": 3})           # every path cold and in steady state; ragged 256-row tiles everywhere
     _vs_oracle("td2", "resnet50", 129, 257, 4, kernel_opts={"precision": 3})           # Bottleneck backbone: the 1x1 convs (K up to 2048) on the split kernel
     _vs_oracle("td4", "resnet18", 257, 513, 5, kernel_opts={"precision": 3, "overlap": 41 | 4})   # + row-parity chains
+    _vs_oracle("td4", "resnet50", 129, 257, 6, kernel_opts={"precision": 3})           # d_v = 2048: the split attention as four 512-channel launches on one pre-split V'
+
+
+def test_precision2_psp101_small_golden(golden_dir):
+    """The stateless comparison model (pspnet.py:31-115) with every eligible GEMM on the split kernel -- the Bottleneck 1x1 convs of ResNet-101 with K up to
+    2048, the Winograd convs, the head -- against the golden captured from the real reference."""
+    import os
+    from tdnet_amd import weights
+    from tdnet_amd.model import pspnet
+    g = np.load(os.path.join(golden_dir, "psp_resnet101_33x65.npz"))
+    m = pspnet.pspnet(nclass=19, model_path=None, synthetic_seed=0, kernel_opts={"precision": 3}).eval().to("cuda")
+    x = torch.from_numpy(weights.synth_video(33, 65, 1, seed=1)[0]).cuda()
+    with torch.no_grad():
+        out = m(x, pos_id=0).cpu().numpy()
+    assert m.engine.opts()["precision"] == 3
+    assert np.abs(out - g["f0_logits"]).max() <= 1e-3 and (out[0].argmax(0) == g["f0_logits"][0].argmax(0)).all()
 
 
 def test_precision2_uncalibrated_reference_init_129x257():
