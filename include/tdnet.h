@@ -47,7 +47,7 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 237606  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072; bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+#define TDNET_FUSION_DEFAULT 499750  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072 | 262144; bit 262144 since round 6: 276.4 -> 277.2 frames/s at C3, 393.6 -> 394.3 at 769x1537, one launch fewer, bit-identical (profiles/r06p_*); bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
                                        bits 8192 and 32768 (precision 1 only) since round 4: 1042 -> 1053 -> (see DESIGN) frames/s at 720x960 fp16, bit-identical
                                        (profiles/r04j_*, r04x_*); bit 65536 (fp32 only) since round 5: the 7x7 stem 168 -> 125 us at 1024x2048, frames/s +0.2 % (td4
                                        1024x2048, where the stem runs beside the cache-only attention chain) ... +1.5 % (td2 1024x2048) (profiles/r05j_*);
@@ -105,7 +105,10 @@ typedef struct tdnet_opts {
                                 131072 = precision 1 only (default, round 5): a BasicBlock's conv1 and 1x1 downsample in ONE launch where both run on the
                                      register-staged kernel (ResNet layer2.0 at 720x960), and the Encoding's five 1x1 convs in TWO launches -- value / query / key first layers
                                      side by side on z, then the query / key second layers (k_conv_igemm_h_group: blocks of up to three convs in one
-                                     grid); the value conv is packed for the 64-channel tile of the others.  Same products, same order: bit-identical. */
+                                     grid); the value conv is packed for the 64-channel tile of the others.  Same products, same order: bit-identical.
+                                262144 = fp32 / precision 2 (default, round 6): the FCN head's 1x1 classifier inside its 3x3 conv's Winograd output transform
+                                     (k_wino4_out_cls; td4_psp18.py:295-299): one launch fewer, the 128- / 64-channel hidden map is never written; same
+                                     arithmetic in the same order: bit-identical low-resolution logits. */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
                                 1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

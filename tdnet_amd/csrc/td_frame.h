@@ -228,12 +228,16 @@ static int finish_frame(tdnet* n, PathLayers& L, bool steady, hipStream_t s) {
     run_layernorm(n, feat, n->Lq, DV, L.d_ln_g, L.d_ln_b, n->ln_part, n->ln_mean, n->ln_rstd, ln_in_head ? nullptr : n->ln, s, stats_nstr, ln16);
     n->ln_pending = ln_in_head || ln16;
     n->ln_path = (int)(&L - &n->paths[0]);
+    // fusion bit 262144 (round 6): the 1x1 classifier inside the head conv's Winograd output transform (k_wino4_out_cls): the hidden map is never
+    // written, one launch fewer, low-resolution logits bit-identical to the two-kernel form
+    const bool cls_in_head = (n->opts.fusion & 262144) && L.head3.wino && L.head3.chunks == 1 && wino_out_cls_supports(n->MID, n->cfg.nclass);
+    const ClsArgs ca = {L.d_cls_w, L.d_cls_b, n->lowres, n->cfg.nclass};
     if (ln_in_head) {
         const LnFuse lf = {n->ln_mean, n->ln_rstd, L.d_ln_g, L.d_ln_b};
-        TD_TRY(run_conv(n, L.head3, feat, n->h, n->w, nullptr, n->headmid, s, nullptr, nullptr, &lf));
+        TD_TRY(run_conv(n, L.head3, feat, n->h, n->w, nullptr, n->headmid, s, nullptr, nullptr, &lf, cls_in_head ? &ca : nullptr));
     } else
-    TD_TRY(run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s));
-    TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
+    TD_TRY(run_conv(n, L.head3, n->ln, n->h, n->w, nullptr, n->headmid, s, nullptr, nullptr, nullptr, cls_in_head ? &ca : nullptr));
+    if (!cls_in_head) TD_TRY(run_classifier(n, n->headmid, n->Lq, n->MID, n->cfg.nclass, L.d_cls_w, L.d_cls_b, n->lowres, s));
     if (n->failed) return -1;
     // FIFO push (td4_psp18.py:153-154, :123-134): host bookkeeping only -- the entry's data was written by encode_frame into its slot.
     // It is the LAST thing a frame does: a frame whose head fails to launch is not in the FIFO.

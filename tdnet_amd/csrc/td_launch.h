@@ -55,8 +55,9 @@ static void launch_wino4_c(bool out_side, const WinoArgs& wa, hipStream_t s) {
 
 // Winograd F(4x4) conv (or one chunk of it): input transform -> 36 batched GEMMs -> output transform, all on stream s.
 // V / Mb: workspaces for THIS call ([nb][Tc + pad][C]); nullptr = the handle's (n->wino_v / wino_m) or, without a handle, temporary ones.
+// cls != nullptr: the conv is the FCN head's 3x3 and its output transform also applies the 1x1 classifier (k_wino4_out_cls): `out` is not written
 static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
-                    const LnFuse* lnf, const WinoChunk& ck, float* V, float* Mb) {
+                    const LnFuse* lnf, const WinoChunk& ck, float* V, float* Mb, const ClsArgs* cls = nullptr) {
     const int TY = wino_tiles_1d(H, L.dil, L.wino), TX = wino_tiles_1d(W, L.dil, L.wino);
     const long T = (long)L.dil * L.dil * TY * TX;
     const bool chunked = ck.ny != 1 || ck.nx != 1;
@@ -81,6 +82,11 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         if (n && (probe_skip() & 1)) return;
         prof_begin(n, 2, false, 0, s);
         const int C = out_side ? L.Cout : L.Cin;
+        if (out_side && cls) {
+            const unsigned grid = (unsigned)((Tc + 3) / 4);
+            if (L.Cout == 128) TD_LAUNCH((k_wino4_out_cls<2>), dim3(grid), dim3(256), wino_out_cls_lds(128, cls->NC), s, wa, *cls);
+            else TD_LAUNCH((k_wino4_out_cls<1>), dim3(grid), dim3(256), wino_out_cls_lds(64, cls->NC), s, wa, *cls);
+        } else
         if (L.vw == 1) launch_wino4_c<1>(out_side, wa, s);
         else if (L.vw == 2 && C % 2 == 0) launch_wino4_c<2>(out_side, wa, s);
         else if (L.vw == 4 && C % 4 == 0) launch_wino4_c<4>(out_side, wa, s);
@@ -132,8 +138,9 @@ static void launch_conv_dma_forms(const ConvLayer& L, const ConvArgs& a, hipStre
 
 // out[Ho*Wo][Cout] = act(conv(in[H][W][Cin]) + bias (+ resid))
 static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W, const float* resid, float* out, hipStream_t s,
-                    int* Ho_out = nullptr, int* Wo_out = nullptr, const LnFuse* lnf = nullptr) {
+                    int* Ho_out = nullptr, int* Wo_out = nullptr, const LnFuse* lnf = nullptr, const ClsArgs* cls = nullptr) {
     if (lnf && !L.wino) return td_fail("internal: LayerNorm fusion needs a Winograd input transform");
+    if (cls && (!L.wino || L.chunks > 1 || resid)) return td_fail("internal: the classifier rides in a whole Winograd conv's output transform");
     const int Ho = out_size(H, L.KS, L.stride, L.dil, L.pad), Wo = out_size(W, L.KS, L.stride, L.dil, L.pad);
     if (L.wino) {
         if (Ho_out) *Ho_out = H;
@@ -145,7 +152,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
             }
             return 0;
         }
-        return run_wino(n, L, in, H, W, resid, out, s, lnf, WinoChunk(), nullptr, nullptr);
+        return run_wino(n, L, in, H, W, resid, out, s, lnf, WinoChunk(), nullptr, nullptr, cls);
     }
     ConvArgs a;
     a.in = in; a.wp = L.d_wp; a.bias = L.d_bias; a.resid = resid; a.out = out;

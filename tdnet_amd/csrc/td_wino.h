@@ -379,6 +379,83 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, VW == 4 ? 2 : 4) k_wino4_out_c(WinoArgs p) 
     if (wv >= p.Tc * slices) return;
     td_wino4_out_unit<VW>(p, wv, []() {});
 }
+// ---- the FCN head's output transform + its 1x1 classifier in one launch (round 6; td4_psp18.py:295-299: conv3x3 -> BN -> ReLU -> conv1x1 + bias) -------------
+// A wave owns one tile = 16 pixels x ALL Cout = 64 VW channels of the head's hidden map (td4: 128, td2: 64): A^T m A + bias, ReLU as in td_wino4_out_unit, the
+// 16 x Cout values go to LDS (rows padded by 4 floats: 16 lanes reading 16 rows hit 16 different 16-byte slots) instead of HBM, and lane i computes the outputs
+// (pixel i & 15, class i >> 4), (.., + 4), .. with k_classifier's summation order -- four sequential fma chains over the channel quarters, added as
+// ((s0 + s1) + s2) + s3 + bias -- so the low-resolution logits are bit-identical to the two-kernel form.  The hidden map (17 MB at 1024x2048) is never written.
+struct ClsArgs { const float* w; const float* b; float* out; int NC; };   // classifier [NC][Cout], [NC]; out planar [NC][H * W]
+template <int VW>
+TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_wino4_out_cls(WinoArgs p, ClsArgs c) {
+    typedef WinoVec<VW> X;
+    typedef typename X::T T;
+    constexpr int C = 64 * VW, ROW = C + 4;
+    TD_DYN_LDS(smem);
+    float* ws = reinterpret_cast<float*>(smem);                        // [NC][C]
+    float* ys = ws + c.NC * C + (threadIdx.x >> 6) * (16 * ROW);       // this wave's [16 pixels][ROW]
+    for (int i = threadIdx.x; i < c.NC * C; i += blockDim.x) ws[i] = c.w[i];
+    __syncthreads();                                                   // the only workgroup barrier: waves past the last tile may leave after it
+    const int wv = TD_UNIFORM((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wv >= p.Tc) return;
+    const int lane = threadIdx.x & 63;
+    const WinoTile w = td_wino_unit_tile(p, 1, wv);
+    const float slope = td_act_slope(p.act);
+    const unsigned coff = (unsigned)(lane * VW) * 4u;
+    const unsigned plane = (unsigned)p.TP * (unsigned)C * 4u;
+    const TdBuf mb = td_make_buf(p.Mb, 36u * plane);
+    const unsigned moff = (unsigned)w.tl * (unsigned)C * 4u;
+    T mm[6][6];                                                       // [c][r]
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) mm[cc][r] = X::ld(mb, coff, (unsigned)(r * 6 + cc) * plane + moff);
+    const TdBuf bbuf = td_make_buf(p.bias, (unsigned)C * 4u);
+    const T b = X::ld(bbuf, coff, 0u);
+    T sm[4][6];
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+        T col[4];
+        td_wino4_at_t(mm[cc], col);                                   // A^T m, one column
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[r][cc] = col[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T o4[4];
+        td_wino4_at_t(sm[r], o4);                                     // (.) A, one row
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            T o = o4[cc] + b;
+            o = o + T(0.f);                                           // the zero residual of td_wino4_out_unit / k_wino4_out (-0 + 0 = +0: same bits)
+            o = X::act(o, slope);
+            float* dst = ys + (r * 4 + cc) * ROW + lane * VW;
+            if constexpr (VW == 1) dst[0] = o;
+            else { dst[0] = o[0]; dst[1] = o[1]; }
+        }
+    }
+    td_wave_sync();
+    const int CQ = C >> 2;
+    for (int idx = lane; idx < 16 * c.NC; idx += 64) {
+        const int px = idx & 15, k = idx >> 4;
+        const float* yr = ys + px * ROW;
+        const float* wr = ws + k * C;
+        float s[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float a = 0.f;
+            for (int ch = 0; ch < CQ; ch += 4) {
+                const f32x4 v = td_ld4(yr + qd * CQ + ch), u = td_ld4(wr + qd * CQ + ch);
+                a = fmaf(v[0], u[0], a); a = fmaf(v[1], u[1], a); a = fmaf(v[2], u[2], a); a = fmaf(v[3], u[3], a);
+            }
+            s[qd] = a;
+        }
+        const int y = w.py + p.dil * (4 * w.ty + (px >> 2)), x = w.px + p.dil * (4 * w.tx + (px & 3));
+        if (y < p.H && x < p.W) c.out[(size_t)k * p.H * p.W + (size_t)y * p.W + x] = (((s[0] + s[1]) + s[2]) + s[3]) + c.b[k];
+    }
+}
+static inline bool wino_out_cls_supports(int Cout, int NC) { return (Cout == 64 || Cout == 128) && NC >= 1 && NC <= 32; }
+static inline int wino_out_cls_lds(int Cout, int NC) { return (NC * Cout + 4 * 16 * (Cout + 4)) * 4; }
+
 // grid of a chunked transform: one wave per (tile, channel slice)
 static inline unsigned wino_chunk_grid(int Tc, int C, int VW) { return (unsigned)(((long)Tc * ((C + 64 * VW - 1) / (64 * VW)) + 3) / 4); }
 

@@ -676,3 +676,30 @@ def test_pipeline_precision2_against_reference_goldens(lib, golden_dir, name, bb
             top2 = np.sort(ref[0], axis=0)[-2:]
             assert ((top2[1] - top2[0])[bad] <= 2 * err).all(), (t, int(bad.sum()))
     e.close()
+
+
+@pytest.mark.parametrize("name,P,bb,opts", [("td4", 4, "resnet18", {}), ("td2", 2, "resnet18", {"winograd": 4})])
+def test_classifier_inside_the_head_output_transform(lib, name, P, bb, opts):
+    """tdnet_opts.fusion bit 262144 (round 6, td_wino.h k_wino4_out_cls): the FCN head's 1x1 classifier (td4_psp18.py:295-299) computed by the wave that holds a
+    tile's 16 pixels x all hidden channels, with k_classifier's summation order: logits bit for bit those of the two-kernel form, one launch fewer, in the
+    warm-up and the steady-state frames.  td4: 128 hidden channels (two per lane).  td2's head (128 -> 64) is a direct conv by default; under winograd = 4
+    (F(4x4) for every stride-1 3x3) it exercises the one-channel-per-lane form."""
+    H, W = 33, 65
+    spec = arch.model_spec(name, 19, bb)
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
+    base = lib.opts(**opts).fusion
+    assert base & 262144                                               # the default since round 6 (profiles/r06p_*)
+    outs, launches = [], []
+    for fusion in (base & ~262144, base | 262144):
+        e = Engine(P, int(bb[6:]), 19, H, W, 0, lib=lib, opts=dict(opts, fusion=fusion))
+        e.load_state_dict(sd)
+        o = []
+        for t, x in enumerate(weights.synth_video(H, W, P, seed=2)):
+            out = np.zeros((1, 19, H, W), np.float32)
+            e.forward(x, t % P, out)
+            o.append(out)
+        outs.append(o)
+        launches.append(e.last_launch_count())
+        e.close()
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
+    assert launches[0] - launches[1] == 1, launches
