@@ -29,6 +29,8 @@
 //   k_gemm_dma (exact fp32 MFMA)  306 us, MFMA pipes 0.88 busy, 126 TFLOP/s -- at its roof;
 //   this kernel                   187 us, MFMA pipes 0.57 busy at 2.09 GHz (the chip's clock under this load), 207 TFLOP/s = 1240 TFLOP/s of
 //                                 bf16 MFMA issue, what the guide's best plain-HIP bf16 GEMM reaches on random data (cdna_hip_programming.md).
+// Three LDS buffers of A with the step's last four DMA pieces left in flight across the barrier (vmcnt(4) instead of 0): 0.307 vs 0.308 ms per conv, +0.3 % in the
+// frame = noise (profiles/r06r_*): the wait at the end of a step is not what the pipes are waiting for.  Not kept.
 // First form of this kernel (removed; last commit with it: the one before this header's): four matrix + four LOADER waves (k_conv_dma_h3p's
 // recipe), one workgroup per CU, ring of five LDS buffers: 200 us.  Leave-one-out probes of that form (profiles/r06b_* .. r06d_*): without MFMAs
 // 90 us, without memory traffic 113, without the split 120, without B fragment reads 124, without epilogue stores 121, skeleton alone (barriers +
