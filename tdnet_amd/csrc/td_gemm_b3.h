@@ -31,6 +31,13 @@
 //                                 bf16 MFMA issue, what the guide's best plain-HIP bf16 GEMM reaches on random data (cdna_hip_programming.md).
 // Three LDS buffers of A with the step's last four DMA pieces left in flight across the barrier (vmcnt(4) instead of 0): 0.307 vs 0.308 ms per conv, +0.3 % in the
 // frame = noise (profiles/r06r_*): the wait at the end of a step is not what the pipes are waiting for.  Not kept.
+// Where the other 43 % goes (in-kernel s_memtime stamps, tools/gemm_b3_trace.hip, profiles/r06s_* .. r06u_*): with two workgroups on a CU a K step of 48 MFMAs per
+// wave (1536 pipe cycles) takes ~4400-5000 cycles per workgroup = issue 2100-2250 + vmcnt wait 750-1600 + barrier 800-1100.  With the A pieces zero-filled (no
+// memory traffic) the conv's 36 GEMMs take 0.1925 ms, with the B pieces 0.1898, with both 0.1836, against 0.2239: the CU's LDS-DMA path carries 56 KB per ~4400 cycles,
+// ~13 B/clk/CU = ~7 TB/s over the chip, and that is what the last 18 % waits for; the rest is two waves per SIMD sharing one MFMA pipe at a power-limited 2.09 GHz.
+// A loaded straight from global memory into registers in fragment layout (a wave owns its 64 rows, so staging A in LDS shares nothing; two raw register sets, loop
+// unrolled by two, only B on LDS-DMA: 43 % of the DMA bytes): no spills in the loop, bit-identical, and SLOWER -- the issue phase grows 2176 -> 3119 cycles (the
+// register loads' vmcnt waits land inside it), 0.2299 vs 0.2224 ms per 36 GEMMs, frame 322.9 vs 325.8 at 1024x2048, 440.1 vs 444.4 at 769x1537 (profiles/r06u_*).  Not kept.
 // First form of this kernel (removed; last commit with it: the one before this header's): four matrix + four LOADER waves (k_conv_dma_h3p's
 // recipe), one workgroup per CU, ring of five LDS buffers: 200 us.  Leave-one-out probes of that form (profiles/r06b_* .. r06d_*): without MFMAs
 // 90 us, without memory traffic 113, without the split 120, without B fragment reads 124, without epilogue stores 121, skeleton alone (barriers +
@@ -64,6 +71,15 @@ TD_DEV void td_split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned&
     l = td_pk_bf16(sa, sb);
 }
 
+#ifdef TD_B3_TRACE      // tools/gemm_b3_trace.hip only: s_memtime stamps of workgroups 0..7, every wave, the first 48 K steps:
+// [0] step start, [1] all MFMAs issued, [2] after the vmcnt wait, [3] after the barrier
+#define TD_B3_STAMP(gs_, slot) do { if (blockIdx.x < 8 && (gs_) < 48 && lane == 0) \
+    TD_B3_TRACE[(((size_t)blockIdx.x * 4 + wave) * 48 + (gs_)) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TD_B3_DEAD(bit) ((p.act & (bit)) != 0)                      // trace builds: GemmArgs.act bit 1 / 2 = no memory traffic for the A / B pieces (zero fill)
+#else
+#define TD_B3_STAMP(gs_, slot) ((void)0)
+#define TD_B3_DEAD(bit) false
+#endif
 struct GemmB3Geom {
     static constexpr int BM = 256, BN = 128;
     static constexpr int A_BYTES = BM * 64, B_BYTES = 12 * 1024, LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;
@@ -125,7 +141,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_b3(GemmArgs p) {
     };
     int abuf_i = 0, wbuf_i = 0;                                        // buffer the next A / B step goes to
     auto issue_a = [&](int j) {
-        const bool live = ca.tile < my_tiles;
+        const bool live = ca.tile < my_tiles && !TD_B3_DEAD(1);
         td_buf_ld16_lds(a_buf, smem + abuf_i * G::A_BYTES + (wave + 4 * j) * 1024, live ? a_off[j] : TD_BUF_OOB, live ? (unsigned)ca.step * 64u : 0u);
     };
     auto end_a = [&]() {
@@ -133,7 +149,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_b3(GemmArgs p) {
         if (ca.tile < my_tiles && ++ca.step == nsteps) { ca.step = 0; if (++ca.tile < my_tiles) { advance(ca.pos); enter_a(); } }
     };
     auto issue_w = [&](int jb) {
-        const bool live = cw.tile < my_tiles;
+        const bool live = cw.tile < my_tiles && !TD_B3_DEAD(2);
         td_buf_ld16_lds(w_buf, bbase + wbuf_i * G::B_BYTES + (wave + 4 * jb) * 1024, live ? b_off[jb] : TD_BUF_OOB, live ? (unsigned)cw.step * w_step_bytes : 0u);
     };
     auto end_w = [&]() {
@@ -195,8 +211,11 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_b3(GemmArgs p) {
         TD_BARRIER_RAW();                                              // every wave has read A(0): its buffer may be refilled (A(2), step 0)
     }
     int cb = 0;                                                        // buffer of B(g); A(g + 1) sits in buffer cb ^ 1
+    int gs = 0;                                                        // global step (trace builds)
+    (void)gs;
     for (int t = 0; t < my_tiles; ++t) {
         for (int st = 0; st < nsteps; ++st) {
+            TD_B3_STAMP(gs, 0);
             // step g: twelve fenced groups of four MFMAs; the split of A(g + 1), the fragment reads and this wave's seven DMA pieces
             // (A(g + 2) into the buffer A(g) left, B(g + 1) into the buffer B(g - 1) left) ride between them
             f32x4 nx[2][2];
@@ -253,8 +272,12 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, 2) k_gemm_b3(GemmArgs p) {
             end_w(); end_a();
 #pragma unroll
             for (int i = 0; i < 2; ++i) { ah[i] = nh[i]; am[i] = nm[i]; al[i] = nl[i]; }
+            TD_B3_STAMP(gs, 1);
             TD_WAIT_VM_PIECES(0);
+            TD_B3_STAMP(gs, 2);
             TD_BARRIER_RAW();
+            TD_B3_STAMP(gs, 3);
+            ++gs;
             cb ^= 1;
         }
         float* outb = p.out + (size_t)spos.b * p.MP * p.N;
