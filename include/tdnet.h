@@ -47,7 +47,7 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 499750  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072 | 262144; bit 262144 since round 6: 276.4 -> 277.2 frames/s at C3, 393.6 -> 394.3 at 769x1537, one launch fewer, bit-identical (profiles/r06p_*); bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+#define TDNET_FUSION_DEFAULT 1024038  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072 | 262144 | 524288; bit 524288 (precision 2 only) since round 6: 322.9 -> 339.6 frames/s at C3 with precision 2, 441.8 -> 458.9 at 769x1537, td2-psp34 720x960 446.9 -> 469.0 (profiles/r06z_*); bit 262144 since round 6: 276.4 -> 277.2 frames/s at C3, 393.6 -> 394.3 at 769x1537, one launch fewer, bit-identical (profiles/r06p_*); bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
                                        bits 8192 and 32768 (precision 1 only) since round 4: 1042 -> 1053 -> (see DESIGN) frames/s at 720x960 fp16, bit-identical
                                        (profiles/r04j_*, r04x_*); bit 65536 (fp32 only) since round 5: the 7x7 stem 168 -> 125 us at 1024x2048, frames/s +0.2 % (td4
                                        1024x2048, where the stem runs beside the cache-only attention chain) ... +1.5 % (td2 1024x2048) (profiles/r05j_*);
@@ -108,7 +108,10 @@ typedef struct tdnet_opts {
                                      grid); the value conv is packed for the 64-channel tile of the others.  Same products, same order: bit-identical.
                                 262144 = fp32 / precision 2 (default, round 6): the FCN head's 1x1 classifier inside its 3x3 conv's Winograd output transform
                                      (k_wino4_out_cls; td4_psp18.py:295-299): one launch fewer, the 128- / 64-channel hidden map is never written; same
-                                     arithmetic in the same order: bit-identical low-resolution logits. */
+                                     arithmetic in the same order: bit-identical low-resolution logits.
+                                524288 = precision 2 only (default, round 6): the Cout <= 64 convs that read their A operand straight from global memory (bit 32:
+                                     ResNet layer1, the packed-row 7x7 stem of bit 65536) on the bf16 MFMA with both operands as three bf16 parts
+                                     (td_conv_ad_b3.h): layer1's conv 85 -> 59 us at 1024x2048, errors against fp64 at or below the fp32 kernel's. */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
                                 1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -19,6 +19,7 @@
 #include "td_gemm.h"
 #include "td_gemm_dma.h"
 #include "td_gemm_b3.h"
+#include "td_conv_ad_b3.h"
 #include "td_attn.h"
 #include "td_attn_h.h"
 #include "td_attn_b3.h"

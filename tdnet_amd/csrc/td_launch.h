@@ -173,8 +173,10 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     } else if (L.adirect && L.stem_rows) {                              // the image is padded already: its own geometry, 3 channels, no padding taps
         ConvArgs r = a;
         r.H = stem_rows_hp(H); r.W = stem_rows_wp(W); r.Cin = 3; r.pad = 0;
-        conv_launch_adirect(r, L.KS, 2, s);
-    } else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem ? 1 : 0, s);
+        if (L.b3) conv_launch_adirect_b3(r, L.KS, 2, s);
+        else conv_launch_adirect(r, L.KS, 2, s);
+    } else if (L.adirect && L.b3) conv_launch_adirect_b3(a, L.KS, 0, s);
+    else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem ? 1 : 0, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);
     if (Ho_out) *Ho_out = Ho;

@@ -89,15 +89,31 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         gemm_b3_pack(w.data(), Cout, Cin, packed.data());
         TD_TRY(dev_alloc((unsigned short**)&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    } else if (o.precision >= 2 && (o.fusion & 32) && (o.fusion & 524288) && !gemm1x1 && conv_adirect_b3_supports(L.tile, Cin, KS, stem)) {
+        // precision 2: the Cout <= 64 convs (ResNet layer1) on the bf16 MFMA, A straight from global memory (td_conv_ad_b3.h)
+        L.b3 = 1;
+        L.nsteps = conv_nsteps(Cin, KS, 0);
+        std::vector<unsigned short> packed(conv_adb3_packed_bytes(Cout, Cin, KS) / 2);
+        conv_pack_weights_adb3(w.data(), Cout, Cin, KS, packed.data());
+        TD_TRY(dev_alloc((unsigned short**)&L.d_wp, packed.size()));
+        TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     } else {
         // the 7x7 stem with its A operand straight from global memory can read a packed-row image instead of NHWC4 taps: K = 168 instead of 224
         L.stem_rows = stem && KS == 7 && stride == 2 && (o.fusion & 65536) && (o.fusion & 32) && conv_adirect_supports(L.tile, 1);
         const int stem_kind = L.stem_rows ? 2 : stem ? 1 : 0;
         L.nsteps = conv_nsteps(Cin, KS, stem_kind);
+        if (L.stem_rows && o.precision >= 2 && (o.fusion & 524288)) {   // precision 2: the packed-row stem on the bf16 MFMA (td_conv_ad_b3.h STEM = 2)
+            L.b3 = 1;
+            std::vector<unsigned short> packed(conv_adb3_packed_bytes(Cout, Cin, KS, 2) / 2);
+            conv_pack_weights_adb3(w.data(), Cout, Cin, KS, packed.data(), 2);
+            TD_TRY(dev_alloc((unsigned short**)&L.d_wp, packed.size()));
+            TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        } else {
         std::vector<float> packed((size_t)L.nsteps * 8 * L.CoutPad * 4);
         conv_pack_weights(w.data(), Cout, Cin, KS, stem_kind, L.tile, packed.data());
         TD_TRY(dev_alloc(&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     L.adirect = (o.fusion & 32) && !L.h16 && !gemm1x1 && conv_adirect_supports(L.tile, 1);
     std::vector<float> bb(Cout, 0.f);

@@ -631,6 +631,15 @@ def test_split_gemm_precision2_ops(lib):
     opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0, online=17)
     opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=17, ln=True)
     opcheck.attention(lib, MEM, 70, 300, 512, online=17, ramp=True, ln=True)
+    # the Cout <= 64 convs of precision 2 (td_conv_ad_b3.h, fusion bit 524288: A straight from global memory, weights by LDS-DMA on three buffers): ResNet
+    # layer1's shape, an odd number of K steps with stride / dilation / ragged channels, a single step, the strided 1x1 form, the packed-row 7x7 stem
+    o2 = {"precision": 2}
+    opcheck.conv(lib, MEM, 13, 21, 64, 64, 3, 1, 1, 1, True, opts=o2)
+    opcheck.conv(lib, MEM, 11, 9, 96, 48, 3, 2, 2, 0, False, opts=o2)
+    opcheck.conv(lib, MEM, 9, 17, 32, 64, 1, 1, 1, 2, True, opts=dict(o2, gemm_persistent=0))
+    opcheck.conv(lib, MEM, 9, 17, 64, 40, 1, 2, 1, 2, True, opts=o2)
+    for H, W in ((33, 65), (18, 23), (7, 9)):
+        opcheck.stem(lib, MEM, H, W, opts=o2)
     # the size heuristic of precision 2: a GEMM of fewer than 256 tiles stays on the exact-fp32 kernels, bit for bit
     import ctypes
     g = np.random.default_rng(3)
@@ -644,6 +653,15 @@ def test_split_gemm_precision2_ops(lib):
         outs.append(out.copy())
     assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
     assert np.abs(outs[0] - outs[2]).max() < 1e-4
+    x = g.standard_normal((13, 21, 64)).astype(np.float32)
+    w = (g.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32)
+    outs = []
+    for kw in ({}, {"precision": 2}, {"precision": 2, "fusion": lib.opts().fusion & ~524288}):   # the narrow convs: split with the bit, exact fp32 without
+        out = MEM.empty((13, 21, 64))
+        oo = lib.opts(**kw)
+        lib.check(lib.tdnet_op_conv2d(MEM.ptr(MEM.put(x)), 13, 21, 64, w.ctypes.data, None, 64, 3, 1, 1, None, 0, ctypes.byref(oo), -1, MEM.ptr(out), None))
+        outs.append(out.copy())
+    assert not np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.abs(outs[0] - outs[1]).max() < 1e-4
 
 
 @pytest.mark.parametrize("name,bb,H,W,opts", [("td2", "resnet18", 33, 65, {"precision": 3, "overlap": 41 | 4}), ("td2", "resnet50", 33, 65, {"precision": 3})])

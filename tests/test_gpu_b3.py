@@ -55,8 +55,12 @@ def test_split_gemm_operators_are_as_accurate_as_the_fp32_kernels():
                                                    (33, 65, 128, 132, 3, 1, True, 1),       # ragged tile rows, N not a multiple of 128
                                                    (97, 193, 512, 512, 1, 1, False, 0),     # the Encoding's value conv at the native feature size
                                                    (40, 52, 512, 64, 1, 1, True, 2),        # 512 -> 64 (half a tile of padding), residual, LeakyReLU
-                                                   (17, 33, 2048, 512, 1, 1, False, 1)]:    # K = 2048 (a Bottleneck conv1): 128 steps
+                                                   (17, 33, 2048, 512, 1, 1, False, 1),     # K = 2048 (a Bottleneck conv1): 128 steps
+                                                   (128, 256, 64, 64, 3, 1, True, 1),       # ResNet layer1 (k_conv_adirect_b3, fusion bit 524288)
+                                                   (37, 53, 96, 48, 3, 3, False, 0)]:       # the same kernel: 27 steps, ragged rows and channels, dilation 3
         vs = [v for v in V if not ((v[0].get("overlap", 0) & 1) and (KS == 1 or dil % 2))]
+        if Cout <= 64 and KS == 3:
+            vs = [({}, -1), ({"precision": 2}, -1)]                    # fusion bit 524288 (default): the split kernel whatever the size
         e = _conv_errors(lib, H, W, Cin, Cout, KS, dil, resid, act if act != 2 else 0, vs)
         print("conv %dx%d %d->%d k%d d%d: fp32 max %.2e rms %.2e | split %s" % (H, W, Cin, Cout, KS, dil, e[0][0], e[0][1], " ".join("max %.2e rms %.2e" % x for x in e[1:])))
         for x in e[1:]:
@@ -66,6 +70,22 @@ def test_split_gemm_operators_are_as_accurate_as_the_fp32_kernels():
     opcheck.conv(lib, mem, 13, 21, 128, 128, 3, 1, 2, 1, True, opts={"precision": 3})
     opcheck.conv(lib, mem, 11, 19, 64, 160, 1, 1, 1, 2, True, opts={"precision": 3})
     opcheck.conv(lib, mem, 300, 40, 64, 256, 1, 1, 1, 0, False, opts={"precision": 3, "gemm_persistent": 11})
+    opcheck.conv(lib, mem, 61, 77, 64, 64, 3, 1, 1, 1, True, opts={"precision": 2})            # k_conv_adirect_b3: layer1, ragged rows
+    opcheck.conv(lib, mem, 40, 52, 96, 40, 3, 2, 2, 2, False, opts={"precision": 2})           # stride 2, dilation 2, 27 steps (odd), ragged channels
+    opcheck.conv(lib, mem, 33, 65, 64, 64, 1, 2, 1, 0, False, opts={"precision": 2})           # the strided 1x1 form
+    for H, W in ((131, 259), (224, 224), (7, 9)):                                               # the packed-row 7x7 stem on the split kernel
+        opcheck.stem(lib, mem, H, W, opts={"precision": 2})
+    # the new kernels really ran (their sums are not the fp32 MFMA's bit for bit) and a handle without the bit keeps the exact-fp32 ones
+    g = np.random.default_rng(3)
+    x = torch.from_numpy(g.standard_normal((61, 77, 64)).astype(np.float32)).cuda()
+    w = (g.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32)
+    outs = []
+    for kw in ({}, {"precision": 2}, {"precision": 2, "fusion": lib.opts().fusion & ~524288}):
+        out = torch.empty(61, 77, 64, device="cuda")
+        o = lib.opts(**kw)
+        lib.check(lib.tdnet_op_conv2d(x.data_ptr(), 61, 77, 64, w.ctypes.data, None, 64, 3, 1, 1, None, 0, ctypes.byref(o), -1, out.data_ptr(), None))
+        outs.append(out.cpu())
+    assert not torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and (outs[0] - outs[1]).abs().max() < 1e-4
 
 
 def test_split_attention_is_as_accurate_as_the_fp32_kernel():

@@ -1,15 +1,16 @@
 #!/bin/bash
-# GPU-box: counter passes (one set per rocprofv3 run, kernel trace only) over tools/b3_one.py; prints per-kernel derived figures.
-#   tools/b3_pmc.sh <outdir> <b3_one.py args...>
+# GPU-box: counter passes (one set per rocprofv3 run, kernel trace only) over tools/b3_one.py (or the command in $PMC_CMD); prints per-kernel derived figures.
+#   tools/b3_pmc.sh <outdir> <b3_one.py args...>        PMC_CMD="python tools/adb3_probe.py 256x512 20 split" tools/b3_pmc.sh <outdir>
+# (no TCC_* counters: that pass hung until its timeout on this pool, three times -- round 6)
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$1; shift
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/tools/b3_one.py $*"
+B=${PMC_CMD:-"python $GRAFT_REPO_ROOT/tools/b3_one.py $*"}
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d "$R/p1" -o r1 -- $B > "$R/p1.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE -d "$R/p2" -o r1 -- $B > "$R/p2.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC -d "$R/p3" -o r1 -- $B > "$R/p3.log" 2>&1
-timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum -d "$R/p4" -o r1 -- $B > "$R/p4.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$R/p4" -o r1 -- $B > "$R/p4.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$R/p5" -o r1 -- $B > "$R/p5.log" 2>&1
 cd "$GRAFT_REPO_ROOT"
 python - "$R" <<'PY'
