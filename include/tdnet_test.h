@@ -36,7 +36,8 @@ int tdnet_op_stem(const float* img_dev, int H, int W, const float* w_host, const
  * online: tdnet_opts.attention (0 = exact two-pass softmax, 1 = single pass with a lazily moved reference, 2 = 1 pipelined to one
  * barrier per key tile), or 16 = the fp16-MFMA kernel of tdnet_opts.precision = 1 (single pass; operands and P rounded to fp16,
  * softmax and accumulation fp32), or 17 = the split kernel of tdnet_opts.precision = 2 (td_attn_b3.h: q, k, P and v' as three bf16 parts each, six
- * bf16-MFMA products per product, fp32 softmax and accumulation).  The fp32 kernels read V' in whole 128-key tiles: when Lk is not a multiple of 128 the op runs on a
+ * bf16-MFMA products per product, fp32 softmax and accumulation; at DV = 512 k the form is picked by Lq as in a frame; 18 forces the 64-query / eight-wave
+ * form, 19 the 32-query form).  The fp32 kernels read V' in whole 128-key tiles: when Lk is not a multiple of 128 the op runs on a
  * zero-padded copy of vp, unless `online | 32` says vp_dev itself has ((Lk + 127) / 128) * 128 rows, the extra ones finite.
  * ln_out != NULL: also the plane LayerNorm (affine ln_g, ln_b [Lq]) of the result, from the strip statistics the kernel's epilogue
  * writes (tdnet_opts.fusion bit 2) -> ln_out [Lq,DV].                                                                          */

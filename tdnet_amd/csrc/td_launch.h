@@ -224,7 +224,7 @@ static int run_conv_group(tdnet* n, const ConvCall* c, int ng, hipStream_t s, in
 // td_attn_b3.h; the handle uses it for the FINAL attention of a frame only -- the cached-frame steps are hidden on the side stream either way)
 static int run_attention(tdnet* n, const float* q, const float* k, const float* vp, const float* bias, const float* resid,
                          int Lq, int Lk, int DV, float* out, hipStream_t s, int online = 0, float* ln_part = nullptr,
-                         _Float16* vt16 = nullptr, bool slices = false, bool vt_ready = false, bool b3 = false) {
+                         _Float16* vt16 = nullptr, bool slices = false, bool vt_ready = false, int b3 = 0) {   // b3: 1 = the split kernels (form by size), 2 / 3 = the 32- / 64-query form (tests)
     if (n && n->vt16 && (n->opts.precision == 1 || b3)) vt16 = n->vt16;
     AttnArgs a;
     a.q = q; a.k = k; a.vp = vp; a.bias = bias; a.resid = resid; a.out = out; a.Lq = Lq; a.Lk = Lk;
@@ -232,7 +232,7 @@ static int run_attention(tdnet* n, const float* q, const float* k, const float* 
     a.ln_part = ln_part; a.ln_nstr = 0;
     if (n && (probe_skip() & 4) && Lq > Lk) return 0;
     prof_begin(n, 1, false, 2.0 * Lq * (double)Lk * (64 + DV), s);
-    const int rc = (vt16 && b3) ? attn_launch_b3(a, DV, reinterpret_cast<unsigned short*>(vt16), s, vt_ready)
+    const int rc = (vt16 && b3) ? attn_launch_b3(a, DV, reinterpret_cast<unsigned short*>(vt16), s, vt_ready, b3 - 1)
                  : vt16 ? attn_launch_h(a, DV, vt16, s, vt_ready) : attn_launch(a, DV, online, s, slices);   // vt16: the fp16-MFMA kernel (tdnet_opts.precision = 1)
     prof_end(n, s);
     if (rc) return td_fail("attention: unsupported d_v=%d (128 or a multiple of 512)", DV);

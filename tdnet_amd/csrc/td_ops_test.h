@@ -112,7 +112,8 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     online &= ~(32 | 64);
     // arguments are validated BEFORE anything is allocated; every later exit goes through cleanup()
     if (ln_out && (!ln_g || !ln_b)) return td_fail("tdnet_op_attention: ln_out needs ln_g and ln_b");
-    if (online != 16 && online != 17 && (online < 0 || online > 2)) return td_fail("tdnet_op_attention: online must be 0, 1, 2, 16 or 17");
+    const bool split = online >= 17 && online <= 19;                   // 17: the split kernels of precision 2 (td_attn_b3.h), form by size; 18: the 64-query form; 19: the 32-query form
+    if (online != 16 && !split && (online < 0 || online > 2)) return td_fail("tdnet_op_attention: online must be 0, 1, 2 or 16 .. 19");
     float *part = nullptr, *mean = nullptr, *rstd = nullptr, *vpad = nullptr;
     _Float16* vt = nullptr;                                            // online == 16: the fp16-MFMA kernel of tdnet_opts.precision = 1 (td_attn_h.h)
     auto cleanup = [&]() {
@@ -121,15 +122,15 @@ extern "C" int tdnet_op_attention(const float* q, const float* k, const float* v
     };
     int rc = 0;
     if (ln_out && (dev_alloc(&part, (size_t)2 * attn_strips(Lq, DV) * DV) || dev_alloc(&mean, DV) || dev_alloc(&rstd, DV))) rc = -1;   // + plane LayerNorm of the result from the epilogue's strip statistics
-    if (!rc && (online == 16 || online == 17) && dev_alloc(&vt, (size_t)(online == 17 ? 3 : 1) * DV * attn_lkpad(Lk))) rc = -1;   // 17: the split kernel of precision 2 (td_attn_b3.h)
-    if (!rc && online != 16 && online != 17 && !padded && attn_vp_rows(Lk) != Lk) {    // the kernels' contract: V' padded to attn_vp_rows(Lk) zero rows
+    if (!rc && (online == 16 || split) && dev_alloc(&vt, (size_t)(split ? 3 : 1) * DV * attn_lkpad(Lk))) rc = -1;
+    if (!rc && online != 16 && !split && !padded && attn_vp_rows(Lk) != Lk) {    // the kernels' contract: V' padded to attn_vp_rows(Lk) zero rows
         const size_t rows = (size_t)attn_vp_rows(Lk);
         if (dev_alloc(&vpad, rows * DV)) rc = -1;
         else if (hipMemsetAsync(vpad, 0, rows * DV * sizeof(float), s) != hipSuccess ||
                  hipMemcpyAsync(vpad, vp, (size_t)Lk * DV * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = td_fail("tdnet_op_attention: copy failed");
         else vp = vpad;
     }
-    if (!rc) rc = run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online >= 16 ? 1 : online, part, vt, slices, false, online == 17);
+    if (!rc) rc = run_attention(nullptr, q, k, vp, bias, resid, Lq, Lk, DV, out, s, online >= 16 ? 1 : online, part, vt, slices, false, online == 17 ? 1 : online == 18 ? 3 : online == 19 ? 2 : 0);
     if (!rc && ln_out) run_layernorm(nullptr, out, Lq, DV, ln_g, ln_b, part, mean, rstd, ln_out, s, attn_strips(Lq, DV));
     if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) rc = td_fail("tdnet_op_attention: device error");
     cleanup();

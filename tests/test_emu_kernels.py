@@ -631,6 +631,14 @@ def test_split_gemm_precision2_ops(lib):
     opcheck.attention(lib, MEM, 200, 131, 128, True, False, qk_scale=2.0, online=17)
     opcheck.attention(lib, MEM, 130, 193, 128, True, True, spike=True, online=17, ln=True)
     opcheck.attention(lib, MEM, 70, 300, 512, online=17, ramp=True, ln=True)
+    # the 64-query / eight-wave form of the 512-channel kernel (k_attention_b3w; picked by a frame for Lq >= 16384, forced here by online = 18): a workgroup's second
+    # query tile empty, partly filled and full; strips past Lq not written; a single key; keys sorted by growing score (the reference moves in both query tiles)
+    opcheck.attention(lib, MEM, 45, 6, 512, online=18)
+    opcheck.attention(lib, MEM, 300, 200, 512, spike=True, online=18)
+    opcheck.attention(lib, MEM, 97, 130, 512, True, True, spike=True, online=18, ln=True)
+    opcheck.attention(lib, MEM, 70, 300, 512, online=18, ramp=True, ln=True)
+    opcheck.attention(lib, MEM, 64, 128, 512, online=18, ln=True)
+    opcheck.attention(lib, MEM, 33, 1, 512, online=18, ln=True)
     # the Cout <= 64 convs of precision 2 (td_conv_ad_b3.h, fusion bit 524288: A straight from global memory, weights by LDS-DMA on three buffers): ResNet
     # layer1's shape, an odd number of K steps with stride / dilation / ragged channels, a single step, the strided 1x1 form, the packed-row 7x7 stem
     o2 = {"precision": 2}
