@@ -49,43 +49,47 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, TD_ADB3_OCC) k_conv_adirect_b3(ConvArgs p) 
     // raw A fragments of step la_step: raw[2 b + e] = channels 16 b + 8 half + 4 e .. + 3 of the step's 32; advanced after every call
     struct ASet { f32x4 raw[4]; u32x4 h0, m0, l0; };                  // a step's raw fragments and the three parts of its k block 0
     int la_step = 0, la_chunk = 0, la_tap = 0;
-    auto load_a = [&](ASet& a) {
+    unsigned la_off = 0;                                              // this lane's byte offset of step la_step's 32 floats (or out of range)
+    auto addr_a = [&]() {
         const bool live = la_step < p.nsteps;                       // wave-uniform: past the last step nothing is consumed -> read zeros
         if (STEM == 2) {                                            // kernel row la_step: floats 16 b + 8 half + 4 e .. + 3 of its 32 (4-byte aligned 16-byte loads)
-            const unsigned off = (live && m < p.M) ? a_off + (unsigned)(la_step * p.W * 3) * 4u : TD_BUF_OOB;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) a.raw[2 * b + e] = td_buf_ld4(in_buf, off, (unsigned)(b * 64 + e * 16));
-            ++la_step;
+            la_off = (live && m < p.M) ? a_off + (unsigned)(la_step * p.W * 3) * 4u : TD_BUF_OOB;
             return;
         }
         const int ky = la_tap / KS;
         const int dy = ky * p.dil, dx = (la_tap - ky * KS) * p.dil;
         const int iy = a_by + dy, ix = a_bx + dx;
         const bool ok = live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const unsigned off = ok ? a_off + (unsigned)((dy * p.W + dx) * p.Cin + la_chunk * 32) * 4u : TD_BUF_OOB;
-        if (!(TD_ADB3_SKIP & 2) || la_step == 0) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) a.raw[2 * b + e] = td_buf_ld4(in_buf, off, (unsigned)(b * 64 + e * 16));
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) TD_PIN(a.raw[q]);
-        }
+        la_off = ok ? a_off + (unsigned)((dy * p.W + dx) * p.Cin + la_chunk * 32) * 4u : TD_BUF_OOB;
+    };
+    auto piece_a = [&](ASet& a, int q) {                             // raw[q], q = 2 b + e
+        if (!(TD_ADB3_SKIP & 2) || la_step == 0) a.raw[q] = td_buf_ld4(in_buf, la_off, (unsigned)((q >> 1) * 64 + (q & 1) * 16));
+        else TD_PIN(a.raw[q]);
+    };
+    auto end_a = [&]() {
         ++la_step;
-        if (++la_tap == NTAPS) { la_tap = 0; ++la_chunk; }
+        if (!STEM && ++la_tap == NTAPS) { la_tap = 0; ++la_chunk; }
+    };
+    auto load_a = [&](ASet& a) {
+        addr_a();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece_a(a, q);
+        end_a();
     };
     int lb_step = 0, lb_buf = 0;                                      // the weights of step lb_step go to LDS buffer lb_buf = lb_step % 3
-    auto issue_w = [&]() {
+    auto piece_w = [&](int i) {
         const bool live = lb_step < p.nsteps;
         if (!(TD_ADB3_SKIP & 8) || lb_step < 3)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
             td_buf_ld16_lds(w_buf, smem + lb_buf * BUF_BYTES + (wave + 4 * i) * 1024, live ? b_off[i] : TD_BUF_OOB, live ? (unsigned)lb_step * w_step_bytes : 0u);
+    };
+    auto end_w = [&]() {
         ++lb_step;
         lb_buf = lb_buf == 2 ? 0 : lb_buf + 1;
+    };
+    auto issue_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) piece_w(i);
+        end_w();
     };
 
     f32x16 acc[NT];
@@ -122,7 +126,7 @@ TD_KERNEL void TD_LAUNCH_BOUNDS(256, TD_ADB3_OCC) k_conv_adirect_b3(ConvArgs p) 
     // the weights two steps ahead (group 0), the split of this step's k block 1 (groups 0-3) and of the next step's k block 0 (groups 6-9), the B fragments one
     // to three groups ahead of their MFMAs.  One bare barrier at the top: it publishes the weights issued during the previous step (each wave waits for its own
     // pieces first) to the step AFTER this one's -- three buffers, so nothing written after it is read before the next barrier and nothing read after it is
-    // overwritten before the next barrier.
+    // overwritten before the next barrier.  (The step's seven vector-memory requests one per group instead of all in group 0: 59.5 vs 60.0 us, profiles/r06ad_*.)
     auto kstep = [&](ASet& C, ASet& N) {
         TD_WAIT_VM_PIECES(0);
         TD_BARRIER_RAW();
