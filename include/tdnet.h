@@ -111,7 +111,8 @@ typedef struct tdnet_opts {
                                      arithmetic in the same order: bit-identical low-resolution logits.
                                 524288 = precision 2 only (default, round 6): the Cout <= 64 convs that read their A operand straight from global memory (bit 32:
                                      ResNet layer1, the packed-row 7x7 stem of bit 65536) on the bf16 MFMA with both operands as three bf16 parts
-                                     (td_conv_ad_b3.h): layer1's conv 85 -> 59 us at 1024x2048, errors against fp64 at or below the fp32 kernel's. */
+                                     (td_conv_ad_b3.h): layer1's conv 85 -> 59 us at 1024x2048, errors against fp64 at or below the fp32 kernel's; also the
+                                     direct convs of 65 .. 128 output channels (the strided convs of layer2.0, a deep stem's 64 -> 128 conv) as two 64-column tiles. */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
                                 1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

@@ -164,6 +164,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
     if (L.h16 && L.stem) conv_launch_stem_h(a, L.out16, s);
     else if (L.h16 && L.rh) launch_conv_dma_forms(L, a, s);
     else if (L.h16) conv_launch_h(a, L.tile, L.KS, L.in16, L.out16, s);
+    else if (L.adirect && L.b3 && !L.stem_rows) conv_launch_adirect_b3(a, L.KS, 0, s);   // precision 2, narrow convs (incl. the stride-1 1x1 ones kept off the GEMM route)
     else if (L.pers && L.KS == 1 && L.stride == 1 && !L.stem && gemm_supports(L.Cin)) {
         GemmArgs ga;
         ga.a = in; ga.wp = L.d_wp; ga.bias = L.d_bias; ga.resid = resid; ga.out = out;
@@ -175,7 +176,7 @@ static int run_conv(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         r.H = stem_rows_hp(H); r.W = stem_rows_wp(W); r.Cin = 3; r.pad = 0;
         if (L.b3) conv_launch_adirect_b3(r, L.KS, 2, s);
         else conv_launch_adirect(r, L.KS, 2, s);
-    } else if (L.adirect && L.b3) conv_launch_adirect_b3(a, L.KS, 0, s);
+    }
     else if (L.adirect) conv_launch_adirect(a, L.KS, L.stem ? 1 : 0, s);
     else conv_launch(a, L.tile, L.KS, L.stem, s);
     prof_end(n, s);

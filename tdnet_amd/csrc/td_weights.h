@@ -60,8 +60,18 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     }
     L.h16 = o.precision == 1 && !stem && Cin % 64 == 0;
     const bool stem16 = o.precision == 1 && stem && KS == 7 && stride == 2 && Cout <= 64;    // fp16-MFMA stem (td_conv_h.h)
-    const bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && o.gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
+    bool gemm1x1 = !L.h16 && !stem && KS == 1 && stride == 1 && o.gemm_persistent && gemm_supports(Cin);   // run_conv's persistent-GEMM route
+    // precision 2: a stride-1 1x1 conv to <= 128 channels on a large map (a Bottleneck's conv1 in layers 1-2) is too narrow for the split GEMM's 128-column tiles
+    // and would stay on the fp32 GEMM: it runs on the split DIRECT kernel instead (td_conv_ad_b3.h with KS = 1: a lane's A row is contiguous)
+    // (td2-psp50 769x1537 169.2 -> 170.9 frames/s, td4-psp18 unchanged: profiles/r06ah_*)
+    if (gemm1x1 && forced_tile < 0 && o.precision >= 2 && (o.fusion & 32) && (o.fusion & 524288) && Cout <= 128 && M >= 8192 && gemm_b3_supports(Cin, Cout) &&
+        !gemm_b3_pick(M, 1, Cout) && conv_adirect_b3_supports(CT_128x64, Cin, KS, stem)) gemm1x1 = false;
     L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout, deep) : conv_pick_tile((int)M, Cout, deep);
+    // precision 2: a direct conv of up to 128 output channels (a strided 3x3 / 1x1 of layer2.0, a deep stem's 64 -> 128 conv) runs as two 64-column tiles of the
+    // split direct kernel (td_conv_ad_b3.h; A is loaded once per column tile) instead of the fp32 128-column kernel
+    // (td2-psp50 769x1537 164.4 -> 168.0 frames/s, td4-psp18 1024x2048 351.1 -> 352.5, two processes each way on one box: profiles/r06ah_*)
+    if (forced_tile < 0 && o.precision >= 2 && (o.fusion & 32) && (o.fusion & 524288) && !L.h16 && !stem && !gemm1x1 && Cout <= 128 &&
+        conv_adirect_b3_supports(CT_128x64, Cin, KS, stem)) L.tile = CT_128x64;
     // fp16 mode, ResNet layer1 (64 -> 64, 3x3 stride 1): packed for the 128-wide two-wave-column tile, of which the narrow LDS-DMA kernel
     // runs the first 64-channel column (finalize_block's dma(); the second column is all padding and is never launched)
     if (L.h16 && forced_tile < 0 && !stem16 && (o.fusion & 32768) && !(o.fusion & 128) && KS == 3 && stride == 1 && Cout == 64 && Cin % 64 == 0)

@@ -648,6 +648,9 @@ def test_split_gemm_precision2_ops(lib):
     opcheck.conv(lib, MEM, 9, 17, 64, 40, 1, 2, 1, 2, True, opts=o2)
     for H, W in ((33, 65), (18, 23), (7, 9)):
         opcheck.stem(lib, MEM, H, W, opts=o2)
+    opcheck.conv(lib, MEM, 13, 21, 64, 128, 3, 2, 1, 1, False, opts=dict(o2, winograd=0))   # 65 .. 128 output channels: two 64-column tiles (layer2.0's strided conv)
+    opcheck.conv(lib, MEM, 9, 17, 64, 100, 1, 2, 1, 0, True, opts=o2)                       # the strided 1x1 downsample, ragged second tile
+    opcheck.conv(lib, MEM, 96, 96, 64, 64, 1, 1, 1, 1, True, opts=o2)                       # a stride-1 1x1 conv to <= 128 channels on >= 8192 pixels: kept off the GEMM route
     # the size heuristic of precision 2: a GEMM of fewer than 256 tiles stays on the exact-fp32 kernels, bit for bit
     import ctypes
     g = np.random.default_rng(3)

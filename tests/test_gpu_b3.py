@@ -73,6 +73,11 @@ def test_split_gemm_operators_are_as_accurate_as_the_fp32_kernels():
     opcheck.conv(lib, mem, 61, 77, 64, 64, 3, 1, 1, 1, True, opts={"precision": 2})            # k_conv_adirect_b3: layer1, ragged rows
     opcheck.conv(lib, mem, 40, 52, 96, 40, 3, 2, 2, 2, False, opts={"precision": 2})           # stride 2, dilation 2, 27 steps (odd), ragged channels
     opcheck.conv(lib, mem, 33, 65, 64, 64, 1, 2, 1, 0, False, opts={"precision": 2})           # the strided 1x1 form
+    opcheck.conv(lib, mem, 129, 257, 64, 128, 3, 2, 1, 1, False, opts={"precision": 2})        # 65 .. 128 output channels as two 64-column tiles: layer2.0's strided conv
+    opcheck.conv(lib, mem, 97, 193, 64, 128, 3, 1, 1, 1, False, opts={"precision": 2, "winograd": 0})   # a deep stem's 64 -> 128 conv (Cin < 128: never Winograd by default either)
+    opcheck.conv(lib, mem, 40, 52, 64, 100, 1, 2, 1, 0, True, opts={"precision": 2})           # strided 1x1 downsample with a residual, ragged second tile
+    opcheck.conv(lib, mem, 97, 193, 256, 64, 1, 1, 1, 1, False, opts={"precision": 2})         # a Bottleneck's conv1 in layer1 (stride-1 1x1, 18721 pixels): the split direct kernel, not the fp32 GEMM
+    opcheck.conv(lib, mem, 97, 193, 512, 128, 1, 1, 1, 1, True, opts={"precision": 2})         # layer2's conv1: two 64-column tiles, 16 K steps
     for H, W in ((131, 259), (224, 224), (7, 9)):                                               # the packed-row 7x7 stem on the split kernel
         opcheck.stem(lib, mem, H, W, opts={"precision": 2})
     # the new kernels really ran (their sums are not the fp32 MFMA's bit for bit) and a handle without the bit keeps the exact-fp32 ones
