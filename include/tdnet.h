@@ -47,7 +47,7 @@ typedef struct tdnet_cfg {
  * tdnet_opts_default() fills the defaults; fields left 0 by a caller that memset()s the struct select the plain variants. */
 #define TDNET_WINOGRAD_DEFAULT 3
 #define TDNET_ATTENTION_DEFAULT 2
-#define TDNET_FUSION_DEFAULT 1024038  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072 | 262144 | 524288; bit 524288 (precision 2 only) since round 6: 322.9 -> 339.6 frames/s at C3 with precision 2, 441.8 -> 458.9 at 769x1537, td2-psp34 720x960 446.9 -> 469.0 (profiles/r06z_*); bit 262144 since round 6: 276.4 -> 277.2 frames/s at C3, 393.6 -> 394.3 at 769x1537, one launch fewer, bit-identical (profiles/r06p_*); bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
+#define TDNET_FUSION_DEFAULT 2072614  /* 2 | 4 | 32 | 8192 | 32768 | 65536 | 131072 | 262144 | 524288 | 1048576; bit 1048576 (fp32 / precision 2) since round 6: 273.9 -> 275.4 frames/s at C3, bit-identical (profiles/r06al_*); bit 524288 (precision 2 only) since round 6: 322.9 -> 339.6 frames/s at C3 with precision 2, 441.8 -> 458.9 at 769x1537, td2-psp34 720x960 446.9 -> 469.0 (profiles/r06z_*); bit 262144 since round 6: 276.4 -> 277.2 frames/s at C3, 393.6 -> 394.3 at 769x1537, one launch fewer, bit-identical (profiles/r06p_*); bit 32 since the end of round 3: 270.1 -> 274.4 frames/s at C3, twice on one box (profiles/r03y_*);
                                        bits 8192 and 32768 (precision 1 only) since round 4: 1042 -> 1053 -> (see DESIGN) frames/s at 720x960 fp16, bit-identical
                                        (profiles/r04j_*, r04x_*); bit 65536 (fp32 only) since round 5: the 7x7 stem 168 -> 125 us at 1024x2048, frames/s +0.2 % (td4
                                        1024x2048, where the stem runs beside the cache-only attention chain) ... +1.5 % (td2 1024x2048) (profiles/r05j_*);
@@ -112,7 +112,10 @@ typedef struct tdnet_opts {
                                 524288 = precision 2 only (default, round 6): the Cout <= 64 convs that read their A operand straight from global memory (bit 32:
                                      ResNet layer1, the packed-row 7x7 stem of bit 65536) on the bf16 MFMA with both operands as three bf16 parts
                                      (td_conv_ad_b3.h): layer1's conv 85 -> 59 us at 1024x2048, errors against fp64 at or below the fp32 kernel's; also the
-                                     direct convs of 65 .. 128 output channels (the strided convs of layer2.0, a deep stem's 64 -> 128 conv) as two 64-column tiles. */
+                                     direct convs of 65 .. 128 output channels (the strided convs of layer2.0, a deep stem's 64 -> 128 conv) as two 64-column tiles.
+                                1048576 = fp32 / precision 2 (default, round 6): the cache-only attention chain of a frame (side stream) forks in front of the backbone's first
+                                     dilated block (layer3) instead of at the frame's start: it then overlaps the large Winograd GEMMs, not the stem and layer1.
+                                     Same launches, same results bit for bit; +0.2 ... 1.0 % by workload; ignored in the fp16 mode (-2.6 % there). */
     int32_t overlap;         /* bit mask (default TDNET_OVERLAP_DEFAULT), on BasicBlock backbones:
                                 1 = the trailing run of even-dilation convs (ResNet layers 3-4: resnet.py:181-198) is split into its
                                     even-row and odd-row halves -- a dilated conv maps a row parity onto itself, so the halves are independent

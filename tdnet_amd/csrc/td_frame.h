@@ -113,7 +113,8 @@ static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t 
     return 0;
 }
 
-static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s) {
+static int launch_chain_now(tdnet* n, PathLayers& L, hipStream_t s);
+static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s, int chain_at = -1) {   // chain_at >= 0: fork the cache-only chain in front of that backbone block
     const int DV = n->DV;
     // backbone (resnet.py:204-215)
     run_stem_pre(n, img, n->H, n->W, n->img4, s, n->opts.fusion, L.stem.stem_rows);
@@ -128,6 +129,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     int ch = n->H2, cw = n->W2;
     for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
         BlockLayers& B = L.blocks[bi];
+        if ((int)bi == chain_at && launch_chain_now(n, L, s)) return -1;
         if ((int)bi == n->seg_block) {                                 // the rest of the backbone as two row-parity chains
             if (ch != n->h || cw != n->w) return td_fail("internal: the chained run is not at the output resolution");
             TD_TRY(run_parity_chains(n, L, ch, cw, s));
@@ -330,8 +332,17 @@ static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream
     TD_TRY(place_chain_stream(n, s));
     *started = true;
     const bool steady = n->cfg.model != 1 && (int)n->fifo.size() >= n->FIFO;
-    if (steady && launch_chain_now(n, L, s)) return -1;               // overlaps the backbone below
-    if (encode_frame(n, L, img, s)) return -1;
+    // The cache-only chain overlaps the backbone: forked at the frame's start, or (fusion bit 1048576, default; fp32 and precision 2) in front of the first dilated block =
+    // layer3, where it shares the chip with the large Winograd GEMMs instead of slowing the stem and layer1 (bound by the vector-memory path the chain's attention also
+    // loads).  Interleaved in one process (profiles/r06al_*): td4-psp18 1024x2048 273.9 -> 275.4 (precision 2: 333.9 -> 335.4), 769x1537 392.7 -> 393.6 (450.2 -> 454.8),
+    // 512x1024 838.5 -> 841.9, td2-psp50 131.5 -> 131.8; the fp16 mode LOSES (1024x2048 705.3 -> 686.7, 720x960 neutral) and keeps the early fork.  Same work, same
+    // results bit for bit.  Forking in front of layer1's second block or of layer2: -1.0 % / -0.7 % with precision 2 (TDNET_CHAIN_AT experiment, visit r6ak).
+    int chain_at = -1;
+    if (steady && (n->opts.fusion & 1048576) && n->opts.precision != 1)
+        for (size_t b = 0; b < n->bspec.size() && b < L.blocks.size(); ++b)
+            if (n->bspec[b].dil1 > 1 || n->bspec[b].dil2 > 1) { chain_at = (int)b; break; }
+    if (steady && chain_at < 0 && launch_chain_now(n, L, s)) return -1;
+    if (encode_frame(n, L, img, s, chain_at)) return -1;
     if (n->cfg.model == 1) return 0;
     return finish_frame(n, L, steady, s);
 }

@@ -732,3 +732,30 @@ def test_classifier_inside_the_head_output_transform(lib, name, P, bb, opts):
         e.close()
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
     assert launches[0] - launches[1] == 1, launches
+
+
+def test_cache_chain_forked_in_front_of_layer3_is_bit_identical(lib):
+    """tdnet_opts.fusion bit 1048576 (round 6, default for fp32 / precision 2): the cache-only attention chain of a steady-state frame is enqueued on the side stream in
+    front of the backbone's first dilated block instead of at the frame's start (td_frame.h forward_lowres_impl).  Same kernels on the same inputs: warm-up and
+    steady-state frames bit for bit, same launch count -- fp32 with the row-parity chains forced on (three streams), and the fp16 mode, which ignores the bit."""
+    H, W = 33, 65
+    spec = arch.model_spec("td4", 19, "resnet18")
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
+    for opts in ({"overlap": 41 | 4}, {"precision": 1}):
+        base = lib.opts(**opts).fusion
+        assert base & 1048576
+        outs, launches = [], []
+        for fusion in (base & ~1048576, base):
+            e = Engine(4, 18, 19, H, W, 0, lib=lib, opts=dict(opts, fusion=fusion))
+            e.load_state_dict(sd)
+            o = []
+            for t, x in enumerate(weights.synth_video(H, W, 6, seed=2)):
+                out = np.zeros((1, 19, H, W), np.float32)
+                e.forward(x, t % 4, out)
+                o.append(out)
+            outs.append(o)
+            launches.append(e.last_launch_count())
+            e.close()
+        assert all(np.array_equal(a, b) for a, b in zip(*outs)), opts
+        assert launches[0] == launches[1], launches
+
