@@ -83,8 +83,7 @@ static int run_ds_rows(tdnet* n, const ConvLayer& L, const float* in, int H, int
 // streams, bit-identical -- and measured 1121 -> 1050 frames/s at 720x960: a half-height conv takes exactly as long as the whole one (a
 // workgroup's time is its K-loop latency chain; the chip has CUs to spare either way), the two chains run in lockstep, nothing overlaps.
 // profiles/r05a_*row_parity_chains*; removed, last commit with that code: 8dff3b9.)
-static int launch_chain_now(tdnet* n, PathLayers& L, hipStream_t s);
-static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s, int chain_at = -1) {
+static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t s) {
     const int sb = n->seg_block, nblk = (int)L.blocks.size();
     hipStream_t st[2] = {s, n->chain2};
     float* Vw[2] = {n->wino_v, n->wino_v2};
@@ -99,7 +98,6 @@ static int run_parity_chains(tdnet* n, PathLayers& L, int h, int w, hipStream_t 
     for (int b = sb; b < nblk; ++b) {
         BlockLayers& B = L.blocks[b];
         const float* xin = b == sb ? n->bx : n->seg_x[b - 1];
-        if (b == chain_at && b > sb && launch_chain_now(n, L, s)) return -1;   // EXPERIMENT
         for (int c = 0; c < 2; ++c) {
             WinoChunk ck; ck.ny = 2; ck.cy = c;
             if (!(b == sb && n->seg_conv == 1)) TD_TRY(run_wino(n, B.c1, xin, h, w, nullptr, n->seg_t[b], st[c], nullptr, ck, Vw[c], Mw[c]));
@@ -132,8 +130,7 @@ static int encode_frame(tdnet* n, PathLayers& L, const float* img, hipStream_t s
     for (size_t bi = 0; bi < L.blocks.size(); ++bi) {
         BlockLayers& B = L.blocks[bi];
         if ((int)bi == chain_at && launch_chain_now(n, L, s)) return -1;
-        if ((int)bi == n->seg_block) {
-            if (chain_at > n->seg_block) { TD_TRY(run_parity_chains(n, L, ch, cw, s, chain_at)); break; }   // EXPERIMENT                                 // the rest of the backbone as two row-parity chains
+        if ((int)bi == n->seg_block) {                                 // the rest of the backbone as two row-parity chains
             if (ch != n->h || cw != n->w) return td_fail("internal: the chained run is not at the output resolution");
             TD_TRY(run_parity_chains(n, L, ch, cw, s));
             break;
@@ -339,12 +336,12 @@ static int forward_lowres_impl(tdnet* n, const float* img, int pos_id, hipStream
     // layer3, where it shares the chip with the large Winograd GEMMs instead of slowing the stem and layer1 (bound by the vector-memory path the chain's attention also
     // loads).  Interleaved in one process (profiles/r06al_*): td4-psp18 1024x2048 273.9 -> 275.4 (precision 2: 333.9 -> 335.4), 769x1537 392.7 -> 393.6 (450.2 -> 454.8),
     // 512x1024 838.5 -> 841.9, td2-psp50 131.5 -> 131.8; the fp16 mode LOSES (1024x2048 705.3 -> 686.7, 720x960 neutral) and keeps the early fork.  Same work, same
-    // results bit for bit.  Forking in front of layer1's second block or of layer2: -1.0 % / -0.7 % with precision 2 (TDNET_CHAIN_AT experiment, visit r6ak).
+    // results bit for bit.  Forking in front of layer1's second block or of layer2: -1.0 % / -0.7 % with precision 2; one / two / three blocks INSIDE the row-parity run
+    // (layer3's second block, layer4's blocks): 278.1 -> 275.5 / 275.3 / 273.7 fp32 (experiments TDNET_CHAIN_AT / TDNET_CHAIN_SHIFT, visits r6ak, r6am).
     int chain_at = -1;
     if (steady && (n->opts.fusion & 1048576) && n->opts.precision != 1)
         for (size_t b = 0; b < n->bspec.size() && b < L.blocks.size(); ++b)
             if (n->bspec[b].dil1 > 1 || n->bspec[b].dil2 > 1) { chain_at = (int)b; break; }
-    { static const int shift = getenv("TDNET_CHAIN_SHIFT") ? atoi(getenv("TDNET_CHAIN_SHIFT")) : 0; if (chain_at >= 0 && n->seg_block >= 0) chain_at += shift; }   // EXPERIMENT
     if (steady && chain_at < 0 && launch_chain_now(n, L, s)) return -1;
     if (encode_frame(n, L, img, s, chain_at)) return -1;
     if (n->cfg.model == 1) return 0;
