@@ -102,7 +102,11 @@ static int run_wino(tdnet* n, const ConvLayer& L, const float* in, int H, int W,
         GemmArgs ga;
         ga.a = V; ga.wp = L.d_wp; ga.bias = L.d_zero; ga.resid = nullptr; ga.out = Mb;
         ga.M = (int)Tc; ga.N = L.Cout; ga.NPad = L.CoutPad; ga.K = L.Cin; ga.nbatch = nb; ga.act = 0; ga.tiles_m = ga.tiles_n = 0; ga.MP = (int)TP;
-        if (L.b3) gemm_b3_launch(ga, L.pers > 1 ? L.pers : 0, s);
+        // the split GEMM's persistent grid: 512 workgroups (two per CU); a row-parity CHUNK's GEMM -- two of them are in flight, one per chain -- takes 320: of
+        // layer 4's 576 tiles 256 workgroups then walk two and the sibling's first workgroups find a free slot at once.  Frame with precision 2 at 1024x2048, by grid of the
+        // chunks' GEMMs (profiles/r06ao_*): 512: 339.4, 288: 338.6, 320: 346.0, 352: 344.7, 384: 344.5, 448: 342.1 frames/s.
+        if (L.b3) gemm_b3_launch(ga, L.pers > 1 ? L.pers : chunked ? 320 : 0, s);
+        // (the fp32 kernel keeps its 768 workgroups for the chunks too: 448 / 512 / 576 / 640 / 1024 gave 273.1 / 273.4 / 271.8 / 275.5 / 274.3 against 278.9 frames/s)
         else if (L.gdma && gemm_dma_supports(L.Cin, L.Cout, L.tile)) gemm_dma_launch(ga, L.pers > 1 ? L.pers : 0, s);
         else gemm_launch(ga, L.tile, L.pers > 1 ? L.pers : 0, s);
     } else {
