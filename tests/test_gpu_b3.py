@@ -129,6 +129,12 @@ def test_precision2_meets_the_fp32_gate_native_769x1537_and_td2():
     _vs_oracle("td2", "resnet18", 1024, 2048, 3, kernel_opts={"precision": 2})         # configs[1]
 
 
+def test_precision2_bottleneck_backbone_with_the_narrow_conv_routings():
+    """td2-psp50 at 385x769: the deep stem's 64 -> 128 conv as two column tiles of the split direct kernel, layer1's stride-1 1x1 convs to 64 channels (18721
+    pixels: above the 8192-pixel rule) on k_conv_adirect_b3<1> instead of the fp32 GEMM, the wide 1x1 convs on the split GEMM where its size rule lets them."""
+    _vs_oracle("td2", "resnet50", 385, 769, 3, kernel_opts={"precision": 2})
+
+
 def test_precision2_split_kernel_forced_on_small_maps():
     _vs_oracle("td4", "resnet18", 257, 513, 8, kernel_opts={"precision": 3})           # every path cold and in steady state; ragged 256-row tiles everywhere
     _vs_oracle("td2", "resnet50", 129, 257, 4, kernel_opts={"precision": 3})           # Bottleneck backbone: the 1x1 convs (K up to 2048) on the split kernel
