@@ -345,8 +345,11 @@ static inline void gemm_b3_launch(GemmArgs a, int grid_cap, hipStream_t s) {
 }
 // Which kernel form for a GEMM of `rows` x N per batch: 0 = none -- fewer than one 256 x 128 tile per CU, where the exact-fp32 kernels with
 // their 64 / 128-row tiles are faster (512 -> 512 on 2048 rows: 22 us against 37; 512 -> 64: 24 against 40; profiles/r06a_*) --, else 1 = the
-// matrix-only form (k_gemm_b3; 0.308 ms against 0.322 for the loader-wave form on layer 4's 512 -> 512 conv, profiles/r06e_*).
-static inline int gemm_b3_pick(long rows, int nbatch, int N) {
+// matrix-only form (k_gemm_b3; 0.308 ms against 0.322 for the loader-wave form on layer 4's 512 -> 512 conv, profiles/r06e_*).  K: the reduction length (0 = unknown).
+static inline int gemm_b3_pick(long rows, int nbatch, int N, int K = 0) {
     const long tiles = ((rows + 255) / 256) * (gemm_b3_npad(N) / 128) * nbatch;
+    // a deep K amortises the tile's prologue and epilogue: a Bottleneck's 1024 -> 256 conv1 on 18721 rows (148 tiles, fewer than one per CU) is faster here than on the
+    // fp32 GEMM -- psp101 769x1537 97.7 -> 103.2 frames/s with precision 2, td2-psp50 167.5 -> 170.9 (profiles/r06av_*)
+    if (K >= 1024 && tiles >= 128 && N >= 128) return 1;
     return tiles >= 256 && N >= 128 ? 1 : 0;
 }

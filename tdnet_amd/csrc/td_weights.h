@@ -65,7 +65,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
     // and would stay on the fp32 GEMM: it runs on the split DIRECT kernel instead (td_conv_ad_b3.h with KS = 1: a lane's A row is contiguous)
     // (td2-psp50 769x1537 169.2 -> 170.9 frames/s, td4-psp18 unchanged: profiles/r06ah_*)
     if (gemm1x1 && forced_tile < 0 && o.precision >= 2 && (o.fusion & 32) && (o.fusion & 524288) && Cout <= 128 && M >= 8192 && gemm_b3_supports(Cin, Cout) &&
-        !gemm_b3_pick(M, 1, Cout) && conv_adirect_b3_supports(CT_128x64, Cin, KS, stem)) gemm1x1 = false;
+        !gemm_b3_pick(M, 1, Cout, Cin) && conv_adirect_b3_supports(CT_128x64, Cin, KS, stem)) gemm1x1 = false;
     L.tile = forced_tile >= 0 ? (ConvTile)forced_tile : gemm1x1 ? gemm_pick_tile(M, 1, Cout, deep) : conv_pick_tile((int)M, Cout, deep);
     // precision 2: a direct conv of up to 128 output channels (a strided 3x3 / 1x1 of layer2.0, a deep stem's 64 -> 128 conv) runs as two 64-column tiles of the
     // split direct kernel (td_conv_ad_b3.h; A is loaded once per column tile) instead of the fp32 128-column kernel
@@ -90,7 +90,7 @@ static int make_conv_layer(ConvLayer& L, const std::vector<float>& w, const std:
         conv_pack_weights_h(w.data(), Cout, Cin, KS, L.tile, packed.data());
         TD_TRY(dev_alloc((_Float16**)&L.d_wp, packed.size()));
         TD_HIP(hipMemcpy(L.d_wp, packed.data(), packed.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    } else if (o.precision >= 2 && gemm1x1 && gemm_b3_supports(Cin, Cout) && (forced_tile >= 0 || o.precision == 3 || gemm_b3_pick(M, 1, Cout))) {
+    } else if (o.precision >= 2 && gemm1x1 && gemm_b3_supports(Cin, Cout) && (forced_tile >= 0 || o.precision == 3 || gemm_b3_pick(M, 1, Cout, Cin))) {
         // precision 2: a large stride-1 1x1 conv is one GEMM on the bf16 MFMA with its weights as three bf16 parts (td_gemm_b3.h)
         L.b3 = 1;
         L.CoutPad = gemm_b3_npad(Cout);

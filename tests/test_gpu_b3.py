@@ -56,6 +56,7 @@ def test_split_gemm_operators_are_as_accurate_as_the_fp32_kernels():
                                                    (97, 193, 512, 512, 1, 1, False, 0),     # the Encoding's value conv at the native feature size
                                                    (40, 52, 512, 64, 1, 1, True, 2),        # 512 -> 64 (half a tile of padding), residual, LeakyReLU
                                                    (17, 33, 2048, 512, 1, 1, False, 1),     # K = 2048 (a Bottleneck conv1): 128 steps
+                                                   (97, 193, 1024, 256, 1, 1, False, 1),    # psp101 layer3's conv1 at the native size: 148 tiles, on the split GEMM by the deep-K rule
                                                    (128, 256, 64, 64, 3, 1, True, 1),       # ResNet layer1 (k_conv_adirect_b3, fusion bit 524288)
                                                    (37, 53, 96, 48, 3, 3, False, 0)]:       # the same kernel: 27 steps, ragged rows and channels, dilation 3
         vs = [v for v in V if not ((v[0].get("overlap", 0) & 1) and (KS == 1 or dil % 2))]
