@@ -759,3 +759,27 @@ def test_cache_chain_forked_in_front_of_layer3_is_bit_identical(lib):
         assert all(np.array_equal(a, b) for a, b in zip(*outs)), opts
         assert launches[0] == launches[1], launches
 
+
+def test_precision2_with_the_other_options_switched_off(lib):
+    """tdnet_opts.precision = 2 does not rely on the defaults around it: all-direct convs (no Winograd GEMMs to split: the narrow convs and the attention remain), no
+    persistent GEMMs (the split GEMM needs them: its layers fall back to the exact-fp32 kernels), no fusion bits (no A-from-global kernels, so no split direct conv;
+    unfused LayerNorm, separate classifier).  Every combination is a working handle whose logits stay within the fp32 gate of the default's."""
+    H, W = 33, 65
+    spec = arch.model_spec("td4", 19, "resnet18")
+    sd = weights.synth_state_dict(spec, arch.feat_size(H), arch.feat_size(W), 0)
+    ref = None
+    for opts in ({}, {"precision": 2, "winograd": 0}, {"precision": 2, "gemm_persistent": 0}, {"precision": 2, "fusion": 0}):
+        e = Engine(4, 18, 19, H, W, 0, lib=lib, opts=opts)
+        e.load_state_dict(sd)
+        outs = []
+        for t, x in enumerate(weights.synth_video(H, W, 5, seed=2)):
+            out = np.zeros((1, 19, H, W), np.float32)
+            e.forward(x, t % 4, out)
+            outs.append(out)
+        e.close()
+        if ref is None:
+            ref = outs
+        else:
+            d = max(float(np.abs(a - b).max()) for a, b in zip(outs, ref))
+            assert 0.0 < d < 1e-3, (opts, d)
+
