@@ -19,6 +19,9 @@
 #ifndef TD_ADB3_OCC
 #define TD_ADB3_OCC 4
 #endif
+// (A 128-column tile -- NT = 4, a wave holds 32 rows x 128 channels, A loaded and split once for a conv of 65 .. 128 output channels instead of once per 64-column
+// tile; 170 VGPRs, two workgroups per CU -- was built and measured neutral: td4-psp18 352.4 vs 353.3 frames/s, td2-psp50 169.0 vs 168.8, psp101 102.0 vs 101.7
+// (profiles/r06ax_*).  Removed.)
 // STEM = 2: the 7x7 stride-2 stem on the packed-row image (td_conv_ad.h): a K step is one kernel row, 32 consecutive floats of the image row from the output
 // pixel's first tap -- 21 products (7 taps x 3 channels) and 11 columns of zero weights (the fp32 kernel: 24 floats, 3 zero columns).
 template <int KS, int STEM>
